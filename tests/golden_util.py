@@ -1,0 +1,91 @@
+"""Helpers shared by tools/gen_golden.py (writer) and the tests (reader).
+
+Fixtures are kept small: weights are stored once per seed (``weights_s<seed>.npz``)
+and each case stores only a per-parameter scalar multiplier (or the full array
+where a parameter is not a scalar multiple of the seeded one); gradients are
+stored as a digest (sum, abs-sum and 256 fixed sample entries per parameter).
+"""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+NSAMP = 256
+
+
+def sample_index(n):
+    rs = np.random.RandomState(12345)
+    if n <= NSAMP:
+        return np.arange(n)
+    return np.sort(rs.choice(n, NSAMP, replace=False))
+
+
+def digest(arr):
+    """-> f64[2 + nsamp]: sum, abs-sum, samples."""
+    a = np.asarray(arr, dtype=np.float64).reshape(-1)
+    return np.concatenate([[a.sum(), np.abs(a).sum()], a[sample_index(a.size)]])
+
+
+def encode_weights(base, cur):
+    """Per-parameter: scalar c with cur == base * f32(c), else the full array."""
+    out = {}
+    for k, v in cur.items():
+        b = base.get(k)
+        if b is not None and b.shape == v.shape:
+            if np.array_equal(b, v):
+                continue
+            nz = np.flatnonzero(b)
+            if nz.size:
+                c = np.float32(v.reshape(-1)[nz[0]] / b.reshape(-1)[nz[0]])
+                if np.array_equal(b * c, v):
+                    out['wscale.' + k] = c
+                    continue
+        out['w.' + k] = v
+    return out
+
+
+def load_case(name):
+    """-> dict with arrays; 'weights' = reconstructed {param name: f32 array}."""
+    z = dict(np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False))
+    w = {}
+    if 'weights_ref' in z:
+        base = np.load(os.path.join(GOLDEN, str(z['weights_ref']) + '.npz'), allow_pickle=False)
+        strip = str(z['weights_strip']) if 'weights_strip' in z else ''
+        w = {k[len(strip):]: base[k].copy() for k in base.files if k.startswith(strip)}
+    for k in list(z.keys()):
+        if k.startswith('wscale.'):
+            w[k[7:]] = w[k[7:]] * np.float32(z[k])
+        elif k.startswith('w.'):
+            w[k[2:]] = z[k]
+    z['weights'] = w
+    for k in list(z.keys()):
+        if k.endswith('_keep'):
+            z[k] = z[k].astype(np.float32)
+    return z
+
+
+def noise_dict(z, prefix):
+    """Collect '<prefix>.<key>' entries into a noise dict of numpy arrays."""
+    p = prefix + '.'
+    return {k[len(p):]: v for k, v in z.items() if k.startswith(p)}
+
+
+def cfg_dict(z):
+    out = {}
+    for k, v in z.items():
+        if k.startswith('cfg.'):
+            v = v.item() if v.dtype.kind in 'fiu' else str(v)
+            if isinstance(v, float) and v == int(v) and k[4:] in (
+                    'vocab_size', 'seq_length', 'decoding_constraint', 'vse_max_violation',
+                    'vse_no_imgnorm', 'vse_use_abs', 'use_gen_cider_scores'):
+                v = int(v)
+            out[k[4:]] = v
+    return out
+
+
+def gts_list(z):
+    out, o = [], 0
+    for n in z['gts_count']:
+        out.append(z['gts_flat'][o:o + int(n)])
+        o += int(n)
+    return out

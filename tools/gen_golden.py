@@ -1,0 +1,579 @@
+#!/usr/bin/env python3
+"""Golden-vector generator.  RUNS ONLY IN THE BUILD CONTAINER (needs /root/reference).
+
+Imports the reference (vgilad/CooperativeImageCaptioning) UNMODIFIED through the
+compat harness of SURVEY.md Appendix B, drives it with seeded inputs, records every
+random draw it makes (dropout keep masks, Gumbel uniforms, multinomial picks,
+partial-sampling row uniforms) and writes inputs + weights + noise + outputs as small
+.npz fixtures under tests/golden/.  Nothing of the reference's source travels: the
+fixtures are data only.  tests/test_oracle_golden.py replays them against oracle/.
+
+Usage:  python tools/gen_golden.py            (rewrites tests/golden/*.npz)
+"""
+import argparse
+import os
+import pickle
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+OUT = os.path.join(REPO, 'tests', 'golden')
+sys.path.insert(0, os.path.join(REPO, 'tests'))
+import golden_util as GU  # noqa: E402
+
+
+# ----------------------------------------------------------------------------
+# compat harness (torch 0.4.1 code on torch 2.x, no heavy deps) — SURVEY.md Appendix B
+# ----------------------------------------------------------------------------
+def install_harness():
+    sys.dont_write_bytecode = True
+    os.environ['PYTHONDONTWRITEBYTECODE'] = '1'
+    scratch = tempfile.mkdtemp(prefix='cic_golden_')
+    os.makedirs(os.path.join(scratch, 'cider', 'data'))
+    with open(os.path.join(scratch, 'cider', 'data', 'coco-val.p'), 'wb') as f:
+        pickle.dump({}, f)                      # cider_diff unpickles this at import; never used
+    os.chdir(scratch)
+    for m in ['skimage', 'skimage.io', 'skimage.transform', 'h5py', 'lmdb']:
+        sys.modules[m] = types.ModuleType(m)
+    import warnings
+    warnings.filterwarnings('ignore')
+    import scipy.misc
+    scipy.misc.imresize = lambda *a, **k: None
+    sys.path.insert(0, REF)
+    import torch
+    orig_getitem = torch.Tensor.__getitem__
+
+    def getitem(self, idx):                     # 0.4.1: zero_dim_tensor[0] is the scalar
+        if self.dim() == 0 and isinstance(idx, int) and idx == 0:
+            return self
+        return orig_getitem(self, idx)
+    torch.Tensor.__getitem__ = getitem
+    import models                                # noqa: F401
+    import misc.rewards as rewards               # noqa: F401
+    vm = sys.modules['models.VSEFCModel']
+    orig_pack = vm.pack_padded_sequence
+
+    def pack(x, lengths, batch_first=False):
+        return orig_pack(x, [int(l) for l in lengths], batch_first=batch_first)
+    vm.pack_padded_sequence = pack
+    return torch, models, rewards
+
+
+# ----------------------------------------------------------------------------
+# noise recorder: wraps the torch RNG entry points the reference uses
+# ----------------------------------------------------------------------------
+class Recorder:
+    def __init__(self, torch):
+        self.torch = torch
+        self.events = []
+        self.on = False
+        F = torch.nn.functional
+        self._dropout = F.dropout
+        self._rand = torch.rand
+        self._multinomial = torch.multinomial
+        self._uniform_ = torch.Tensor.uniform_
+        rec = self
+
+        def dropout(input, p=0.5, training=True, inplace=False):
+            if not training:
+                return input
+            if p == 0.0:                       # keep the event stream shape-stable
+                if rec.on:
+                    rec.events.append(('dropout', torch.ones_like(input)))
+                return input
+            keep = torch.bernoulli(torch.full_like(input, 1.0 - p))
+            if rec.on:
+                rec.events.append(('dropout', keep.clone()))
+            return input * (keep / (1.0 - p))
+
+        def rand(*a, **k):
+            u = rec._rand(*a, **k)
+            if rec.on:
+                rec.events.append(('rand', u.clone()))
+            return u
+
+        def multinomial(p, n, *a, **k):
+            r = rec._multinomial(p, n, *a, **k)
+            if rec.on:
+                rec.events.append(('multinomial', r.view(-1).clone()))
+            return r
+
+        def uniform_(self_, *a, **k):
+            r = rec._uniform_(self_, *a, **k)
+            if rec.on and self_.dim() == 1:
+                rec.events.append(('uniform', r.clone()))
+            return r
+        F.dropout = dropout
+        torch.rand = rand
+        torch.multinomial = multinomial
+        torch.Tensor.uniform_ = uniform_
+
+    def start(self):
+        self.events = []
+        self.on = True
+
+    def stop(self):
+        self.on = False
+        ev, self.events = self.events, []
+        return ev
+
+
+def split_decodes(events, T, B, E, H, Vp1):
+    """Split a flat event list into per-decode noise dicts (see oracle/speaker.py).
+    A 3-D dropout event (att_embed) opens a new decode; 2-D dropout events then
+    alternate x_keep[t], out_keep[t]; rand / multinomial / uniform events belong to
+    the step whose x_keep comes next."""
+    decs = []
+    cur = None
+    for kind, t in events:
+        if kind == 'dropout' and t.dim() == 3:
+            cur = dict(att_keep=t.numpy(), x_keep=np.ones((T, B, E), np.float32),
+                       out_keep=np.ones((T, B, H), np.float32),
+                       gumbel_u=np.full((T, B, Vp1), 0.5, np.float32),
+                       pick=np.zeros((T, B), np.int64), ps_u=np.ones((T, B), np.float32),
+                       _nx=0, _no=0, has_u=False, has_pick=False, has_ps=False)
+            decs.append(cur)
+        elif kind == 'dropout':
+            if cur['_nx'] == cur['_no']:
+                cur['x_keep'][cur['_nx']] = t.numpy()
+                cur['_nx'] += 1
+            else:
+                cur['out_keep'][cur['_no']] = t.numpy()
+                cur['_no'] += 1
+        elif kind == 'rand':
+            cur['gumbel_u'][cur['_nx']] = t.numpy()
+            cur['has_u'] = True
+        elif kind == 'multinomial':
+            cur['pick'][cur['_nx']] = t.numpy()
+            cur['has_pick'] = True
+        elif kind == 'uniform':
+            cur['ps_u'][cur['_nx']] = t.numpy()
+            cur['has_ps'] = True
+    out = []
+    for d in decs:
+        o = dict(att_keep=d['att_keep'], x_keep=d['x_keep'], out_keep=d['out_keep'])
+        if d['has_u']:
+            o['gumbel_u'] = d['gumbel_u']
+        if d['has_pick']:
+            o['pick'] = d['pick']
+        if d['has_ps']:
+            o['ps_u'] = d['ps_u']
+        out.append(o)
+    return out
+
+
+# ----------------------------------------------------------------------------
+# configs / inputs
+# ----------------------------------------------------------------------------
+def make_opt(**kw):
+    d = dict(vocab_size=97, input_encoding_size=64, rnn_size=64, num_layers=1, drop_prob_lm=0.0,
+             seq_length=16, fc_feat_size=96, att_feat_size=96, att_hid_size=64,
+             retrieval_reward='gumbel', gumbel_temp=1.0, multinomial_temp=1.0,
+             prob_gumbel_softmax=0.5, prob_multinomial_soft=0.5, use_bn=0, decoding_constraint=0,
+             rnn_type='lstm', caption_model='att2in2', vse_model='fc', share_embed=0, phase=None,
+             vse_embed_size=128, vse_no_imgnorm=0, vse_use_abs=0, vse_num_layers=1,
+             vse_rnn_type='gru', vse_pool_type='last', vse_margin=0.2, vse_measure='cosine',
+             vse_max_violation=1, vse_loss_type='contrastive', batch_size=6, vse_loss_weight=0,
+             caption_loss_weight=0, alternating_turn=['speaker', 'listener'],
+             retrieval_reward_weight=0.01, reinforce_baseline_type='gt', only_one_retrieval='off',
+             cider_optimization=0.99, use_gen_cider_scores=0, is_alternating=0, start_from=None,
+             initialize_retrieval=None, df='corpus')
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+def make_batch(torch, opt, K=7, seed=0, ncap=5):
+    g = torch.Generator().manual_seed(1234 + seed)
+    B, V, SL = opt.batch_size, opt.vocab_size, opt.seq_length
+    att = (torch.randn(B, K, opt.att_feat_size, generator=g).abs() * 0.5)
+    fc = att.mean(1)
+    rs = np.random.RandomState(seed)
+
+    def cap():
+        ln = rs.randint(3, SL + 1)
+        toks = np.minimum(rs.zipf(1.3, size=ln), V).astype(np.int64)
+        row = np.zeros(SL, np.int64)
+        row[:ln] = toks
+        return row
+    gts = [np.stack([cap() for _ in range(ncap)]) for _ in range(B)]
+    labels = np.zeros((B, SL + 2), np.int64)
+    masks = np.zeros((B, SL + 2), np.float32)
+    for i in range(B):
+        labels[i, 1:SL + 1] = gts[i][0]
+        nnz = int((gts[i][0] > 0).sum())
+        masks[i, :nnz + 2] = 1
+    return dict(fc_feats=fc, att_feats=att, att_masks=None, labels=torch.from_numpy(labels),
+                masks=torch.from_numpy(masks), gts=gts)
+
+
+def widen(cg, batch):
+    for w in (cg.core.i2h.weight, cg.core.h2h.weight, cg.core.a2c.weight, cg.embed[0].weight,
+              cg.core.attention.h2att.weight, cg.core.attention.alpha_net.weight):
+        w.data.mul_(3.0)
+    cg.logit.weight.data.mul_(6.0)
+    B = batch['att_feats'].shape[0]
+    sc = (0.3 + 0.5 * np.arange(B)).astype(np.float32)
+    import torch
+    batch['att_feats'] = batch['att_feats'] * torch.from_numpy(sc).view(B, 1, 1)
+    batch['fc_feats'] = batch['att_feats'].mean(1)
+
+
+def sd_np(module, prefix=''):
+    return {prefix + k: v.detach().numpy().copy() for k, v in module.state_dict().items()}
+
+
+def flat_noise(prefix, nd):
+    return {f'{prefix}.{k}': v for k, v in nd.items()}
+
+
+_BASES = {}
+
+
+def base_weights(seed, module):
+    """Store the seeded state dict once; later cases reference it by name."""
+    key = f'weights_s{seed}'
+    sd = sd_np(module)
+    if key not in _BASES:
+        _BASES[key] = sd
+        os.makedirs(OUT, exist_ok=True)
+        np.savez_compressed(os.path.join(OUT, key + '.npz'), **sd)
+        print('wrote', key, sum(a.nbytes for a in sd.values()) // 1024, 'KiB')
+    return key
+
+
+def weights_of(key, module, strip=''):
+    base = _BASES[key]
+    cur = {k: v for k, v in sd_np(module).items() if not k.startswith('prev_')}
+    if strip:
+        base = {k[len(strip):]: v for k, v in base.items() if k.startswith(strip)}
+    enc = GU.encode_weights(base, cur)
+    enc['weights_ref'] = np.array(key)
+    if strip:
+        enc['weights_strip'] = np.array(strip)
+    return enc
+
+
+def digests(named_grads):
+    return {'gdig.' + k: GU.digest(g.detach().numpy()) for k, g in named_grads}
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    clean = {}
+    for k, v in arrs.items():
+        if v is None:
+            continue
+        if hasattr(v, 'detach'):
+            v = v.detach().numpy()
+        v = np.asarray(v)
+        if k.endswith('_keep'):
+            v = v.astype(np.uint8)
+        clean[k] = v
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **clean)
+    print('wrote', name, sum(a.nbytes for a in clean.values()) // 1024, 'KiB')
+
+
+def opt_np(opt):
+    keys = ['vocab_size', 'seq_length', 'drop_prob_lm', 'gumbel_temp', 'multinomial_temp',
+            'prob_gumbel_softmax', 'prob_multinomial_soft', 'decoding_constraint', 'vse_margin',
+            'vse_max_violation', 'vse_no_imgnorm', 'vse_use_abs', 'retrieval_reward_weight',
+            'cider_optimization', 'caption_loss_weight', 'vse_loss_weight', 'use_gen_cider_scores']
+    d = {'cfg.' + k: np.float64(getattr(opt, k)) for k in keys}
+    d['cfg.retrieval_reward'] = np.array(opt.retrieval_reward)
+    d['cfg.reinforce_baseline_type'] = np.array(opt.reinforce_baseline_type)
+    d['cfg.only_one_retrieval'] = np.array(opt.only_one_retrieval)
+    d['cfg.vse_pool_type'] = np.array(opt.vse_pool_type)
+    return d
+
+
+# ----------------------------------------------------------------------------
+def main():
+    torch, models, rewards = install_harness()
+    rec = Recorder(torch)
+    torch.set_num_threads(4)
+
+    def build(opt, seed=0, eos_bias=None):
+        torch.manual_seed(seed)
+        m = models.AlternatingJointModel(opt)
+        m._wkey = base_weights(seed, m)
+        if eos_bias is not None:
+            m.caption_generator.logit.bias.data[0] = eos_bias
+        # make biases non-trivial so a dropped bias shows
+        return m
+
+    # ------------------------------------------------------------------ S3 / S4 / S5 kernels
+    opt = make_opt()
+    m = build(opt, 1)
+    cg = m.caption_generator
+    batch = make_batch(torch, opt, K=7, seed=1)
+    B, H = opt.batch_size, opt.rnn_size
+    g = torch.Generator().manual_seed(7)
+    h = torch.randn(B, H, generator=g) * 0.5
+    c = torch.randn(B, H, generator=g) * 0.5
+    att = cg.att_embed(batch['att_feats'])
+    p_att = cg.ctx2att(att)
+    att_res = cg.core.attention(h, att, p_att, None)
+    am = (torch.rand(B, 7, generator=g) > 0.3).float()
+    am[:, 0] = 1
+    att_res_m = cg.core.attention(h, att, p_att, am)
+    xt = torch.randn(B, opt.input_encoding_size, generator=g)
+    out, st = cg.core(xt, None, att, p_att, None, (h.unsqueeze(0), c.unsqueeze(0)))
+    logp = torch.nn.functional.log_softmax(cg.logit(out), dim=1)
+    save('kernels_speaker', **weights_of(m._wkey, cg, 'caption_generator.'), **opt_np(opt), att_raw=batch['att_feats'], h=h, c=c, xt=xt,
+         att=att, p_att=p_att, att_res=att_res, att_masks=am, att_res_masked=att_res_m,
+         out=out, h2=st[0][0], c2=st[1][0], logp=logp)
+
+    # ------------------------------------------------------------------ S1 decodes
+    for name, rr, kw, opts_, eos in [
+        ('sample_greedy_full', 'gumbel', {}, {'sample_max': 1}, None),
+        ('sample_greedy_early', 'gumbel', {}, {'sample_max': 1}, 'search'),
+        ('sample_greedy_dropout', 'gumbel', {'drop_prob_lm': 0.5}, {'sample_max': 1}, 'search'),
+        ('sample_multinomial_plain', 'reinforce', {'drop_prob_lm': 0.5}, {'sample_max': 0, 'temperature': 1}, 2.5),
+        ('sample_multinomial_temp', 'reinforce', {}, {'sample_max': 0, 'temperature': 0.7}, 2.5),
+        ('sample_gumbel_st', 'gumbel', {'drop_prob_lm': 0.5}, {'sample_max': 0, 'temperature': 1, 'use_one_hot': 1}, 2.5),
+        ('sample_gumbel_st_tau', 'gumbel', {'gumbel_temp': 0.5}, {'sample_max': 0, 'temperature': 1, 'use_one_hot': 1}, 3.0),
+        ('sample_multinomial_st', 'multinomial', {'drop_prob_lm': 0.5}, {'sample_max': 0, 'temperature': 1, 'use_one_hot': 1}, 2.5),
+        ('sample_gumbel_ps', 'gumbel_softmax', {'drop_prob_lm': 0.5}, {'sample_max': 0, 'temperature': 1, 'use_one_hot': 1}, 2.5),
+        ('sample_multinomial_ps', 'multinomial_soft', {'multinomial_temp': 1.0}, {'sample_max': 0, 'temperature': 1, 'use_one_hot': 1}, 2.5),
+        ('sample_multinomial_ps_tau', 'multinomial_soft', {'multinomial_temp': 2.0}, {'sample_max': 0, 'temperature': 1, 'use_one_hot': 1}, 2.5),
+        ('sample_constraint', 'reinforce', {'decoding_constraint': 1}, {'sample_max': 1}, None),
+    ]:
+        opt = make_opt(retrieval_reward=rr, **kw)
+        m = build(opt, 2, None if eos == 'search' else eos)
+        cg = m.caption_generator
+        cg.train()
+        batch = make_batch(torch, opt, K=7, seed=2)
+        if eos == 'search':
+            # greedy decodes finish all-at-once for a large EOS bias and never for a small
+            # one: widen the logits, then scan for mixed lengths
+            cg.logit.weight.data.mul_(4.0)
+            found = None
+            for bias in np.linspace(0.0, 3.0, 61):
+                cg.logit.bias.data[0] = float(bias)
+                torch.manual_seed(11)
+                try:
+                    r = cg.sample(batch['fc_feats'], batch['att_feats'], None, dict(opts_))
+                except ValueError:
+                    break
+                lens = (r[0] > 0).sum(1)
+                if 2 <= r[0].shape[1] < opt.seq_length and len(set(lens.tolist())) >= 3:
+                    found = float(bias)
+            assert found is not None, name
+            cg.logit.bias.data[0] = found
+        torch.manual_seed(11)
+        rec.start()
+        res = cg.sample(batch['fc_feats'], batch['att_feats'], None, dict(opts_))
+        ev = rec.stop()
+        T = opt.seq_length + 1
+        nd = split_decodes(ev, T, opt.batch_size, opt.input_encoding_size, opt.rnn_size, opt.vocab_size + 1)
+        nz = flat_noise('noise', nd[0]) if nd else {}
+        outs = {f'res{i}': r for i, r in enumerate(res)}
+        print(name, 'L =', res[0].shape[1])
+        save(name, **weights_of(m._wkey, cg, 'caption_generator.'), **opt_np(opt), **nz, **outs, att_raw=batch['att_feats'],
+             fc=batch['fc_feats'], **{'opt.' + k: np.float64(v) for k, v in opts_.items()})
+
+    # ------------------------------------------------------------------ S2 MLE
+    for name, kw, ss in [('mle_plain', {}, 0.0), ('mle_dropout', {'drop_prob_lm': 0.5}, 0.0),
+                         ('mle_ss', {'drop_prob_lm': 0.5}, 0.25)]:
+        opt = make_opt(**kw)
+        m = build(opt, 3)
+        cg = m.caption_generator
+        cg.train()
+        cg.ss_prob = ss
+        batch = make_batch(torch, opt, K=7, seed=3)
+        torch.manual_seed(12)
+        rec.start()
+        loss = cg(batch['fc_feats'], batch['att_feats'], None, batch['labels'], batch['masks'])
+        ev = rec.stop()
+        loss.backward()
+        T = opt.seq_length + 1
+        # scheduled sampling draws: uniform_ [B] then (maybe) multinomial per step i>=1
+        nd = split_decodes(ev, T, opt.batch_size, opt.input_encoding_size, opt.rnn_size, opt.vocab_size + 1)[0]
+        if 'ps_u' in nd:
+            nd['ss_u'] = nd.pop('ps_u')
+        grads = digests((k, p.grad) for k, p in cg.named_parameters() if p.grad is not None)
+        save(name, **weights_of(m._wkey, cg, 'caption_generator.'), **opt_np(opt), **flat_noise('noise', nd), **grads, loss=loss,
+             ss_prob=np.float64(ss), att_raw=batch['att_feats'], fc=batch['fc_feats'],
+             labels=batch['labels'], masks=batch['masks'])
+
+    # ------------------------------------------------------------------ V1-V4 listener
+    opt = make_opt()
+    m = build(opt, 4)
+    vse = m.vse
+    batch = make_batch(torch, opt, K=7, seed=4)
+    B, V = opt.batch_size, opt.vocab_size
+    img = vse.img_enc(batch['fc_feats'])
+    cap = vse.txt_enc(batch['labels'], batch['masks'])
+    onehot = torch.zeros(B, batch['labels'].shape[1], V + 2)
+    onehot.scatter_(2, batch['labels'].unsqueeze(2), 1.0)
+    g = torch.Generator().manual_seed(5)
+    soft = torch.softmax(torch.randn(B, batch['labels'].shape[1], V + 2, generator=g), 2)
+    soft.requires_grad_(True)
+    cap_oh = vse.txt_enc(onehot, batch['masks'])
+    res = {}
+    for wb in (False, True):
+        for oor in ('off', 'image', 'caption'):
+            res[f'loss_wb{int(wb)}_{oor}'] = vse(batch['fc_feats'], None, batch['labels'], batch['masks'], wb, oor)
+    vse.zero_grad()
+    loss_soft = vse(batch['fc_feats'], None, soft, batch['masks'])
+    loss_soft.backward()
+    grads = digests((k, p.grad) for k, p in vse.named_parameters())
+    save('listener', **weights_of(m._wkey, vse, 'vse.'), **opt_np(opt), fc=batch['fc_feats'], labels=batch['labels'],
+         masks=batch['masks'], img_emb=img, cap_emb=cap, cap_emb_onehot=cap_oh, soft=soft,
+         loss_soft=loss_soft, grad_soft=soft.grad, **grads, **res)
+    for name, kw in [('listener_mean', dict(vse_pool_type='mean', vse_max_violation=0)),
+                     ('listener_max', dict(vse_pool_type='max', vse_use_abs=1, vse_no_imgnorm=1))]:
+        opt2 = make_opt(**kw)
+        m2 = build(opt2, 4)
+        l = m2.vse(batch['fc_feats'], None, batch['labels'], batch['masks'])
+        save(name, **weights_of(m2._wkey, m2.vse, 'vse.'), **opt_np(opt2), fc=batch['fc_feats'], labels=batch['labels'],
+             masks=batch['masks'], loss=l)
+
+    # ------------------------------------------------------------------ R1-R4 CIDEr-D
+    rewards.init_scorer('corpus')
+    rs = np.random.RandomState(9)
+    B, L = 12, 16
+    V = 23
+
+    def rnd_rows(n, Lr, p0):
+        a = rs.randint(1, V, size=(n, Lr))
+        for i in range(n):
+            if rs.rand() < p0:
+                a[i, rs.randint(0, Lr):] = 0
+        return a
+    gen = rnd_rows(B, L, 0.7)
+    gen[0, :] = 0            # EOS first
+    gen[1] = 3               # repeated token, no EOS
+    gen[2, :5] = [4, 5, 4, 5, 4]
+    greedy = rnd_rows(B, 11, 0.7)
+    gts = [rnd_rows(rs.randint(1, 6), 16, 0.9) for _ in range(B)]
+    gts[3][0] = gen[3]       # exact match
+    sc, cg_ = rewards.get_self_critical_reward({'gts': gts}, torch.from_numpy(gen), torch.from_numpy(greedy))
+    cgen, sc2, cg2 = rewards.get_self_critical_reward({'gts': gts}, torch.from_numpy(gen),
+                                                      torch.from_numpy(greedy), True)
+    ngts = np.array([len(x) for x in gts])
+    gts_flat = np.concatenate(gts, 0)
+    save('ciderd', gen=gen, greedy=greedy, gts_flat=gts_flat, gts_count=ngts, reward=sc,
+         cider_greedy=np.float64(cg_), cider_gen=cgen)
+    # seq_per_img = 2 variant
+    gts2 = gts[:6]
+    sc3, cg3 = rewards.get_self_critical_reward({'gts': gts2}, torch.from_numpy(gen), torch.from_numpy(greedy))
+    save('ciderd_spi2', gen=gen, greedy=greedy, gts_flat=np.concatenate(gts2, 0),
+         gts_count=np.array([len(x) for x in gts2]), reward=sc3, cider_greedy=np.float64(cg3))
+
+    # ------------------------------------------------------------------ A1 full joint steps
+    cases = [
+        ('joint_gumbel', dict(retrieval_reward='gumbel'), 'speaker', 2.5),
+        ('joint_gumbel_dropout', dict(retrieval_reward='gumbel', drop_prob_lm=0.5), 'speaker', 2.5),
+        ('joint_gumbel_tau', dict(retrieval_reward='gumbel', gumbel_temp=0.5, only_one_retrieval='image'), 'speaker', 2.5),
+        ('joint_multinomial', dict(retrieval_reward='multinomial', drop_prob_lm=0.5), 'speaker', 2.5),
+        ('joint_gumbel_ps', dict(retrieval_reward='gumbel_softmax', drop_prob_lm=0.5), 'speaker', 2.5),
+        ('joint_multinomial_ps', dict(retrieval_reward='multinomial_soft'), 'speaker', 2.5),
+        ('joint_reinforce_gt', dict(retrieval_reward='reinforce', reinforce_baseline_type='gt', drop_prob_lm=0.5), 'speaker', 2.5),
+        ('joint_reinforce_greedy', dict(retrieval_reward='reinforce', reinforce_baseline_type='greedy'), 'speaker', 2.5),
+        ('joint_reinforce_no', dict(retrieval_reward='reinforce', reinforce_baseline_type='no', cider_optimization=0), 'speaker', 2.5),
+        ('joint_reinforce_listener', dict(retrieval_reward='reinforce', vse_loss_weight=1.0, drop_prob_lm=0.5), 'listener', 2.5),
+        ('joint_gumbel_mle', dict(retrieval_reward='gumbel', caption_loss_weight=0.5, use_gen_cider_scores=1), 'speaker', 2.5),
+        ('joint_plain_all', dict(retrieval_reward='gumbel', caption_loss_weight=1.0, vse_loss_weight=1.0), None, 2.5),
+    ]
+    for name, kw, turn, eos in cases:
+        opt = make_opt(**kw)
+        m = build(opt, 5, None)
+        m.train()
+        batch = make_batch(torch, opt, K=7, seed=5)
+        cg = m.caption_generator
+        # random-init greedy decodes are knife-edge (never EOS / all EOS at t=1, SURVEY.md
+        # Appendix A.16): widen the dynamics so the state, and with it EOS, varies per row
+        widen(cg, batch)
+        shapes = []
+        orig_sample = cg.sample
+
+        def spy(*a, **k):
+            r = orig_sample(*a, **k)
+            shapes.append((r[0].shape[1], sorted(set((r[0] > 0).sum(1).tolist()))))
+            return r
+        cg.sample = spy
+
+        def run():
+            if turn is None:
+                return m(batch['fc_feats'], batch['labels'], batch['masks'], {'gts': batch['gts']},
+                         batch['att_feats'], None)
+            return m(batch['fc_feats'], batch['labels'], batch['masks'], {'gts': batch['gts']},
+                     batch['att_feats'], None, is_alternating=True, alternating_turn=turn)
+        # scan the EOS bias for a run whose decodes have mixed lengths and (if any
+        # greedy decode happens) at least one decode that stops early (L < 16)
+        found = None
+        import contextlib, io
+        for bias in np.linspace(-1.0, 3.0, 81):
+            cg.logit.bias.data[0] = float(bias)
+            torch.manual_seed(13)
+            del shapes[:]
+            try:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    run()
+            except ValueError:
+                continue
+            ok = all(len(sh[1]) >= 2 for sh in shapes) and any(len(sh[1]) >= 3 for sh in shapes)
+            early = any(sh[0] < opt.seq_length for sh in shapes)
+            if ok and (early or found is None):
+                found = float(bias)
+                if early:
+                    break
+        assert found is not None, name
+        cg.logit.bias.data[0] = found
+        if hasattr(m, 'prev_vse'):      # drop the reinforce bookkeeping copies made by the scan
+            del m.prev_vse, m.prev_caption_generator, m.prev_gradDic
+        del shapes[:]
+        torch.manual_seed(13)
+        rec.start()
+        loss = run()
+        print(name, 'eos bias', found, 'decodes (L, lens):', shapes)
+        ev = rec.stop()
+        m.zero_grad()
+        loss.backward()
+        T = opt.seq_length + 1
+        decs = split_decodes(ev, T, opt.batch_size, opt.input_encoding_size, opt.rnn_size, opt.vocab_size + 1)
+        nz = {}
+        for i, d in enumerate(decs):
+            nz.update(flat_noise(f'noise{i}', d))
+        grads = digests((k, p.grad) for k, p in m.named_parameters()
+                        if not k.startswith('prev_') and p.grad is not None)
+        sd = weights_of(m._wkey, m)
+        aux = {}
+        for k, v in m.loss().items():
+            try:
+                aux['aux.' + k] = np.float64(float(v))
+            except Exception:
+                pass
+        print(name, 'loss', float(loss), 'ndecodes', len(decs), 'ngrads', len(grads))
+        save(name, **sd, **opt_np(opt), **nz, **grads, **aux, loss=loss, n_decodes=np.int64(len(decs)),
+             turn=np.array(str(turn)), fc=batch['fc_feats'], att_raw=batch['att_feats'],
+             labels=batch['labels'], masks=batch['masks'],
+             gts_flat=np.concatenate(batch['gts'], 0), gts_count=np.array([len(x) for x in batch['gts']]))
+
+    # ------------------------------------------------------------------ O1 clamp + Adam
+    import misc.utils as rutils
+    torch.manual_seed(3)
+    p0 = torch.randn(37, 5)
+    p = torch.nn.Parameter(p0.clone())
+    optim = torch.optim.Adam([p], lr=5e-4, weight_decay=0)
+    traj = []
+    gs = []
+    for it in range(3):
+        gr = torch.randn(37, 5) * (0.3 if it != 1 else 0.01)
+        gs.append(gr.clone())
+        optim.zero_grad()
+        p.grad = gr.clone()
+        rutils.clip_gradient(optim, 0.1)
+        optim.step()
+        traj.append(p.detach().clone())
+    save('clamp_adam', p0=p0, grads=torch.stack(gs), traj=torch.stack(traj), lr=np.float64(5e-4),
+         grad_clip=np.float64(0.1))
+
+
+if __name__ == '__main__':
+    main()
