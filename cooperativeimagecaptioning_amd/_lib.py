@@ -1,0 +1,90 @@
+"""ctypes binding of libcic_hip.so (the C ABI declared in include/cic.h).
+
+The library is the product: there is no eager/CPU fallback.  If the shared object is
+missing or a symbol is absent, importing this module raises.
+"""
+import ctypes as C
+import os
+import re
+
+import torch  # noqa: F401  (loads the HIP runtime the library links against first)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, 'libcic_hip.so')
+_HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'cic.h')
+
+
+class CicError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise CicError(
+            f'{_LIB_PATH} not found: build it with `python -m cooperativeimagecaptioning_amd.build` '
+            f'(hipcc --offload-arch=gfx950).  There is no fallback path.')
+    return C.CDLL(_LIB_PATH)
+
+
+lib = _load()
+
+c_f32p = C.c_void_p   # device pointers travel as integers
+c_ptr = C.c_void_p
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [('M', C.c_int), ('N', C.c_int), ('K', C.c_int),
+                ('A', c_ptr), ('lda', C.c_int), ('a_kc', C.c_int),
+                ('B', c_ptr), ('ldb', C.c_int), ('b_kc', C.c_int),
+                ('K2', C.c_int),
+                ('A2', c_ptr), ('lda2', C.c_int),
+                ('B2', c_ptr), ('ldb2', C.c_int),
+                ('C', c_ptr), ('ldc', C.c_int),
+                ('bias', c_ptr), ('accumulate', C.c_int), ('relu', C.c_int)]
+
+
+class SamplerArgs(C.Structure):
+    _fields_ = [('logits', c_ptr), ('B', C.c_int), ('V1', C.c_int), ('ld', C.c_int),
+                ('mode', C.c_int), ('temp', C.c_float),
+                ('U', c_ptr), ('ldu', C.c_int),
+                ('pick', c_ptr), ('constraint_prev', c_ptr), ('step', C.c_int),
+                ('unfinished', c_ptr), ('it_next', c_ptr), ('seq', c_ptr), ('slp', c_ptr),
+                ('stv', c_ptr), ('seq_ld', C.c_int), ('any_unfinished', c_ptr)]
+
+
+SAMPLE_NONE, SAMPLE_GREEDY, SAMPLE_MULTINOMIAL, SAMPLE_GUMBEL_ST, SAMPLE_MULTINOMIAL_ST = range(5)
+
+
+def declared_symbols():
+    """Every function name declared in include/cic.h."""
+    with open(_HEADER) as f:
+        src = f.read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(cic_[a-z0-9_]+)\s*\(', src)))
+
+
+def check_exports():
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    if missing:
+        raise CicError('libcic_hip.so lacks symbols declared in cic.h: ' + ', '.join(missing))
+
+
+lib.cic_last_error.restype = C.c_char_p
+lib.cic_version.restype = C.c_int
+
+
+def check(rc, what=''):
+    if rc != 0:
+        raise CicError(f'{what} failed (rc={rc}): {lib.cic_last_error().decode()}')
+
+
+def ptr(t):
+    """Device (or host) pointer of a contiguous torch tensor, or None."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'cic: tensor must be contiguous'
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

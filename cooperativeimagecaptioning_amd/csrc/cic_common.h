@@ -1,0 +1,87 @@
+// Internal helpers shared by the HIP translation units of libcic_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "cic.h"
+
+void cic_set_error(const char* fmt, ...);
+
+#define CIC_HIP(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            cic_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+            return 2;                                                                      \
+        }                                                                                  \
+    } while (0)
+
+#define CIC_REQUIRE(cond, ...)                                                             \
+    do {                                                                                   \
+        if (!(cond)) {                                                                     \
+            cic_set_error("%s:%d requirement failed: %s", __FILE__, __LINE__, #cond);      \
+            return 1;                                                                      \
+        }                                                                                  \
+    } while (0)
+
+#define CIC_LAUNCH_CHECK() CIC_HIP(hipGetLastError())
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+static inline hipStream_t cic_s(cic_stream_t s) { return (hipStream_t)s; }
+static inline int cic_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- wave / block reductions (wave = 64 lanes) ---------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- fast, accurate-enough transcendental helpers (f32, abs err ~1e-7) ----------------
+__device__ __forceinline__ float fast_tanh(float x) {
+    // tanh(x) = sign(x) * (1 - e) / (1 + e),  e = exp(-2|x|)
+    float ax = fabsf(x);
+    float e = __expf(-2.0f * ax);
+    float t = (1.0f - e) / (1.0f + e);
+    return copysignf(t, x);
+}
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    // stable on both sides: 1/(1+e^-x) for x>=0, e^x/(1+e^x) for x<0
+    float e = __expf(-fabsf(x));
+    float r = 1.0f / (1.0f + e);
+    return x >= 0.0f ? r : e * r;
+}
+
+// ---- Philox4x32-10 ---------------------------------------------------------------------
+struct Philox4 {
+    uint32_t v[4];
+};
+__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint64_t counter, uint64_t seed) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+    uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = 0u, c3 = 0u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    Philox4 o;
+    o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+    return o;
+}
+__host__ __device__ __forceinline__ float u32_to_unit(uint32_t r) {
+    return (float)(r >> 8) * (1.0f / 16777216.0f);   // [0,1), 24 bits like torch.rand
+}

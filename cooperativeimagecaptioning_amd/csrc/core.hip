@@ -1,0 +1,60 @@
+// Library plumbing (version, error text) and the counter-based RNG kernels.
+#include <stdarg.h>
+#include <string.h>
+#include "cic_common.h"
+
+static thread_local char g_err[512] = "";
+
+void cic_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int cic_version(void) { return 100; }
+extern "C" const char* cic_last_error(void) { return g_err; }
+
+namespace {
+
+__global__ __launch_bounds__(256) void uniform_kernel(float* __restrict__ out, int64_t n, uint64_t seed,
+                                                      uint64_t offset) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one Philox call = 4 outputs
+    const int64_t i = q * 4;
+    if (i >= n) return;
+    Philox4 r = philox4x32_10(offset + (uint64_t)q, seed);
+    if (i + 3 < n && ((reinterpret_cast<uintptr_t>(out + i) & 15) == 0)) {
+        f32x4 v = {u32_to_unit(r.v[0]), u32_to_unit(r.v[1]), u32_to_unit(r.v[2]), u32_to_unit(r.v[3])};
+        *reinterpret_cast<f32x4*>(out + i) = v;
+    } else {
+        for (int j = 0; j < 4 && i + j < n; ++j) out[i + j] = u32_to_unit(r.v[j]);
+    }
+}
+
+__global__ __launch_bounds__(256) void keep_kernel(uint8_t* __restrict__ keep, int64_t n, float p, uint64_t seed,
+                                                   uint64_t offset) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = q * 4;
+    if (i >= n) return;
+    Philox4 r = philox4x32_10(offset + (uint64_t)q, seed);
+    for (int j = 0; j < 4 && i + j < n; ++j) keep[i + j] = u32_to_unit(r.v[j]) >= p ? 1 : 0;
+}
+
+}  // namespace
+
+extern "C" int cic_uniform_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, cic_stream_t s) {
+    CIC_REQUIRE(out && n > 0);
+    const int64_t q = (n + 3) / 4;
+    hipLaunchKernelGGL(uniform_kernel, dim3(cic_cdiv(q, 256)), dim3(256), 0, cic_s(s), out, n, seed, offset);
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cic_dropout_keep_u8(uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset,
+                                   cic_stream_t s) {
+    CIC_REQUIRE(keep && n > 0 && p >= 0.f && p < 1.f);
+    const int64_t q = (n + 3) / 4;
+    hipLaunchKernelGGL(keep_kernel, dim3(cic_cdiv(q, 256)), dim3(256), 0, cic_s(s), keep, n, p, seed, offset);
+    CIC_LAUNCH_CHECK();
+    return 0;
+}

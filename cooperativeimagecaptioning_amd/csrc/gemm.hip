@@ -1,0 +1,270 @@
+// f32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact f32, k-ordered fma chain).
+//
+// One kernel template, three tile shapes:
+//   128x128 (4 waves, 2x2, each wave 64x64 = 2x2 MFMA tiles)   big M*N
+//    64x64  (4 waves, 2x2, each wave 32x32)                    mid-size / too few big tiles
+//   128x32  (4 waves, 4x1, each wave 32x32)                    skinny per-timestep GEMMs (M = batch)
+// K is walked in tiles of 32 through LDS with a register prefetch of the next tile.
+//
+// LDS images (no bank conflicts, see MI355X_MICROARCH §LDS):
+//   K-contiguous operand  -> [row][32+4]: filled by ds_write_b128, fragments read by ONE
+//                            ds_read_b128 per 4 MFMAs (lane half h reads k = 8g+4h .. +3)
+//   K-strided operand     -> [k][rows+4]: filled by ds_write_b128 along rows, fragments read by
+//                            ds_read_b32 (32 consecutive rows per lane half)
+// Both operands use the same k permutation inside each group of 8 (MFMA step j multiplies
+// k = 8g+j (lanes 0-31) and k = 8g+4+j (lanes 32-63)), so the sum order is fixed and
+// reproducible run to run.
+#include "cic_common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int KCS = BK + 4;  // row stride of a K-contiguous LDS image (floats)
+
+template <int ROWS, bool KC, bool VEC, int THREADS>
+struct Tile {
+    static constexpr int NV = ROWS * BK / 4 / THREADS;   // float4 per thread per tile
+    static constexpr int LDS_FLOATS = KC ? ROWS * KCS : BK * (ROWS + 4);
+    static_assert(NV >= 1 && NV * THREADS * 4 == ROWS * BK, "tile/threads mismatch");
+
+    // global -> registers.  Out-of-range elements read as 0.
+    __device__ static __forceinline__ void load(f32x4 (&r)[NV], const float* __restrict__ P, int ld,
+                                                int row0, int nrows, int k0, int K, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * THREADS;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (KC) {
+                const int rr = idx >> 3, q = idx & 7;
+                const int row = row0 + rr, k = k0 + 4 * q;
+                if (row < nrows) {
+                    const float* p = P + (size_t)row * ld + k;
+                    if (VEC) {
+                        if (k < K) v = *reinterpret_cast<const f32x4*>(p);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (k + j < K) v[j] = p[j];
+                    }
+                }
+            } else {
+                constexpr int QR = ROWS / 4;
+                const int kk = idx / QR, q = idx % QR;
+                const int k = k0 + kk, row = row0 + 4 * q;
+                if (k < K) {
+                    const float* p = P + (size_t)k * ld + row;
+                    if (VEC) {
+                        if (row < nrows) v = *reinterpret_cast<const f32x4*>(p);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (row + j < nrows) v[j] = p[j];
+                    }
+                }
+            }
+            r[i] = v;
+        }
+    }
+
+    // registers -> LDS
+    __device__ static __forceinline__ void store(const f32x4 (&r)[NV], float* L, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * THREADS;
+            if (KC) {
+                const int rr = idx >> 3, q = idx & 7;
+                *reinterpret_cast<f32x4*>(L + rr * KCS + 4 * q) = r[i];
+            } else {
+                constexpr int QR = ROWS / 4;
+                const int kk = idx / QR, q = idx % QR;
+                *reinterpret_cast<f32x4*>(L + kk * (ROWS + 4) + 4 * q) = r[i];
+            }
+        }
+    }
+
+    // LDS -> MFMA fragment for the group g of 8 k's: f[j] = op[row][8g + 4h + j]
+    __device__ static __forceinline__ f32x4 frag(const float* L, int row, int g, int h) {
+        if (KC) {
+            return *reinterpret_cast<const f32x4*>(L + row * KCS + 8 * g + 4 * h);
+        } else {
+            f32x4 f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[j] = L[(8 * g + 4 * h + j) * (ROWS + 4) + row];
+            return f;
+        }
+    }
+};
+
+template <int BM, int BN, int WM, int WN, bool KCA, bool KCB, bool VEC>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(cic_gemm_args g) {
+    constexpr int THREADS = WM * WN * 64;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    using TA = Tile<BM, KCA, VEC, THREADS>;
+    using TB = Tile<BN, KCB, VEC, THREADS>;
+    __shared__ __attribute__((aligned(16))) float lds[TA::LDS_FLOATS + TB::LDS_FLOATS];
+    float* LA = lds;
+    float* LB = lds + TA::LDS_FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int h = lane >> 5, r = lane & 31;
+
+    // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give each XCD a
+    // contiguous run of tiles; neighbouring tiles share operand panels.  Speed only.
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    f32x4 ra[TA::NV], rb[TB::NV];
+#pragma unroll 1
+    for (int pair = 0; pair < 2; ++pair) {
+        const float* A = pair ? g.A2 : g.A;
+        const float* B = pair ? g.B2 : g.B;
+        const int lda = pair ? g.lda2 : g.lda, ldb = pair ? g.ldb2 : g.ldb;
+        const int K = pair ? g.K2 : g.K;
+        if (K <= 0) continue;
+        const int nk = (K + BK - 1) / BK;
+        TA::load(ra, A, lda, m0, g.M, 0, K, tid);
+        TB::load(rb, B, ldb, n0, g.N, 0, K, tid);
+#pragma unroll 1
+        for (int kt = 0; kt < nk; ++kt) {
+            __syncthreads();   // everyone is done reading the previous tile
+            TA::store(ra, LA, tid);
+            TB::store(rb, LB, tid);
+            __syncthreads();
+            if (kt + 1 < nk) {   // next tile in flight under the MFMAs
+                TA::load(ra, A, lda, m0, g.M, (kt + 1) * BK, K, tid);
+                TB::load(rb, B, ldb, n0, g.N, (kt + 1) * BK, K, tid);
+            }
+#pragma unroll
+            for (int grp = 0; grp < BK / 8; ++grp) {
+                f32x4 af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = TA::frag(LA, wm * (BM / WM) + i * 32 + r, grp, h);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = TB::frag(LB, wn * (BN / WN) + j * 32 + r, grp, h);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / WN) + j * 32 + r;
+            if (n >= g.N) continue;
+            const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m < g.M) {
+                    float* c = g.C + (size_t)m * g.ldc + n;
+                    float v = acc[i][j][e] + bv;
+                    if (g.accumulate) v += *c;
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    *c = v;
+                }
+            }
+        }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_shape(const cic_gemm_args& g, bool vec, hipStream_t st) {
+    const int grid = cic_cdiv(g.M, BM) * cic_cdiv(g.N, BN);
+    dim3 blk(WM * WN * 64);
+#define CIC_GEMM_GO(KA, KB, V) \
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, KA, KB, V>), dim3(grid), blk, 0, st, g)
+    const int code = (g.a_kc ? 4 : 0) | (g.b_kc ? 2 : 0) | (vec ? 1 : 0);
+    switch (code) {
+        case 7: CIC_GEMM_GO(true, true, true); break;
+        case 6: CIC_GEMM_GO(true, true, false); break;
+        case 5: CIC_GEMM_GO(true, false, true); break;
+        case 4: CIC_GEMM_GO(true, false, false); break;
+        case 3: CIC_GEMM_GO(false, true, true); break;
+        case 2: CIC_GEMM_GO(false, true, false); break;
+        case 1: CIC_GEMM_GO(false, false, true); break;
+        default: CIC_GEMM_GO(false, false, false); break;
+    }
+#undef CIC_GEMM_GO
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// the float4 path needs every 4-group of an operand row to be wholly in or out of range
+bool operand_vec_ok(const float* P, int ld, int kc, int rows, int K) {
+    if (!P) return true;
+    if (!aligned16(P) || (ld & 3)) return false;
+    return kc ? (K & 3) == 0 : (rows & 3) == 0;
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int M, int N, int ldx,
+                                                     float* __restrict__ out, int accumulate) {
+    // block = 64 columns x 4 row-groups; grid.y splits M, partial sums combined with atomics
+    __shared__ float part[4][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
+    const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+    const int mb = blockIdx.y * rows_per, me = min(M, mb + rows_per);
+    float s = 0.f;
+    if (n < N)
+        for (int m = mb + rg; m < me; m += 4) s += X[(size_t)m * ldx + n];
+    part[rg][c] = s;
+    __syncthreads();
+    if (rg == 0 && n < N) {
+        s = part[0][c] + part[1][c] + part[2][c] + part[3][c];
+        if (gridDim.y == 1) {
+            out[n] = accumulate ? out[n] + s : s;
+        } else {
+            atomicAdd(out + n, s);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int cic_gemm_f32(const cic_gemm_args* a, cic_stream_t s) {
+    CIC_REQUIRE(a != nullptr);
+    const cic_gemm_args& g = *a;
+    CIC_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.K2 >= 0);
+    CIC_REQUIRE(g.A && g.B && g.C);
+    CIC_REQUIRE(g.K2 == 0 || (g.A2 && g.B2));
+    bool vec = operand_vec_ok(g.A, g.lda, g.a_kc, g.M, g.K) && operand_vec_ok(g.B, g.ldb, g.b_kc, g.N, g.K);
+    if (g.K2 > 0)
+        vec = vec && operand_vec_ok(g.A2, g.lda2, g.a_kc, g.M, g.K2) && operand_vec_ok(g.B2, g.ldb2, g.b_kc, g.N, g.K2);
+    const int64_t big_tiles = (int64_t)cic_cdiv(g.M, 128) * cic_cdiv(g.N, 128);
+    if (g.M <= 128 && g.M > 64) return launch_shape<128, 32, 4, 1>(g, vec, cic_s(s));
+    if (big_tiles >= 192) return launch_shape<128, 128, 2, 2>(g, vec, cic_s(s));
+    return launch_shape<64, 64, 2, 2>(g, vec, cic_s(s));
+}
+
+extern "C" int cic_colsum_f32(const float* X, int M, int N, int ldx, float* out, int accumulate,
+                              cic_stream_t s) {
+    CIC_REQUIRE(X && out && M > 0 && N > 0 && ldx >= N);
+    int ysplit = 1;
+    if (M >= 2048) ysplit = 8;
+    if (ysplit > 1 && !accumulate) CIC_HIP(hipMemsetAsync(out, 0, sizeof(float) * N, cic_s(s)));
+    hipLaunchKernelGGL(colsum_kernel, dim3(cic_cdiv(N, 64), ysplit), dim3(256), 0, cic_s(s), X, M, N, ldx, out,
+                       accumulate);
+    CIC_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,503 @@
+// Speaker (att2in2) forward kernels: per-timestep additive attention over the K embedded
+// regions, the maxout-LSTM cell pointwise part, token embedding, and the fused
+// log-softmax + sampler + EOS bookkeeping row kernel.
+//
+// All kernels are HBM/L2-streaming (no contraction): coalesced 16-B loads, wave-64 shuffles
+// for the per-region reductions, LDS only for the cross-wave hand-off.  The GEMMs around them
+// (h2att, i2h/h2h, a2c, logit) are cic_gemm_f32.
+#include "cic_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// K3 attention step  (reference: Attention.forward, models/AttModel.py:465-489)
+//   dot[k]  = b_a + sum_a w_a * tanh(p_att[b,k,a] + att_h[b,a])
+//   alpha   = softmax_k(dot)  (optionally * mask, renormalised)
+//   att_res = sum_k alpha[k] * att[b,k,:]
+// One workgroup (4 waves) per image.  Wave w owns regions k = w, w+4, ...; lane l owns the
+// float4 columns l, l+64, ... of a region row, so p_att and att rows are read with fully
+// coalesced 1-KiB wave loads.  HOLD=true keeps the att tile of the wave's regions in
+// registers across the softmax barrier (one pass over HBM/L2 for both operands).
+// ---------------------------------------------------------------------------------------
+template <int NI, int KPW, bool HOLD>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ att_h,   // [B,A]
+                                                       const float* __restrict__ p_att,   // [B,K,A]
+                                                       const float* __restrict__ att,     // [B,K,H]
+                                                       const float* __restrict__ w_alpha, // [A]
+                                                       const float* __restrict__ b_alpha, // [1]
+                                                       const float* __restrict__ masks,   // [B,K] or null
+                                                       float* __restrict__ att_res,       // [B,H]
+                                                       float* __restrict__ alpha_out,     // [B,K]
+                                                       float* __restrict__ dot_out,       // [B,K] or null
+                                                       int K, int A, int H) {
+    __shared__ float sdot[64];
+    __shared__ __attribute__((aligned(16))) float sacc[4 * NI * 256];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int A4 = A >> 2, H4 = H >> 2;
+    const f32x4* pa4 = reinterpret_cast<const f32x4*>(p_att + (size_t)b * K * A);
+    const f32x4* at4 = reinterpret_cast<const f32x4*>(att + (size_t)b * K * H);
+    const f32x4* ah4 = reinterpret_cast<const f32x4*>(att_h + (size_t)b * A);
+    const f32x4* wa4 = reinterpret_cast<const f32x4*>(w_alpha);
+
+    f32x4 ah[NI], wa[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = lane + 64 * i;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        ah[i] = c < A4 ? ah4[c] : z;
+        wa[i] = c < A4 ? wa4[c] : z;
+    }
+    const float ba = b_alpha[0];
+
+    f32x4 av[HOLD ? KPW : 1][NI];
+#pragma unroll
+    for (int j = 0; j < KPW; ++j) {
+        const int k = w + 4 * j;
+        if (k < K) {   // wave-uniform
+            f32x4 p[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int c = lane + 64 * i;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                p[i] = c < A4 ? pa4[(size_t)k * A4 + c] : z;
+                if (HOLD) av[j][i] = c < H4 ? at4[(size_t)k * H4 + c] : z;
+            }
+            float part = 0.f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part += wa[i][e] * fast_tanh(p[i][e] + ah[i][e]);
+            part = wave_sum(part);
+            if (lane == 0) sdot[k] = part + ba;
+        }
+    }
+    __syncthreads();
+    // softmax over the K regions — every thread redoes the tiny reduction from LDS
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) mx = fmaxf(mx, sdot[k]);
+    float sum = 0.f;
+    for (int k = 0; k < K; ++k) sum += __expf(sdot[k] - mx);
+    const float inv = 1.0f / sum;
+    float minv = 1.0f;
+    if (masks) {   // weight = weight * mask; weight /= weight.sum()   (AttModel.py:481-483)
+        float ms = 0.f;
+        for (int k = 0; k < K; ++k) ms += __expf(sdot[k] - mx) * inv * masks[(size_t)b * K + k];
+        minv = 1.0f / ms;
+    }
+    f32x4 acc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < KPW; ++j) {
+        const int k = w + 4 * j;
+        if (k < K) {
+            float a = __expf(sdot[k] - mx) * inv;
+            if (masks) a = a * masks[(size_t)b * K + k] * minv;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int c = lane + 64 * i;
+                f32x4 v;
+                if (HOLD) {
+                    v = av[j][i];
+                } else {
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    v = c < H4 ? at4[(size_t)k * H4 + c] : z;
+                }
+                acc[i] += a * v;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+        *reinterpret_cast<f32x4*>(&sacc[(w * NI * 64 + i * 64 + lane) * 4]) = acc[i];
+    __syncthreads();
+    for (int c = tid; c < H4; c += 256) {
+        const int i = c >> 6, l = c & 63;
+        f32x4 s = *reinterpret_cast<f32x4*>(&sacc[((0 * NI + i) * 64 + l) * 4]);
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) s += *reinterpret_cast<f32x4*>(&sacc[((ww * NI + i) * 64 + l) * 4]);
+        reinterpret_cast<f32x4*>(att_res + (size_t)b * H)[c] = s;
+    }
+    if (tid < K) {
+        float a = __expf(sdot[tid] - mx) * inv;
+        if (masks) a = a * masks[(size_t)b * K + tid] * minv;
+        alpha_out[(size_t)b * K + tid] = a;
+        if (dot_out) dot_out[(size_t)b * K + tid] = sdot[tid];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K4 cell pointwise  (Att2in2Core.forward, models/AttModel.py:515-529)
+//   pre[b, 0:5H] = i2h(x)+h2h(h) with a2c(att_res) already added to [3H:5H]
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cell_fwd_kernel(const float* __restrict__ pre, const float* __restrict__ c_prev,
+                                                       const uint8_t* __restrict__ keep, float scale,
+                                                       float* __restrict__ h_new, float* __restrict__ c_new,
+                                                       float* __restrict__ out, int B, int H) {
+    const int H4 = H >> 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * H4) return;
+    const int b = idx / H4, j = idx % H4;
+    const f32x4* p = reinterpret_cast<const f32x4*>(pre + (size_t)b * 5 * H);
+    const f32x4 pi = p[j], pf = p[H4 + j], po = p[2 * H4 + j], pa = p[3 * H4 + j], pb = p[4 * H4 + j];
+    const f32x4 cp = reinterpret_cast<const f32x4*>(c_prev)[idx];
+    f32x4 hn, cn, o;
+    uint32_t kp = 0x01010101u;
+    if (keep) kp = *reinterpret_cast<const uint32_t*>(keep + (size_t)idx * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float ig = fast_sigmoid(pi[e]), fg = fast_sigmoid(pf[e]), og = fast_sigmoid(po[e]);
+        const float g = fmaxf(pa[e], pb[e]);
+        const float c2 = fg * cp[e] + ig * g;
+        const float h2 = og * fast_tanh(c2);
+        cn[e] = c2;
+        hn[e] = h2;
+        const float kf = (float)((kp >> (8 * e)) & 0xffu);
+        o[e] = keep ? h2 * (kf * scale) : h2;
+    }
+    reinterpret_cast<f32x4*>(h_new)[idx] = hn;
+    reinterpret_cast<f32x4*>(c_new)[idx] = cn;
+    reinterpret_cast<f32x4*>(out)[idx] = o;
+}
+
+// ---------------------------------------------------------------------------------------
+// K7 token embedding: x = dropout(relu(E[it]))   (models/AttModel.py:74-76,399)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict__ E, const int32_t* __restrict__ it,
+                                                        const uint8_t* __restrict__ keep, float scale,
+                                                        float* __restrict__ x, int B, int Ed) {
+    const int E4 = Ed >> 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * E4) return;
+    const int b = idx / E4, j = idx % E4;
+    f32x4 v = reinterpret_cast<const f32x4*>(E + (size_t)it[b] * Ed)[j];
+    uint32_t kp = 0x01010101u;
+    if (keep) kp = *reinterpret_cast<const uint32_t*>(keep + (size_t)idx * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float kf = (float)((kp >> (8 * e)) & 0xffu);
+        const float r = fmaxf(v[e], 0.f);
+        v[e] = keep ? r * (kf * scale) : r;
+    }
+    reinterpret_cast<f32x4*>(x)[idx] = v;
+}
+
+// y = x * keep * scale (dropout of the embedded regions, models/AttModel.py:82-85)
+__global__ __launch_bounds__(256) void apply_keep_kernel(const float* __restrict__ x, const uint8_t* __restrict__ keep,
+                                                         float scale, float* __restrict__ y, int64_t n4) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n4) return;
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[idx];
+    if (keep) {
+        const uint32_t kp = *reinterpret_cast<const uint32_t*>(keep + idx * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * ((float)((kp >> (8 * e)) & 0xffu) * scale);
+    }
+    reinterpret_cast<f32x4*>(y)[idx] = v;
+}
+
+// ---------------------------------------------------------------------------------------
+// K5b/K6 row kernel: log-softmax over the vocabulary + sampler + EOS bookkeeping
+//   (models/AttModel.py:328-365,401-434,438-444; models/gumbel.py:6-30; models/multinomial.py:4-27)
+// One workgroup per batch row; the row (<= RV*1024 floats) lives in registers between passes.
+// ---------------------------------------------------------------------------------------
+struct ArgMax {
+    float v;
+    int i;
+};
+__device__ __forceinline__ ArgMax amax_better(ArgMax a, ArgMax b) {
+    // larger value wins; ties -> lowest index (torch.max on CPU)
+    return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+__device__ __forceinline__ ArgMax wave_argmax(ArgMax a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ArgMax b;
+        b.v = __shfl_xor(a.v, o, 64);
+        b.i = __shfl_xor(a.i, o, 64);
+        a = amax_better(a, b);
+    }
+    return a;
+}
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+__device__ __forceinline__ ArgMax block_argmax(ArgMax a, float* shv, int* shi) {
+    a = wave_argmax(a);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        shv[threadIdx.x >> 6] = a.v;
+        shi[threadIdx.x >> 6] = a.i;
+    }
+    __syncthreads();
+    ArgMax r = {shv[0], shi[0]};
+#pragma unroll
+    for (int w = 1; w < 4; ++w) r = amax_better(r, ArgMax{shv[w], shi[w]});
+    return r;
+}
+
+__device__ __forceinline__ float gumbel_from_u(float u) {
+    // -log(-log(U + eps) + eps), eps = 1e-20, in f32 exactly as models/gumbel.py:6-11
+    return -logf(-logf(u + 1e-20f) + 1e-20f);
+}
+
+template <int RV>   // RV float4 per thread: rows up to RV*1024 floats
+__global__ __launch_bounds__(256) void logsoftmax_sample_kernel(cic_sampler_args a) {
+    __shared__ float shf[4];
+    __shared__ int shi[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int V1 = a.V1;
+    float* row = a.logits + (size_t)b * a.ld;
+    const bool vec = ((a.ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.logits) & 15) == 0);
+    const int nq = (V1 + 3) >> 2;
+
+    float x[RV][4];
+    const int cons = (a.constraint_prev && a.step >= 2) ? a.constraint_prev[b] : -1;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < RV; ++r) {
+        const int q = tid + 256 * r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[r][e] = -INFINITY;
+        if (q < nq) {
+            if (vec && 4 * q + 3 < V1) {
+                const f32x4 v = reinterpret_cast<const f32x4*>(row)[q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[r][e] = v[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * q + e < V1) x[r][e] = row[4 * q + e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (4 * q + e == cons) x[r][e] = -INFINITY;   // decoding_constraint, AttModel.py:438-442
+                mx = fmaxf(mx, x[r][e]);
+            }
+        }
+    }
+    mx = block_max(mx, shf);
+    float se = 0.f;
+#pragma unroll
+    for (int r = 0; r < RV; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) se += __expf(x[r][e] - mx);   // exp(-inf) = 0 for padding
+    se = block_sum(se, shf);
+    const float lse = mx + logf(se);
+    // log-probs back to memory (saved for the backward pass) and kept in registers
+#pragma unroll
+    for (int r = 0; r < RV; ++r) {
+        const int q = tid + 256 * r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[r][e] -= lse;
+        if (q < nq) {
+            if (vec && 4 * q + 3 < V1) {
+                f32x4 v = {x[r][0], x[r][1], x[r][2], x[r][3]};
+                reinterpret_cast<f32x4*>(row)[q] = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * q + e < V1) row[4 * q + e] = x[r][e];
+            }
+        }
+    }
+    if (a.mode == CIC_SAMPLE_NONE) return;
+
+    // ---- choose the token -------------------------------------------------------------
+    const float* urow = a.U ? a.U + (size_t)b * a.ldu : nullptr;
+    const bool use_noise = (a.mode != CIC_SAMPLE_GREEDY) && !(a.pick && a.mode != CIC_SAMPLE_GUMBEL_ST);
+    const float inv_t = 1.0f / a.temp;
+    ArgMax best = {-INFINITY, 0x7fffffff};
+    float z[RV][4];
+#pragma unroll
+    for (int r = 0; r < RV; ++r) {
+        const int q = tid + 256 * r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int col = 4 * q + e;
+            float zz = -INFINITY;
+            if (q < nq && col < V1) {
+                if (a.mode == CIC_SAMPLE_GREEDY) {
+                    zz = x[r][e];
+                } else if (a.mode == CIC_SAMPLE_GUMBEL_ST) {
+                    zz = (x[r][e] + gumbel_from_u(urow[col])) * inv_t;           // gumbel.py:13-15
+                } else {   // multinomial flavours: Gumbel-max draw from softmax(logp / temp)
+                    zz = x[r][e] * inv_t;
+                    if (use_noise) zz += gumbel_from_u(urow[col]);
+                }
+            }
+            z[r][e] = zz;
+            best = amax_better(best, ArgMax{zz, col});
+        }
+    }
+    best = block_argmax(best, shf, shi);
+    int it = best.i;
+    if (a.pick && a.mode != CIC_SAMPLE_GREEDY && a.mode != CIC_SAMPLE_GUMBEL_ST) it = (int)a.pick[b];
+
+    // sampled log-prob (gather) and the straight-through value v = (1 - y_it) + y_it
+    float slp_part = 0.f;
+#pragma unroll
+    for (int r = 0; r < RV; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * (tid + 256 * r) + e == it) slp_part = x[r][e];
+    const float slp = block_sum(slp_part, shf);
+    float v = 1.0f;
+    if (a.mode == CIC_SAMPLE_GUMBEL_ST || a.mode == CIC_SAMPLE_MULTINOMIAL_ST) {
+        // y = softmax(z) with z = (logp+g)/tau  (gumbel)  or  logp/tau  (multinomial.py:10-15)
+        float zm, zi = -INFINITY;
+        float s2 = 0.f;
+        if (a.mode == CIC_SAMPLE_GUMBEL_ST) {
+            zm = best.v;
+#pragma unroll
+            for (int r = 0; r < RV; ++r)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s2 += __expf(z[r][e] - zm);
+                    if (4 * (tid + 256 * r) + e == it) zi = z[r][e];
+                }
+        } else {
+            float m2 = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < RV; ++r)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m2 = fmaxf(m2, x[r][e] * inv_t);
+            zm = block_max(m2, shf);
+#pragma unroll
+            for (int r = 0; r < RV; ++r)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = x[r][e] * inv_t;
+                    s2 += __expf(t - zm);
+                    if (4 * (tid + 256 * r) + e == it) zi = t;
+                }
+        }
+        s2 = block_sum(s2, shf);
+        zi = block_max(zi, shf);
+        const float y = __expf(zi - zm) / s2;
+        v = (1.0f - y) + y;    // (y_hard - y).detach() + y at the arg-max entry, gumbel.py:28
+    }
+
+    // ---- EOS bookkeeping (AttModel.py:401-434) -----------------------------------------
+    if (tid == 0) {
+        const int t = a.step;   // loop iteration of the reference (1-based for sampled tokens)
+        int unf = (it > 0) ? 1 : 0;
+        if (t > 1) unf = unf & a.unfinished[b];
+        a.unfinished[b] = unf;
+        a.it_next[b] = it;                                  // un-masked: embed(it) precedes the masking (:399)
+        a.seq[(size_t)b * a.seq_ld + (t - 1)] = unf ? it : 0;   // it * unfinished (:409)
+        a.slp[(size_t)b * a.seq_ld + (t - 1)] = slp;
+        if (a.stv) a.stv[(size_t)b * a.seq_ld + (t - 1)] = unf ? v : 1.0f;   // finished rows -> exact EOS one-hot (:419-420)
+        if (unf) atomicOr(a.any_unfinished + t, 1);
+    }
+}
+
+// L = number of appended columns: the reference breaks at the first t >= 1 whose unfinished
+// sum is 0 (AttModel.py:407-408); otherwise seq_length.
+__global__ void finalize_len_kernel(const int* __restrict__ any_unf, int T, int* __restrict__ L) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int l = T;
+        for (int t = 1; t <= T; ++t)
+            if (any_unf[t] == 0) {
+                l = t - 1;
+                break;
+            }
+        *L = l;
+    }
+}
+
+}  // namespace
+
+// ---- launchers ---------------------------------------------------------------------------
+extern "C" int cic_attn_fwd(const float* att_h, const float* p_att, const float* att, const float* w_alpha,
+                            const float* b_alpha, const float* masks, float* att_res, float* alpha,
+                            float* dot, int B, int K, int A, int H, cic_stream_t s) {
+    CIC_REQUIRE(att_h && p_att && att && w_alpha && b_alpha && att_res && alpha);
+    CIC_REQUIRE(B > 0 && K > 0 && K <= 64 && (A & 3) == 0 && (H & 3) == 0);
+    const int mx = A > H ? A : H;
+    CIC_REQUIRE(mx <= 1024);
+    dim3 grid(B), blk(256);
+    hipStream_t st = cic_s(s);
+#define GO(NI, KPW, HOLD)                                                                              \
+    hipLaunchKernelGGL((attn_fwd_kernel<NI, KPW, HOLD>), grid, blk, 0, st, att_h, p_att, att, w_alpha, \
+                       b_alpha, masks, att_res, alpha, dot, K, A, H)
+    if (mx <= 256) {
+        if (K <= 36) GO(1, 9, true); else GO(1, 16, false);
+    } else if (mx <= 512) {
+        if (K <= 36) GO(2, 9, true); else GO(2, 16, false);
+    } else {
+        GO(4, 16, false);
+    }
+#undef GO
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cic_cell_fwd(const float* pre, const float* c_prev, const uint8_t* keep, float p_drop,
+                            float* h_new, float* c_new, float* out, int B, int H, cic_stream_t s) {
+    CIC_REQUIRE(pre && c_prev && h_new && c_new && out && B > 0 && H > 0 && (H & 3) == 0);
+    const int n = B * (H / 4);
+    hipLaunchKernelGGL(cell_fwd_kernel, dim3(cic_cdiv(n, 256)), dim3(256), 0, cic_s(s), pre, c_prev, keep,
+                       1.0f / (1.0f - p_drop), h_new, c_new, out, B, H);
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cic_embed_fwd(const float* E, const int32_t* it, const uint8_t* keep, float p_drop, float* x,
+                             int B, int Ed, cic_stream_t s) {
+    CIC_REQUIRE(E && it && x && B > 0 && Ed > 0 && (Ed & 3) == 0);
+    const int n = B * (Ed / 4);
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(cic_cdiv(n, 256)), dim3(256), 0, cic_s(s), E, it, keep,
+                       1.0f / (1.0f - p_drop), x, B, Ed);
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cic_apply_keep(const float* x, const uint8_t* keep, float p_drop, float* y, int64_t n,
+                              cic_stream_t s) {
+    CIC_REQUIRE(x && y && n > 0 && (n & 3) == 0);
+    hipLaunchKernelGGL(apply_keep_kernel, dim3(cic_cdiv(n / 4, 256)), dim3(256), 0, cic_s(s), x, keep,
+                       1.0f / (1.0f - p_drop), y, n / 4);
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cic_logsoftmax_sample(const cic_sampler_args* a, cic_stream_t s) {
+    CIC_REQUIRE(a && a->logits && a->B > 0 && a->V1 > 0 && a->ld >= a->V1);
+    if (a->mode != CIC_SAMPLE_NONE) {
+        CIC_REQUIRE(a->unfinished && a->it_next && a->seq && a->slp && a->any_unfinished && a->step >= 1);
+        CIC_REQUIRE(a->temp > 0.f);
+        const bool needs_u = a->mode == CIC_SAMPLE_GUMBEL_ST ||
+                             ((a->mode == CIC_SAMPLE_MULTINOMIAL || a->mode == CIC_SAMPLE_MULTINOMIAL_ST) && !a->pick);
+        CIC_REQUIRE(!needs_u || (a->U && a->ldu >= a->V1));
+    }
+    dim3 grid(a->B), blk(256);
+    hipStream_t st = cic_s(s);
+    if (a->V1 <= 1024) hipLaunchKernelGGL((logsoftmax_sample_kernel<1>), grid, blk, 0, st, *a);
+    else if (a->V1 <= 4096) hipLaunchKernelGGL((logsoftmax_sample_kernel<4>), grid, blk, 0, st, *a);
+    else if (a->V1 <= 10240) hipLaunchKernelGGL((logsoftmax_sample_kernel<10>), grid, blk, 0, st, *a);
+    else {
+        cic_set_error("cic_logsoftmax_sample: vocabulary %d too large (max 10240)", a->V1);
+        return 1;
+    }
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cic_finalize_len(const int* any_unfinished, int T, int* L, cic_stream_t s) {
+    CIC_REQUIRE(any_unfinished && L && T > 0);
+    hipLaunchKernelGGL(finalize_len_kernel, dim3(1), dim3(64), 0, cic_s(s), any_unfinished, T, L);
+    CIC_LAUNCH_CHECK();
+    return 0;
+}

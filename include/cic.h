@@ -1,0 +1,126 @@
+/*
+ * cic.h — C ABI of libcic_hip.so, the MI355X (gfx950) hot path of the cooperative
+ * image-captioning joint training step (speaker <-> listener).
+ *
+ * Boundary: the reference has no FFI; its boundary is the Python module
+ * API (models.*, misc.rewards).  The re-implemented Python host mirrors that API and calls
+ * the entry points below through ctypes.  Every function cites the reference code whose
+ * computation it replaces (paths relative to the reference repo root).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch types.
+ *   - every pointer is a DEVICE pointer to a contiguous row-major buffer owned by the
+ *     caller, unless the parameter name ends in _host.
+ *   - explicit hipStream_t (passed as void*); nothing synchronises the device.
+ *   - no hidden allocation: scratch comes from a caller workspace (see *_ws_bytes).
+ *   - return 0 on success, non-zero error code otherwise; cic_last_error() has the text.
+ *     Nothing throws across the ABI.
+ *   - f32 everywhere (the reference computes in fp32); token ids are int64 at the API
+ *     surface (torch LongTensor) and int32 inside workspaces.
+ */
+#ifndef CIC_H
+#define CIC_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* cic_stream_t; /* hipStream_t */
+
+/* ---- library ---------------------------------------------------------------------- */
+int cic_version(void);
+const char* cic_last_error(void);
+
+/* ---- RNG (replaces torch.rand / nn.Dropout's bernoulli_ draws) ---------------------- */
+/* Philox4x32-10 counter RNG.  u[i] = (r >> 8) * 2^-24 in [0,1), as torch.rand does
+ * (models/gumbel.py:6-11).  Element i uses counter (offset + i/4), lane i%4. */
+int cic_uniform_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, cic_stream_t s);
+/* keep[i] = u[i] >= p  (1 = keep), nn.Dropout in training mode (models/AttModel.py:74-85,506). */
+int cic_dropout_keep_u8(uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset,
+                        cic_stream_t s);
+
+/* ---- dense contraction on the f32 MFMA (v_mfma_f32_32x32x2_f32) --------------------- */
+/* C[M,N] = op(A)[M,K] * op(B)[K,N] (+ A2*B2 over K2) (+ bias[N]) (+ C if accumulate), then
+ * optional ReLU.  Row-major with leading dimensions.
+ *   a_kc != 0: op(A)[m,k] = A[m*lda + k]   (K contiguous: activations x[M,K])
+ *   a_kc == 0: op(A)[m,k] = A[k*lda + m]   (A stored [K,M]:  dW = dY^T X)
+ *   b_kc != 0: op(B)[k,n] = B[n*ldb + k]   (nn.Linear weight W[N,K]:  y = x W^T)
+ *   b_kc == 0: op(B)[k,n] = B[k*ldb + n]   (B stored [K,N]:  dX = dY W)
+ * Replaces every nn.Linear / mm / matmul on the path: models/AttModel.py:82-88,140,444,
+ * 470,477,503-505,514,522; models/VSEFCModel.py:28,42,74-76,104,146. */
+typedef struct {
+    int M, N, K;
+    const float* A; int lda; int a_kc;
+    const float* B; int ldb; int b_kc;
+    int K2;                       /* 0 = no second operand pair */
+    const float* A2; int lda2;    /* same a_kc / b_kc as the first pair */
+    const float* B2; int ldb2;
+    float* C; int ldc;
+    const float* bias;            /* [N] or NULL */
+    int accumulate;               /* C += ... */
+    int relu;
+} cic_gemm_args;
+int cic_gemm_f32(const cic_gemm_args* a, cic_stream_t s);
+/* out[n] (+)= sum_m X[m*ldx + n]   — bias gradients. */
+int cic_colsum_f32(const float* X, int M, int N, int ldx, float* out, int accumulate,
+                   cic_stream_t s);
+
+/* ---- speaker (att2in2) forward kernels ----------------------------------------------- */
+/* Attention.forward, models/AttModel.py:465-489.  att_h = h2att(h) (bias included) comes
+ * from cic_gemm_f32.  masks: f32[B,K] or NULL.  Writes att_res[B,H], alpha[B,K] and, if dot
+ * is not NULL, the pre-softmax scores dot[B,K] (saved for the backward pass).
+ * Requires K <= 64, A and H multiples of 4 and <= 1024. */
+int cic_attn_fwd(const float* att_h, const float* p_att, const float* att, const float* w_alpha,
+                 const float* b_alpha, const float* masks, float* att_res, float* alpha, float* dot,
+                 int B, int K, int A, int H, cic_stream_t s);
+/* Att2in2Core.forward pointwise part, models/AttModel.py:515-529.  pre[B,5H] = i2h(x)+h2h(h)
+ * with a2c(att_res) added to columns [3H,5H).  keep: u8[B,H] dropout keep mask or NULL. */
+int cic_cell_fwd(const float* pre, const float* c_prev, const uint8_t* keep, float p_drop,
+                 float* h_new, float* c_new, float* out, int B, int H, cic_stream_t s);
+/* x = dropout(relu(E[it])), models/AttModel.py:74-76,399.  it: int32[B]. */
+int cic_embed_fwd(const float* E, const int32_t* it, const uint8_t* keep, float p_drop, float* x,
+                  int B, int Ed, cic_stream_t s);
+/* y = x * keep / (1-p)  (n multiple of 4; keep NULL = copy), models/AttModel.py:82-85. */
+int cic_apply_keep(const float* x, const uint8_t* keep, float p_drop, float* y, int64_t n,
+                   cic_stream_t s);
+
+/* Sampler modes of the fused log-softmax row kernel. */
+enum {
+    CIC_SAMPLE_NONE = 0,           /* log-softmax only (teacher forcing, AttModel.py:140) */
+    CIC_SAMPLE_GREEDY = 1,         /* torch.max, ties -> lowest index (AttModel.py:328-329) */
+    CIC_SAMPLE_MULTINOMIAL = 2,    /* it ~ softmax(logp/temp) (AttModel.py:332-343); Gumbel-max draw or pick[] */
+    CIC_SAMPLE_GUMBEL_ST = 3,      /* models/gumbel.py:17-30 */
+    CIC_SAMPLE_MULTINOMIAL_ST = 4  /* models/multinomial.py:4-27 */
+};
+typedef struct {
+    float* logits;        /* [B, ld] in: logits, out: log-probs (in place) */
+    int B, V1, ld;        /* V1 = vocab_size + 1 */
+    int mode;
+    float temp;           /* temperature / gumbel_temp / multinomial_temp */
+    const float* U;       /* [B, ldu] uniforms for the Gumbel noise, or NULL */
+    int ldu;
+    const int64_t* pick;  /* [B] externally chosen tokens (multinomial modes), or NULL */
+    const int32_t* constraint_prev; /* [B] token to suppress (decoding_constraint) or NULL */
+    int step;             /* reference loop iteration t >= 1 whose input token is chosen */
+    int32_t* unfinished;  /* [B] in/out */
+    int32_t* it_next;     /* [B] out: un-masked token fed to the next core step */
+    int32_t* seq;         /* [B, seq_ld] out: column step-1 = it * unfinished */
+    float* slp;           /* [B, seq_ld] out: column step-1 = logp[it] */
+    float* stv;           /* [B, seq_ld] out (ST modes, may be NULL): straight-through value */
+    int seq_ld;
+    int32_t* any_unfinished; /* [seq_length+1] zero-initialised flags, entry step is OR-ed */
+} cic_sampler_args;
+/* logit bias/GEMM output -> F.log_softmax + sampling + EOS bookkeeping,
+ * models/AttModel.py:328-365,401-434,438-444. */
+int cic_logsoftmax_sample(const cic_sampler_args* a, cic_stream_t s);
+/* L = first step t>=1 with no unfinished row, minus 1 (the reference's break, AttModel.py:407-408);
+ * seq_length if none. */
+int cic_finalize_len(const int32_t* any_unfinished, int T, int32_t* L, cic_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CIC_H */
