@@ -47,9 +47,38 @@ class SamplerArgs(C.Structure):
     _fields_ = [('logits', c_ptr), ('B', C.c_int), ('V1', C.c_int), ('ld', C.c_int),
                 ('mode', C.c_int), ('temp', C.c_float),
                 ('U', c_ptr), ('ldu', C.c_int),
-                ('pick', c_ptr), ('constraint_prev', c_ptr), ('step', C.c_int),
+                ('pick', c_ptr), ('decoding_constraint', C.c_int), ('step', C.c_int),
                 ('unfinished', c_ptr), ('it_next', c_ptr), ('seq', c_ptr), ('slp', c_ptr),
                 ('stv', c_ptr), ('seq_ld', C.c_int), ('any_unfinished', c_ptr)]
+
+
+class SpeakerDims(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ('B', 'K', 'D', 'H', 'E', 'A', 'V', 'T')] + [('p_drop', C.c_float)]
+
+
+SPEAKER_PARAM_FIELDS = [
+    # (struct field, reference state-dict key)
+    ('embed_w', 'embed.0.weight'),
+    ('att_embed_w', 'att_embed.0.weight'), ('att_embed_b', 'att_embed.0.bias'),
+    ('logit_w', 'logit.weight'), ('logit_b', 'logit.bias'),
+    ('ctx2att_w', 'ctx2att.weight'), ('ctx2att_b', 'ctx2att.bias'),
+    ('a2c_w', 'core.a2c.weight'), ('a2c_b', 'core.a2c.bias'),
+    ('i2h_w', 'core.i2h.weight'), ('i2h_b', 'core.i2h.bias'),
+    ('h2h_w', 'core.h2h.weight'), ('h2h_b', 'core.h2h.bias'),
+    ('h2att_w', 'core.attention.h2att.weight'), ('h2att_b', 'core.attention.h2att.bias'),
+    ('alpha_w', 'core.attention.alpha_net.weight'), ('alpha_b', 'core.attention.alpha_net.bias'),
+]
+
+
+class SpeakerParams(C.Structure):
+    _fields_ = [(f, c_ptr) for f, _ in SPEAKER_PARAM_FIELDS]
+
+
+class DecodeIO(C.Structure):
+    _fields_ = [('mode', C.c_int), ('temp', C.c_float), ('decoding_constraint', C.c_int),
+                ('att_pre', c_ptr), ('att_masks', c_ptr), ('att_keep', c_ptr), ('x_keep', c_ptr),
+                ('out_keep', c_ptr), ('U', c_ptr), ('pick', c_ptr),
+                ('seq', c_ptr), ('slp', c_ptr), ('stv', c_ptr), ('L', c_ptr)]
 
 
 SAMPLE_NONE, SAMPLE_GREEDY, SAMPLE_MULTINOMIAL, SAMPLE_GUMBEL_ST, SAMPLE_MULTINOMIAL_ST = range(5)

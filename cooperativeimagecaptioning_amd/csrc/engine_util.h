@@ -1,0 +1,91 @@
+// Host-side helpers for the sequence engines: workspace carving and GEMM call shorthands.
+#pragma once
+#include "cic_common.h"
+
+struct Carver {
+    char* base;
+    size_t off;
+    explicit Carver(void* b) : base(static_cast<char*>(b)), off(0) {}
+    void* take(size_t bytes) {
+        off = (off + 255) & ~size_t(255);   // 256-B aligned slices (float4 / dwordx4 safe)
+        void* p = base ? base + off : nullptr;
+        off += bytes;
+        return p;
+    }
+    float* f32(size_t n) { return static_cast<float*>(take(n * sizeof(float))); }
+    int32_t* i32(size_t n) { return static_cast<int32_t*>(take(n * sizeof(int32_t))); }
+    double* f64(size_t n) { return static_cast<double*>(take(n * sizeof(double))); }
+    uint64_t* u64(size_t n) { return static_cast<uint64_t*>(take(n * sizeof(uint64_t))); }
+    size_t used() const { return (off + 255) & ~size_t(255); }
+};
+
+// Activations of one speaker decode, in the order the backward pass walks them.
+struct SpkWs {
+    float *att, *p_att;                       // [B,K,H], [B,K,A]
+    float *x_all, *h_all, *c_all;             // [T,B,E], [T+1,B,H], [T+1,B,H]
+    float *att_h_all, *att_res_all;           // [T,B,A], [T,B,H]
+    float *alpha_all, *dot_all;               // [T,B,K]
+    float *pre_all, *out_all, *logp_all;      // [T,B,5H], [T,B,H], [T,B,V+1]
+    float* bias_ih;                           // [5H] = i2h.bias + h2h.bias
+    int32_t *it_all, *unfinished, *any_unf;   // [T+1,B], [B], [T+1]
+    size_t bytes;
+};
+SpkWs spk_carve(const cic_speaker_dims& d, void* base);
+
+int cic_fill_i32(int32_t* p, int n, int32_t v, hipStream_t st);
+int cic_add_vec(const float* a, const float* b, float* o, int n, hipStream_t st);
+
+// C[M,N] = A[M,K] W[N,K]^T (+bias) (+C)           — nn.Linear forward
+static inline int gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
+                          const float* bias, bool accumulate, bool relu, hipStream_t st) {
+    cic_gemm_args g = {};
+    g.M = M; g.N = N; g.K = K;
+    g.A = A; g.lda = lda; g.a_kc = 1;
+    g.B = W; g.ldb = ldw; g.b_kc = 1;
+    g.C = C; g.ldc = ldc; g.bias = bias; g.accumulate = accumulate; g.relu = relu;
+    return cic_gemm_f32(&g, st);
+}
+// C = A1 W1^T + A2 W2^T + bias
+static inline int gemm_nt2(const float* A1, int lda1, const float* W1, int ldw1, int K1, const float* A2, int lda2,
+                           const float* W2, int ldw2, int K2, float* C, int ldc, int M, int N, const float* bias,
+                           hipStream_t st) {
+    cic_gemm_args g = {};
+    g.M = M; g.N = N; g.K = K1;
+    g.A = A1; g.lda = lda1; g.a_kc = 1;
+    g.B = W1; g.ldb = ldw1; g.b_kc = 1;
+    g.K2 = K2; g.A2 = A2; g.lda2 = lda2; g.B2 = W2; g.ldb2 = ldw2;
+    g.C = C; g.ldc = ldc; g.bias = bias;
+    return cic_gemm_f32(&g, st);
+}
+// C[M,N] = A[M,K] Bm[K,N] (+C)                    — dX = dY W   (W stored [K=out, N=in])
+static inline int gemm_nn(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K,
+                          bool accumulate, hipStream_t st) {
+    cic_gemm_args g = {};
+    g.M = M; g.N = N; g.K = K;
+    g.A = A; g.lda = lda; g.a_kc = 1;
+    g.B = Bm; g.ldb = ldb; g.b_kc = 0;
+    g.C = C; g.ldc = ldc; g.accumulate = accumulate;
+    return cic_gemm_f32(&g, st);
+}
+// C = A1 B1 + A2 B2 (+C), all B stored [K,N]
+static inline int gemm_nn2(const float* A1, int lda1, const float* B1, int ldb1, int K1, const float* A2, int lda2,
+                           const float* B2, int ldb2, int K2, float* C, int ldc, int M, int N, bool accumulate,
+                           hipStream_t st) {
+    cic_gemm_args g = {};
+    g.M = M; g.N = N; g.K = K1;
+    g.A = A1; g.lda = lda1; g.a_kc = 1;
+    g.B = B1; g.ldb = ldb1; g.b_kc = 0;
+    g.K2 = K2; g.A2 = A2; g.lda2 = lda2; g.B2 = B2; g.ldb2 = ldb2;
+    g.C = C; g.ldc = ldc; g.accumulate = accumulate;
+    return cic_gemm_f32(&g, st);
+}
+// C[M,N] = At[K,M]^T Bm[K,N] (+C)                 — dW = dY^T X
+static inline int gemm_tn(const float* At, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K,
+                          bool accumulate, hipStream_t st) {
+    cic_gemm_args g = {};
+    g.M = M; g.N = N; g.K = K;
+    g.A = At; g.lda = lda; g.a_kc = 0;
+    g.B = Bm; g.ldb = ldb; g.b_kc = 0;
+    g.C = C; g.ldc = ldc; g.accumulate = accumulate;
+    return cic_gemm_f32(&g, st);
+}

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void logsoftmax_sample_kernel(cic_sampler_args
     const int nq = (V1 + 3) >> 2;
 
     float x[RV][4];
-    const int cons = (a.constraint_prev && a.step >= 2) ? a.constraint_prev[b] : -1;
+    const int cons = (a.decoding_constraint && a.step >= 2) ? a.seq[(size_t)b * a.seq_ld + (a.step - 2)] : -1;
     float mx = -INFINITY;
 #pragma unroll
     for (int r = 0; r < RV; ++r) {

@@ -109,14 +109,14 @@ def apply_keep(x, keep, p_drop, y):
     check(_apply_keep(ptr(x), ptr(keep), float(p_drop), ptr(y), x.numel(), stream()), 'cic_apply_keep')
 
 
-def logsoftmax_sample(logits, mode, temp=1.0, U=None, pick=None, constraint_prev=None, step=1,
+def logsoftmax_sample(logits, mode, temp=1.0, U=None, pick=None, decoding_constraint=0, step=1,
                       unfinished=None, it_next=None, seq=None, slp=None, stv=None, any_unfinished=None):
     a = SamplerArgs()
     a.logits, a.B, a.V1, a.ld = logits.data_ptr(), logits.shape[0], logits.shape[1], logits.stride(0)
     a.mode, a.temp = mode, float(temp)
     a.U, a.ldu = (U.data_ptr(), U.stride(0)) if U is not None else (None, 0)
     a.pick = ptr_any(pick)
-    a.constraint_prev = ptr_any(constraint_prev)
+    a.decoding_constraint = int(decoding_constraint)
     a.step = step
     a.unfinished, a.it_next = ptr_any(unfinished), ptr_any(it_next)
     a.seq, a.slp, a.stv = ptr_any(seq), ptr_any(slp), ptr_any(stv)

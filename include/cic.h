@@ -103,7 +103,7 @@ typedef struct {
     const float* U;       /* [B, ldu] uniforms for the Gumbel noise, or NULL */
     int ldu;
     const int64_t* pick;  /* [B] externally chosen tokens (multinomial modes), or NULL */
-    const int32_t* constraint_prev; /* [B] token to suppress (decoding_constraint) or NULL */
+    int decoding_constraint; /* != 0: suppress the previously appended token seq[b, step-2] (step >= 2) */
     int step;             /* reference loop iteration t >= 1 whose input token is chosen */
     int32_t* unfinished;  /* [B] in/out */
     int32_t* it_next;     /* [B] out: un-masked token fed to the next core step */
@@ -119,6 +119,57 @@ int cic_logsoftmax_sample(const cic_sampler_args* a, cic_stream_t s);
 /* L = first step t>=1 with no unfinished row, minus 1 (the reference's break, AttModel.py:407-408);
  * seq_length if none. */
 int cic_finalize_len(const int32_t* any_unfinished, int T, int32_t* L, cic_stream_t s);
+
+/* ---- speaker sequence engines (host loops over the kernels above, one stream, no sync) ---- */
+typedef struct {
+    int B, K, D, H, E, A, V; /* V = vocab_size: logits have V+1 columns, embedding V+2 rows */
+    int T;                   /* seq_length */
+    float p_drop;            /* drop_prob_lm */
+} cic_speaker_dims;
+
+/* Parameter (or gradient) pointers, named as the reference's state dict
+ * (models/AttModel.py:74-88,462-463,503-505). */
+typedef struct {
+    float* embed_w;                       /* embed.0.weight                 [V+2, E] */
+    float *att_embed_w, *att_embed_b;     /* att_embed.0                    [H, D], [H] */
+    float *logit_w, *logit_b;             /* logit                          [V+1, H], [V+1] */
+    float *ctx2att_w, *ctx2att_b;         /* ctx2att                        [A, H], [A] */
+    float *a2c_w, *a2c_b;                 /* core.a2c                       [2H, H], [2H] */
+    float *i2h_w, *i2h_b;                 /* core.i2h                       [5H, E], [5H] */
+    float *h2h_w, *h2h_b;                 /* core.h2h                       [5H, H], [5H] */
+    float *h2att_w, *h2att_b;             /* core.attention.h2att           [A, H], [A] */
+    float *alpha_w, *alpha_b;             /* core.attention.alpha_net       [1, A], [1] */
+} cic_speaker_params;
+
+/* att_pre = relu(att_embed(att_raw)) [B*K, H] — AttModel.py:82-85,315 before the dropout.
+ * It is shared by the decodes of one training step (their dropout masks differ). */
+int cic_speaker_att_embed_fwd(const cic_speaker_dims* d, const cic_speaker_params* p,
+                              const float* att_raw, float* att_pre, cic_stream_t s);
+
+typedef struct {
+    int mode;                 /* CIC_SAMPLE_* (not NONE) */
+    float temp;               /* temperature / gumbel_temp / multinomial_temp */
+    int decoding_constraint;
+    const float* att_pre;     /* [B,K,H] from cic_speaker_att_embed_fwd */
+    const float* att_masks;   /* [B,K] or NULL */
+    const uint8_t* att_keep;  /* [B,K,H]   dropout keep masks; NULL = no dropout at that site */
+    const uint8_t* x_keep;    /* [T+1,B,E] row t: token-embedding dropout of core step t */
+    const uint8_t* out_keep;  /* [T+1,B,H] row t: core-output dropout of step t */
+    const float* U;           /* [T+1,B,V+1] row t (t>=1): Gumbel uniforms used to pick the input of step t */
+    const int64_t* pick;      /* [T+1,B] row t: externally chosen tokens (multinomial modes) or NULL */
+    int32_t* seq;             /* out [B,T]  it * unfinished          (AttModel.py:409-415) */
+    float* slp;               /* out [B,T]  sampled log-probs        (AttModel.py:413,423) */
+    float* stv;               /* out [B,T]  straight-through values, or NULL */
+    int32_t* L;               /* out [1]    number of columns the reference would return */
+} cic_decode_io;
+
+/* Bytes of workspace a decode needs; the same workspace must be handed, untouched, to
+ * cic_speaker_decode_bwd. */
+size_t cic_speaker_decode_ws_bytes(const cic_speaker_dims* d);
+/* AttModel.sample (beam_size 1), models/AttModel.py:291-452: T core steps + samplers, no host
+ * sync (the reference's early break is replaced by the device-side length L). */
+int cic_speaker_decode_fwd(const cic_speaker_dims* d, const cic_speaker_params* p, const cic_decode_io* io,
+                           void* ws, size_t ws_bytes, cic_stream_t s);
 
 #ifdef __cplusplus
 }

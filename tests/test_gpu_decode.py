@@ -1,0 +1,73 @@
+"""GPU: the speaker decode engine (C ABI) replays the golden decodes recorded from the
+reference (tests/golden/sample_*.npz) with the same weights and the same noise.  Token ids
+must match exactly; log-probs / straight-through values within 5e-5."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as GU
+
+pytestmark = pytest.mark.gpu
+
+
+def T_(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def run_decode(z, mode_name):
+    from cooperativeimagecaptioning_amd import engine, _lib
+    cfg = GU.cfg_dict(z)
+    W = {k: T_(v).cuda().contiguous() for k, v in z['weights'].items()}
+    att_raw = T_(z['att_raw']).cuda()
+    B, K, D = att_raw.shape
+    H = W['core.h2h.weight'].shape[1]
+    E = W['core.i2h.weight'].shape[1]
+    A = W['ctx2att.weight'].shape[0]
+    V, T = cfg['vocab_size'], cfg['seq_length']
+    p = cfg['drop_prob_lm']
+    dims = engine.speaker_dims(B, K, D, H, E, A, V, T, p)
+    params = engine.speaker_params(W)
+    att_pre = engine.speaker_att_embed_fwd(dims, params, att_raw)
+    nz = GU.noise_dict(z, 'noise')
+
+    def keep(key):
+        if p == 0.0 or key not in nz:
+            return None
+        return T_(nz[key].astype(np.uint8)).cuda().contiguous()
+    U = T_(nz['gumbel_u']).cuda().contiguous() if 'gumbel_u' in nz else None
+    pick = T_(nz['pick']).cuda().contiguous() if 'pick' in nz else None
+    mode = dict(greedy=_lib.SAMPLE_GREEDY, multinomial=_lib.SAMPLE_MULTINOMIAL, gumbel_st=_lib.SAMPLE_GUMBEL_ST,
+                multinomial_st=_lib.SAMPLE_MULTINOMIAL_ST)[mode_name]
+    temp = dict(greedy=1.0, multinomial=float(z.get('opt.temperature', 1.0)), gumbel_st=cfg['gumbel_temp'],
+                multinomial_st=cfg['multinomial_temp'])[mode_name]
+    out = engine.speaker_decode_fwd(dims, params, att_pre, mode, temp, None, keep('att_keep'), keep('x_keep'),
+                                    keep('out_keep'), U, pick, cfg['decoding_constraint'],
+                                    want_stv=mode_name.endswith('_st'))
+    torch.cuda.synchronize()
+    return out, cfg
+
+
+CASES = [('sample_greedy_full', 'greedy'), ('sample_greedy_early', 'greedy'), ('sample_greedy_dropout', 'greedy'),
+         ('sample_constraint', 'greedy'), ('sample_multinomial_plain', 'multinomial'),
+         ('sample_multinomial_temp', 'multinomial'), ('sample_gumbel_st', 'gumbel_st'),
+         ('sample_gumbel_st_tau', 'gumbel_st'), ('sample_multinomial_st', 'multinomial_st')]
+
+
+@pytest.mark.parametrize('name,mode', CASES)
+def test_decode_matches_reference(name, mode):
+    z = GU.load_case(name)
+    out, cfg = run_decode(z, mode)
+    L = int(out['L'])
+    ref_seq = z['res0']
+    assert L == ref_seq.shape[1], f'length: got {L}, reference {ref_seq.shape[1]}'
+    np.testing.assert_array_equal(out['seq'][:, :L].cpu().numpy(), ref_seq)      # token ids bit-exact
+    ref_lp = z['res1'] if mode in ('greedy', 'multinomial') else z['res2']
+    np.testing.assert_allclose(out['slp'][:, :L].cpu().numpy(), ref_lp, rtol=5e-5, atol=5e-5)
+    if mode.endswith('_st'):
+        # the reference's one-hot rows: exact zeros except at the token, where the value is stv
+        oh = z['res1']                                                            # [B, L, V+2]
+        idx = out['seq'][:, :L].cpu().long()
+        val = torch.from_numpy(oh).gather(2, idx.unsqueeze(2)).squeeze(2)
+        np.testing.assert_allclose(out['stv'][:, :L].cpu().numpy(), val.numpy(), atol=1.5e-7)
+        nnz = (torch.from_numpy(oh) != 0).sum(2)
+        assert int(nnz.max()) == 1
