@@ -81,6 +81,34 @@ class DecodeIO(C.Structure):
                 ('seq', c_ptr), ('slp', c_ptr), ('stv', c_ptr), ('L', c_ptr)]
 
 
+class ListenerDims(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ('B', 'F', 'E', 'J', 'V', 'T', 'Lp')] + [
+        ('margin', C.c_float), ('max_violation', C.c_int), ('no_imgnorm', C.c_int), ('use_abs', C.c_int)]
+
+
+LISTENER_PARAM_FIELDS = [
+    ('img_fc_w', 'img_enc.fc.weight'), ('img_fc_b', 'img_enc.fc.bias'),
+    ('embed_w', 'txt_enc.embed.weight'),
+    ('w_ih', 'txt_enc.rnn.weight_ih_l0'), ('w_hh', 'txt_enc.rnn.weight_hh_l0'),
+    ('b_ih', 'txt_enc.rnn.bias_ih_l0'), ('b_hh', 'txt_enc.rnn.bias_hh_l0'),
+]
+
+
+class ListenerParams(C.Structure):
+    _fields_ = [(f, c_ptr) for f, _ in LISTENER_PARAM_FIELDS]
+
+
+class ListenerIO(C.Structure):
+    _fields_ = [('fc_feats', c_ptr), ('labels', c_ptr), ('masks', c_ptr), ('seq', c_ptr), ('stv', c_ptr),
+                ('L', c_ptr), ('only_one_retrieval', C.c_int), ('loss_rows', c_ptr), ('loss_sum', c_ptr),
+                ('img_emb_out', c_ptr), ('cap_emb_out', c_ptr)]
+
+
+class ListenerBwdIO(C.Structure):
+    _fields_ = [('g_rows', c_ptr), ('g_scalar', c_ptr), ('grads', C.POINTER(ListenerParams)),
+                ('d_onehot', c_ptr)]
+
+
 SAMPLE_NONE, SAMPLE_GREEDY, SAMPLE_MULTINOMIAL, SAMPLE_GUMBEL_ST, SAMPLE_MULTINOMIAL_ST = range(5)
 
 

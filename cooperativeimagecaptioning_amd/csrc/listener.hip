@@ -1,0 +1,466 @@
+// Listener (VSE++ "fc" model): image FC encoder, GRU text encoder over (straight-through)
+// token sequences, max-violation hinge contrastive loss — forward and backward.
+// Reference: models/VSEFCModel.py:12-241.
+//
+// Design notes (MI355X-first):
+//  * the reference multiplies a dense one-hot [B,L,V+2] by the embedding table
+//    (VSEFCModel.py:102-104); (y_hard - y).detach() + y is EXACTLY zero off the sampled
+//    token, so the forward is a row gather scaled by the straight-through value stv;
+//    only the backward needs the dense product (d one_hot = dX E^T), done by cic_gemm_f32.
+//  * packed sequences are replaced by a length mask: rows stop updating h at t >= len, which
+//    yields the same h[len-1] that pack_padded_sequence + gather(len-1) picks (:108-129).
+//  * the input projection of all time steps is ONE GEMM; only h W_hh^T is recurrent.
+#include "cic_common.h"
+#include "engine_util.h"
+
+namespace {
+
+// ---- token preparation -----------------------------------------------------------------
+// generated captions: tokens = [<bos>, seq[:, 0:L]], lens from masks [1,1,(seq>0)[:, :L-1]]
+// (models/AlternatingJointModel.py:353-370)
+__global__ void prep_generated_kernel(const int32_t* __restrict__ seq, const float* __restrict__ stv,
+                                      const int32_t* __restrict__ Lp, int B, int T, int bos,
+                                      int32_t* __restrict__ idx, float* __restrict__ val,
+                                      int32_t* __restrict__ len) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int L = *Lp;
+    int n = 2;
+    idx[(size_t)b * (T + 1)] = bos;
+    val[(size_t)b * (T + 1)] = 1.0f;
+    for (int j = 0; j < T; ++j) {
+        const int tok = seq[(size_t)b * T + j];
+        idx[(size_t)b * (T + 1) + 1 + j] = j < L ? tok : 0;
+        val[(size_t)b * (T + 1) + 1 + j] = (j < L && stv) ? stv[(size_t)b * T + j] : 1.0f;
+        if (j < L - 1 && tok > 0) ++n;
+    }
+    if (n > L + 1) n = L + 1;
+    len[b] = n;
+}
+// ground-truth labels: idx = labels, lens = sum(masks > 0)   (VSEFCModel.py:83-85)
+__global__ void prep_labels_kernel(const int64_t* __restrict__ labels, const float* __restrict__ masks, int B, int Lp,
+                                   int32_t* __restrict__ idx, float* __restrict__ val, int32_t* __restrict__ len) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int n = 0;
+    for (int j = 0; j < Lp; ++j) {
+        idx[(size_t)b * Lp + j] = (int32_t)labels[(size_t)b * Lp + j];
+        val[(size_t)b * Lp + j] = 1.0f;
+        if (masks[(size_t)b * Lp + j] > 0.f) ++n;
+    }
+    len[b] = n;
+}
+
+// x_emb[t,b,:] = val[b,t] * E[idx[b,t],:]     (time-major so each GRU step is one contiguous slab)
+__global__ __launch_bounds__(256) void embed_st_fwd_kernel(const float* __restrict__ E, const int32_t* __restrict__ idx,
+                                                           const float* __restrict__ val, float* __restrict__ x,
+                                                           int B, int Lp, int Ed) {
+    const int E4 = Ed >> 2;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Lp * B * E4) return;
+    const int j = (int)(i % E4);
+    const int b = (int)((i / E4) % B), t = (int)(i / ((int64_t)E4 * B));
+    const int tok = idx[(size_t)b * Lp + t];
+    const float v = val[(size_t)b * Lp + t];
+    f32x4 e = reinterpret_cast<const f32x4*>(E + (size_t)tok * Ed)[j];
+    reinterpret_cast<f32x4*>(x)[i] = e * v;
+}
+// dE[idx[b,t],:] += val[b,t] * dx[t,b,:]   for t < len[b]  (dx is already 0 elsewhere)
+__global__ __launch_bounds__(256) void embed_st_bwd_kernel(const float* __restrict__ dx, const int32_t* __restrict__ idx,
+                                                           const float* __restrict__ val, const int32_t* __restrict__ len,
+                                                           float* __restrict__ dE, int B, int Lp, int Ed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Lp * B * Ed) return;
+    const int j = (int)(i % Ed);
+    const int b = (int)((i / Ed) % B), t = (int)(i / ((int64_t)Ed * B));
+    if (t >= len[b]) return;
+    const int tok = idx[(size_t)b * Lp + t];
+    atomicAdd(dE + (size_t)tok * Ed + j, val[(size_t)b * Lp + t] * dx[i]);
+}
+
+// ---- GRU cell (torch.nn.GRU gate order r, z, n) ------------------------------------------
+__global__ __launch_bounds__(256) void gru_cell_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ gh,
+                                                           const float* __restrict__ h, const int32_t* __restrict__ len,
+                                                           int t, float* __restrict__ h_new, int B, int J) {
+    const int J4 = J >> 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * J4) return;
+    const int b = idx / J4, j = idx % J4;
+    const f32x4 hp = reinterpret_cast<const f32x4*>(h)[idx];
+    f32x4 hn = hp;
+    if (t < len[b]) {
+        const f32x4* a = reinterpret_cast<const f32x4*>(gi + (size_t)b * 3 * J);
+        const f32x4* c = reinterpret_cast<const f32x4*>(gh + (size_t)b * 3 * J);
+        const f32x4 ir = a[j], iz = a[J4 + j], in = a[2 * J4 + j];
+        const f32x4 hr = c[j], hz = c[J4 + j], hnn = c[2 * J4 + j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float r = fast_sigmoid(ir[e] + hr[e]);
+            const float z = fast_sigmoid(iz[e] + hz[e]);
+            const float n = fast_tanh(in[e] + r * hnn[e]);
+            hn[e] = (1.0f - z) * n + z * hp[e];
+        }
+    }
+    reinterpret_cast<f32x4*>(h_new)[idx] = hn;
+}
+// dh (in/out): gradient w.r.t. h_{t+1} in, w.r.t. the direct h_t path out (the W_hh path is added by a GEMM)
+__global__ __launch_bounds__(256) void gru_cell_bwd_kernel(const float* __restrict__ gi, const float* __restrict__ gh,
+                                                           const float* __restrict__ h, const int32_t* __restrict__ len,
+                                                           int t, const float* __restrict__ dh_in,
+                                                           float* __restrict__ dh_out, float* __restrict__ dgi,
+                                                           float* __restrict__ dgh, int B, int J) {
+    const int J4 = J >> 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * J4) return;
+    const int b = idx / J4, j = idx % J4;
+    const f32x4 d = reinterpret_cast<const f32x4*>(dh_in)[idx];
+    f32x4* oi = reinterpret_cast<f32x4*>(dgi + (size_t)b * 3 * J);
+    f32x4* oh = reinterpret_cast<f32x4*>(dgh + (size_t)b * 3 * J);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    if (t >= len[b]) {
+        oi[j] = zero; oi[J4 + j] = zero; oi[2 * J4 + j] = zero;
+        oh[j] = zero; oh[J4 + j] = zero; oh[2 * J4 + j] = zero;
+        reinterpret_cast<f32x4*>(dh_out)[idx] = d;
+        return;
+    }
+    const f32x4 hp = reinterpret_cast<const f32x4*>(h)[idx];
+    const f32x4* a = reinterpret_cast<const f32x4*>(gi + (size_t)b * 3 * J);
+    const f32x4* c = reinterpret_cast<const f32x4*>(gh + (size_t)b * 3 * J);
+    const f32x4 ir = a[j], iz = a[J4 + j], in = a[2 * J4 + j];
+    const f32x4 hr = c[j], hz = c[J4 + j], hnn = c[2 * J4 + j];
+    f32x4 gir, giz, gin, ghn, dprev;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float r = fast_sigmoid(ir[e] + hr[e]);
+        const float z = fast_sigmoid(iz[e] + hz[e]);
+        const float n = fast_tanh(in[e] + r * hnn[e]);
+        const float dn = d[e] * (1.0f - z);
+        const float dz = d[e] * (hp[e] - n);
+        const float dan = dn * (1.0f - n * n);
+        const float dr = dan * hnn[e];
+        gir[e] = dr * r * (1.0f - r);
+        giz[e] = dz * z * (1.0f - z);
+        gin[e] = dan;
+        ghn[e] = dan * r;
+        dprev[e] = d[e] * z;
+    }
+    oi[j] = gir; oi[J4 + j] = giz; oi[2 * J4 + j] = gin;
+    oh[j] = gir; oh[J4 + j] = giz; oh[2 * J4 + j] = ghn;
+    reinterpret_cast<f32x4*>(dh_out)[idx] = dprev;
+}
+
+// ---- l2norm (VSEFCModel.py:12-17): y = x / (||x|| + 1e-7) ---------------------------------
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         float* __restrict__ nrm, int J, int use_abs, int do_norm) {
+    __shared__ float sh[4];
+    const int b = blockIdx.x;
+    float s = 0.f;
+    for (int j = threadIdx.x; j < J; j += 256) {
+        const float v = x[(size_t)b * J + j];
+        s += v * v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float n = sqrtf(sh[0] + sh[1] + sh[2] + sh[3]);
+    const float inv = do_norm ? 1.0f / (n + 1e-7f) : 1.0f;
+    for (int j = threadIdx.x; j < J; j += 256) {
+        float v = x[(size_t)b * J + j] * inv;
+        if (use_abs) v = fabsf(v);
+        y[(size_t)b * J + j] = v;
+    }
+    if (threadIdx.x == 0) nrm[b] = n;
+}
+// dx = (dy' - yn * (yn . dy') * (n + eps) / n) / (n + eps),  yn = x/(n+eps), dy' = dy*sign(yn) if abs
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ nrm,
+                                                         const float* __restrict__ dy, float* __restrict__ dx, int J,
+                                                         int use_abs, int do_norm) {
+    __shared__ float sh[4];
+    const int b = blockIdx.x;
+    const float n = nrm[b];
+    const float inv = do_norm ? 1.0f / (n + 1e-7f) : 1.0f;
+    float s = 0.f;
+    for (int j = threadIdx.x; j < J; j += 256) {
+        const float yn = x[(size_t)b * J + j] * inv;
+        float g = dy[(size_t)b * J + j];
+        if (use_abs) g = yn > 0.f ? g : (yn < 0.f ? -g : 0.f);
+        s += yn * g;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float dot = sh[0] + sh[1] + sh[2] + sh[3];
+    const float k = (n > 0.f) ? dot * (n + 1e-7f) / n : 0.f;
+    for (int j = threadIdx.x; j < J; j += 256) {
+        const float yn = x[(size_t)b * J + j] * inv;
+        float g = dy[(size_t)b * J + j];
+        if (use_abs) g = yn > 0.f ? g : (yn < 0.f ? -g : 0.f);
+        dx[(size_t)b * J + j] = do_norm ? (g - yn * k) * inv : g;
+    }
+}
+
+// ---- contrastive loss (VSEFCModel.py:167-207) ------------------------------------------------
+// scores S[B,B] = im s^T from cic_gemm_f32.  One workgroup does the whole [B,B] reduction
+// (B <= 1024): thread i owns row i (caption retrieval) and column i (image retrieval).
+// out_rows[i] = sel_s*cost_s[i] + sel_im*cost_im[i];  out_sum = sum_i out_rows[i].
+__global__ __launch_bounds__(1024) void contrastive_fwd_kernel(const float* __restrict__ S, int B, float margin,
+                                                               int max_violation, int sel_s, int sel_im,
+                                                               float* __restrict__ out_rows, float* __restrict__ out_sum,
+                                                               int32_t* __restrict__ arg_s, int32_t* __restrict__ arg_im) {
+    __shared__ float sh[16];
+    const int i = threadIdx.x;
+    float tot = 0.f;
+    if (i < B) {
+        const float d = S[(size_t)i * B + i];
+        float cs = 0.f, ci = 0.f;
+        int as = -1, ai = -1;
+        if (max_violation) {
+            // masked_fill(diag, 0) then max: start from 0 (the diagonal entry), strict > keeps the first max
+            for (int j = 0; j < B; ++j) {
+                if (j == i) continue;
+                const float v = fmaxf(margin + S[(size_t)i * B + j] - d, 0.f);      // cost_s[i,j]   (:176)
+                if (v > cs) { cs = v; as = j; }
+                const float u = fmaxf(margin + S[(size_t)j * B + i] - d, 0.f);      // cost_im[j,i]  (:179)
+                if (u > ci) { ci = u; ai = j; }
+            }
+        } else {
+            for (int j = 0; j < B; ++j) {
+                if (j == i) continue;
+                cs += fmaxf(margin + S[(size_t)i * B + j] - d, 0.f);
+                ci += fmaxf(margin + S[(size_t)j * B + i] - d, 0.f);
+            }
+            cs /= (float)B;
+            ci /= (float)B;
+        }
+        const float r = (sel_s ? cs : 0.f) + (sel_im ? ci : 0.f);
+        out_rows[i] = r;
+        if (arg_s) arg_s[i] = as;
+        if (arg_im) arg_im[i] = ai;
+        tot = r;
+    }
+    tot = wave_sum(tot);
+    if ((i & 63) == 0) sh[i >> 6] = tot;
+    __syncthreads();
+    if (i == 0) {
+        float s = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sh[w];
+        *out_sum = s;
+    }
+}
+// dS from per-row upstream gradients g_rows[i] (scalar loss: all equal).  dS must be zeroed first.
+__global__ __launch_bounds__(256) void contrastive_bwd_kernel(const float* __restrict__ S, int B, float margin,
+                                                              int max_violation, int sel_s, int sel_im,
+                                                              const float* __restrict__ g_rows, const float* __restrict__ g_scalar,
+                                                              const int32_t* __restrict__ arg_s,
+                                                              const int32_t* __restrict__ arg_im, float* __restrict__ dS) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    const float g = g_rows ? g_rows[i] : *g_scalar;
+    const float d = S[(size_t)i * B + i];
+    if (max_violation) {
+        if (sel_s && arg_s[i] >= 0) {
+            atomicAdd(dS + (size_t)i * B + arg_s[i], g);
+            atomicAdd(dS + (size_t)i * B + i, -g);
+        }
+        if (sel_im && arg_im[i] >= 0) {
+            atomicAdd(dS + (size_t)arg_im[i] * B + i, g);
+            atomicAdd(dS + (size_t)i * B + i, -g);
+        }
+    } else {
+        const float gb = g / (float)B;
+        for (int j = 0; j < B; ++j) {
+            if (j == i) continue;
+            if (sel_s && margin + S[(size_t)i * B + j] - d > 0.f) {
+                atomicAdd(dS + (size_t)i * B + j, gb);
+                atomicAdd(dS + (size_t)i * B + i, -gb);
+            }
+            if (sel_im && margin + S[(size_t)j * B + i] - d > 0.f) {
+                atomicAdd(dS + (size_t)j * B + i, gb);
+                atomicAdd(dS + (size_t)i * B + i, -gb);
+            }
+        }
+    }
+}
+
+struct LstWs {
+    int32_t *idx, *len, *arg_s, *arg_im;
+    float *val, *x_emb, *gi_all, *gh_all, *h_all, *img_lin, *img_emb, *cap_emb, *nrm_img, *nrm_cap, *S;
+    // backward scratch
+    float *dS, *d_img, *d_cap, *d_lin, *dh, *dh2, *dgi_all, *dgh_all, *dx_emb;
+    size_t bytes;
+};
+LstWs lst_carve(const cic_listener_dims& d, void* base) {
+    LstWs w;
+    Carver c(base);
+    const size_t B = d.B, J = d.J, E = d.E, Lp = d.Lp;
+    w.idx = c.i32(B * Lp);
+    w.len = c.i32(B);
+    w.arg_s = c.i32(B);
+    w.arg_im = c.i32(B);
+    w.val = c.f32(B * Lp);
+    w.x_emb = c.f32(Lp * B * E);
+    w.gi_all = c.f32(Lp * B * 3 * J);
+    w.gh_all = c.f32(Lp * B * 3 * J);
+    w.h_all = c.f32((Lp + 1) * B * J);
+    w.img_lin = c.f32(B * J);
+    w.img_emb = c.f32(B * J);
+    w.cap_emb = c.f32(B * J);
+    w.nrm_img = c.f32(B);
+    w.nrm_cap = c.f32(B);
+    w.S = c.f32(B * B);
+    w.dS = c.f32(B * B);
+    w.d_img = c.f32(B * J);
+    w.d_cap = c.f32(B * J);
+    w.d_lin = c.f32(B * J);
+    w.dh = c.f32(B * J);
+    w.dh2 = c.f32(B * J);
+    w.dgi_all = c.f32(Lp * B * 3 * J);
+    w.dgh_all = c.f32(Lp * B * 3 * J);
+    w.dx_emb = c.f32(Lp * B * E);
+    w.bytes = c.used();
+    return w;
+}
+
+int check_ldims(const cic_listener_dims& d) {
+    CIC_REQUIRE(d.B > 0 && d.B <= 1024 && d.Lp > 0 && d.Lp <= 128);
+    CIC_REQUIRE((d.J & 3) == 0 && (d.E & 3) == 0 && d.F > 0 && d.V > 0);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t cic_listener_ws_bytes(const cic_listener_dims* d) {
+    if (!d) return 0;
+    return lst_carve(*d, nullptr).bytes;
+}
+
+extern "C" int cic_listener_fwd(const cic_listener_dims* dp, const cic_listener_params* p, const cic_listener_io* io,
+                                void* ws, size_t ws_bytes, cic_stream_t s) {
+    CIC_REQUIRE(dp && p && io && ws);
+    const cic_listener_dims& d = *dp;
+    if (int rc = check_ldims(d)) return rc;
+    LstWs w = lst_carve(d, ws);
+    CIC_REQUIRE(ws_bytes >= w.bytes);
+    CIC_REQUIRE(io->fc_feats && io->loss_rows && io->loss_sum);
+    hipStream_t st = cic_s(s);
+    const int B = d.B, J = d.J, E = d.E, Lp = d.Lp;
+    int rc;
+#define RUN(x) if ((rc = (x)) != 0) return rc
+    // tokens
+    if (io->labels) {
+        CIC_REQUIRE(io->masks);
+        hipLaunchKernelGGL(prep_labels_kernel, dim3(cic_cdiv(B, 256)), dim3(256), 0, st, io->labels, io->masks, B, Lp,
+                           w.idx, w.val, w.len);
+    } else {
+        CIC_REQUIRE(io->seq && io->L && Lp == d.T + 1);
+        hipLaunchKernelGGL(prep_generated_kernel, dim3(cic_cdiv(B, 256)), dim3(256), 0, st, io->seq, io->stv, io->L, B,
+                           d.T, d.V + 1, w.idx, w.val, w.len);
+    }
+    CIC_LAUNCH_CHECK();
+    // image encoder: l2norm(fc W^T + b)                                  (VSEFCModel.py:40-54)
+    RUN(gemm_nt(io->fc_feats, d.F, p->img_fc_w, d.F, w.img_lin, J, B, J, d.F, p->img_fc_b, false, false, st));
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(B), dim3(256), 0, st, w.img_lin, w.img_emb, w.nrm_img, J, d.use_abs,
+                       !d.no_imgnorm);
+    CIC_LAUNCH_CHECK();
+    // text encoder                                                       (VSEFCModel.py:95-140)
+    {
+        const int64_t n = (int64_t)Lp * B * (E / 4);
+        hipLaunchKernelGGL(embed_st_fwd_kernel, dim3(cic_cdiv(n, 256)), dim3(256), 0, st, p->embed_w, w.idx, w.val,
+                           w.x_emb, B, Lp, E);
+        CIC_LAUNCH_CHECK();
+    }
+    RUN(gemm_nt(w.x_emb, E, p->w_ih, E, w.gi_all, 3 * J, Lp * B, 3 * J, E, p->b_ih, false, false, st));
+    CIC_HIP(hipMemsetAsync(w.h_all, 0, sizeof(float) * B * J, st));
+    for (int t = 0; t < Lp; ++t) {
+        float* h = w.h_all + (size_t)t * B * J;
+        float* gh = w.gh_all + (size_t)t * B * 3 * J;
+        RUN(gemm_nt(h, J, p->w_hh, J, gh, 3 * J, B, 3 * J, J, p->b_hh, false, false, st));
+        hipLaunchKernelGGL(gru_cell_fwd_kernel, dim3(cic_cdiv(B * (J / 4), 256)), dim3(256), 0, st,
+                           w.gi_all + (size_t)t * B * 3 * J, gh, h, w.len, t, h + (size_t)B * J, B, J);
+        CIC_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(B), dim3(256), 0, st, w.h_all + (size_t)Lp * B * J, w.cap_emb, w.nrm_cap,
+                       J, d.use_abs, 1);
+    CIC_LAUNCH_CHECK();
+    // contrastive loss                                                   (VSEFCModel.py:167-207)
+    RUN(gemm_nt(w.img_emb, J, w.cap_emb, J, w.S, B, B, B, J, nullptr, false, false, st));
+    const int sel_s = io->only_one_retrieval != 1, sel_im = io->only_one_retrieval != 2;
+    hipLaunchKernelGGL(contrastive_fwd_kernel, dim3(1), dim3(((B + 63) / 64) * 64), 0, st, w.S, B, d.margin,
+                       d.max_violation, sel_s, sel_im, io->loss_rows, io->loss_sum, w.arg_s, w.arg_im);
+    CIC_LAUNCH_CHECK();
+    if (io->img_emb_out) CIC_HIP(hipMemcpyAsync(io->img_emb_out, w.img_emb, sizeof(float) * B * J, hipMemcpyDeviceToDevice, st));
+    if (io->cap_emb_out) CIC_HIP(hipMemcpyAsync(io->cap_emb_out, w.cap_emb, sizeof(float) * B * J, hipMemcpyDeviceToDevice, st));
+#undef RUN
+    return 0;
+}
+
+extern "C" int cic_listener_bwd(const cic_listener_dims* dp, const cic_listener_params* p, const cic_listener_io* io,
+                                const cic_listener_bwd_io* bio, void* ws, size_t ws_bytes, cic_stream_t s) {
+    CIC_REQUIRE(dp && p && io && bio && ws);
+    const cic_listener_dims& d = *dp;
+    if (int rc = check_ldims(d)) return rc;
+    LstWs w = lst_carve(d, ws);
+    CIC_REQUIRE(ws_bytes >= w.bytes);
+    CIC_REQUIRE(bio->g_rows || bio->g_scalar);
+    hipStream_t st = cic_s(s);
+    const int B = d.B, J = d.J, E = d.E, Lp = d.Lp;
+    const cic_listener_params* g = bio->grads;   // may be NULL: no parameter gradients wanted
+    int rc;
+#define RUN(x) if ((rc = (x)) != 0) return rc
+    const int sel_s = io->only_one_retrieval != 1, sel_im = io->only_one_retrieval != 2;
+    CIC_HIP(hipMemsetAsync(w.dS, 0, sizeof(float) * B * B, st));
+    hipLaunchKernelGGL(contrastive_bwd_kernel, dim3(cic_cdiv(B, 256)), dim3(256), 0, st, w.S, B, d.margin,
+                       d.max_violation, sel_s, sel_im, bio->g_rows, bio->g_scalar, w.arg_s, w.arg_im, w.dS);
+    CIC_LAUNCH_CHECK();
+    // S = im cap^T  ->  d_im = dS cap,  d_cap = dS^T im
+    RUN(gemm_nn(w.dS, B, w.cap_emb, J, w.d_img, J, B, J, B, false, st));
+    RUN(gemm_tn(w.dS, B, w.img_emb, J, w.d_cap, J, B, J, B, false, st));
+    // image branch
+    if (g) {
+        hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(B), dim3(256), 0, st, w.img_lin, w.nrm_img, w.d_img, w.d_lin, J,
+                           d.use_abs, !d.no_imgnorm);
+        CIC_LAUNCH_CHECK();
+        RUN(gemm_tn(w.d_lin, J, io->fc_feats, d.F, g->img_fc_w, d.F, J, d.F, B, true, st));
+        RUN(cic_colsum_f32(w.d_lin, B, J, J, g->img_fc_b, 1, s));
+    }
+    // text branch: l2norm then GRU BPTT
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(B), dim3(256), 0, st, w.h_all + (size_t)Lp * B * J, w.nrm_cap, w.d_cap,
+                       w.dh, J, d.use_abs, 1);
+    CIC_LAUNCH_CHECK();
+    float* dh = w.dh;
+    float* dh2 = w.dh2;
+    for (int t = Lp - 1; t >= 0; --t) {
+        float* dgi = w.dgi_all + (size_t)t * B * 3 * J;
+        float* dgh = w.dgh_all + (size_t)t * B * 3 * J;
+        hipLaunchKernelGGL(gru_cell_bwd_kernel, dim3(cic_cdiv(B * (J / 4), 256)), dim3(256), 0, st,
+                           w.gi_all + (size_t)t * B * 3 * J, w.gh_all + (size_t)t * B * 3 * J,
+                           w.h_all + (size_t)t * B * J, w.len, t, dh, dh2, dgi, dgh, B, J);
+        CIC_LAUNCH_CHECK();
+        if (t > 0) RUN(gemm_nn(dgh, 3 * J, p->w_hh, J, dh2, J, B, J, 3 * J, true, st));   // += dgh W_hh
+        float* tmp = dh; dh = dh2; dh2 = tmp;
+    }
+    if (g) {
+        RUN(gemm_tn(w.dgh_all, 3 * J, w.h_all, J, g->w_hh, J, 3 * J, J, Lp * B, true, st));
+        RUN(cic_colsum_f32(w.dgh_all, Lp * B, 3 * J, 3 * J, g->b_hh, 1, s));
+        RUN(gemm_tn(w.dgi_all, 3 * J, w.x_emb, E, g->w_ih, E, 3 * J, E, Lp * B, true, st));
+        RUN(cic_colsum_f32(w.dgi_all, Lp * B, 3 * J, 3 * J, g->b_ih, 1, s));
+    }
+    if ((g && g->embed_w) || bio->d_onehot) {
+        // dx_emb = dgi W_ih            [Lp*B, 3J] x [3J, E]
+        RUN(gemm_nn(w.dgi_all, 3 * J, p->w_ih, E, w.dx_emb, E, Lp * B, E, 3 * J, false, st));
+        if (g && g->embed_w) {
+            const int64_t n = (int64_t)Lp * B * E;
+            hipLaunchKernelGGL(embed_st_bwd_kernel, dim3(cic_cdiv(n, 256)), dim3(256), 0, st, w.dx_emb, w.idx, w.val,
+                               w.len, g->embed_w, B, Lp, E);
+            CIC_LAUNCH_CHECK();
+        }
+        if (bio->d_onehot) {
+            // straight-through path back to the speaker: d one_hot[t,b,0:V+1] = dx_emb[t,b,:] E[0:V+1,:]^T for the
+            // generated positions t = 1..T (position 0 is <bos>); time-major [T,B,V+1]   (VSEFCModel.py:104)
+            RUN(gemm_nt(w.dx_emb + (size_t)B * E, E, p->embed_w, E, bio->d_onehot, d.V + 1, (Lp - 1) * B, d.V + 1, E,
+                        nullptr, false, false, st));
+        }
+    }
+#undef RUN
+    return 0;
+}

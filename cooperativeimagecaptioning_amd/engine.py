@@ -6,7 +6,8 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import lib, check, stream, SpeakerDims, SpeakerParams, DecodeIO, SPEAKER_PARAM_FIELDS
+from ._lib import (lib, check, stream, SpeakerDims, SpeakerParams, DecodeIO, SPEAKER_PARAM_FIELDS,
+                   ListenerDims, ListenerParams, ListenerIO, ListenerBwdIO, LISTENER_PARAM_FIELDS)
 
 P = C.c_void_p
 
@@ -17,6 +18,18 @@ lib.cic_speaker_att_embed_fwd.restype = C.c_int
 lib.cic_speaker_decode_fwd.argtypes = [C.POINTER(SpeakerDims), C.POINTER(SpeakerParams), C.POINTER(DecodeIO), P,
                                        C.c_size_t, P]
 lib.cic_speaker_decode_fwd.restype = C.c_int
+
+
+lib.cic_listener_ws_bytes.argtypes = [C.POINTER(ListenerDims)]
+lib.cic_listener_ws_bytes.restype = C.c_size_t
+lib.cic_listener_fwd.argtypes = [C.POINTER(ListenerDims), C.POINTER(ListenerParams), C.POINTER(ListenerIO), P,
+                                 C.c_size_t, P]
+lib.cic_listener_fwd.restype = C.c_int
+lib.cic_listener_bwd.argtypes = [C.POINTER(ListenerDims), C.POINTER(ListenerParams), C.POINTER(ListenerIO),
+                                 C.POINTER(ListenerBwdIO), P, C.c_size_t, P]
+lib.cic_listener_bwd.restype = C.c_int
+
+ONLY_ONE = {'off': 0, 'image': 1, 'caption': 2}
 
 
 def _p(t):
@@ -70,3 +83,52 @@ def speaker_decode_fwd(dims, params, att_pre, mode, temp=1.0, att_masks=None, at
     check(lib.cic_speaker_decode_fwd(C.byref(dims), C.byref(params), C.byref(io), ws.data_ptr(), ws.numel(),
                                      stream()), 'cic_speaker_decode_fwd')
     return out
+
+
+def listener_dims(B, F, E, J, V, T, Lp, margin=0.2, max_violation=1, no_imgnorm=0, use_abs=0):
+    d = ListenerDims()
+    d.B, d.F, d.E, d.J, d.V, d.T, d.Lp = B, F, E, J, V, T, Lp
+    d.margin, d.max_violation, d.no_imgnorm, d.use_abs = float(margin), int(max_violation), int(no_imgnorm), int(use_abs)
+    return d
+
+
+def listener_params(tensors):
+    lp = ListenerParams()
+    for field, key in LISTENER_PARAM_FIELDS:
+        t = tensors.get(key)
+        setattr(lp, field, _p(t) if t is not None else None)
+    return lp
+
+
+def listener_fwd(dims, params, fc_feats, labels=None, masks=None, seq=None, stv=None, L=None,
+                 only_one_retrieval='off', want_emb=False, ws=None):
+    """-> dict(loss_rows f32[B], loss_sum f32[1], img_emb, cap_emb, ws, io)."""
+    dev = fc_feats.device
+    nbytes = lib.cic_listener_ws_bytes(C.byref(dims))
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    out = dict(loss_rows=torch.empty(dims.B, device=dev), loss_sum=torch.empty(1, device=dev), ws=ws,
+               img_emb=torch.empty(dims.B, dims.J, device=dev) if want_emb else None,
+               cap_emb=torch.empty(dims.B, dims.J, device=dev) if want_emb else None)
+    io = ListenerIO()
+    io.fc_feats, io.labels, io.masks = _p(fc_feats), _p(labels), _p(masks)
+    io.seq, io.stv, io.L = _p(seq), _p(stv), _p(L)
+    io.only_one_retrieval = ONLY_ONE[only_one_retrieval]
+    io.loss_rows, io.loss_sum = _p(out['loss_rows']), _p(out['loss_sum'])
+    io.img_emb_out, io.cap_emb_out = _p(out['img_emb']), _p(out['cap_emb'])
+    check(lib.cic_listener_fwd(C.byref(dims), C.byref(params), C.byref(io), ws.data_ptr(), ws.numel(), stream()),
+          'cic_listener_fwd')
+    out['io'] = io
+    out['_keep'] = (fc_feats, labels, masks, seq, stv, L)     # keep inputs alive for the backward call
+    return out
+
+
+def listener_bwd(dims, params, fwd, g_rows=None, g_scalar=None, grads=None, d_onehot=None):
+    bio = ListenerBwdIO()
+    bio.g_rows, bio.g_scalar = _p(g_rows), _p(g_scalar)
+    gp = listener_params(grads) if grads is not None else None
+    bio.grads = C.pointer(gp) if gp is not None else None
+    bio.d_onehot = _p(d_onehot)
+    ws = fwd['ws']
+    check(lib.cic_listener_bwd(C.byref(dims), C.byref(params), C.byref(fwd['io']), C.byref(bio), ws.data_ptr(),
+                               ws.numel(), stream()), 'cic_listener_bwd')

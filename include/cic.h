@@ -171,6 +171,56 @@ size_t cic_speaker_decode_ws_bytes(const cic_speaker_dims* d);
 int cic_speaker_decode_fwd(const cic_speaker_dims* d, const cic_speaker_params* p, const cic_decode_io* io,
                            void* ws, size_t ws_bytes, cic_stream_t s);
 
+/* ---- listener (VSE-fc) engines: models/VSEFCModel.py:12-241 ------------------------------ */
+typedef struct {
+    int B, F, E, J, V;   /* batch, fc_feat_size, input_encoding_size, vse_embed_size, vocab_size */
+    int T;               /* seq_length of generated captions (Lp = T+1 for them) */
+    int Lp;              /* token positions per caption: T+1 (generated) or labels.shape[1] */
+    float margin;        /* vse_margin */
+    int max_violation;   /* vse_max_violation */
+    int no_imgnorm;      /* vse_no_imgnorm */
+    int use_abs;         /* vse_use_abs */
+} cic_listener_dims;
+
+typedef struct {
+    float *img_fc_w, *img_fc_b;   /* img_enc.fc                 [J, F], [J] */
+    float* embed_w;               /* txt_enc.embed.weight       [V+2, E] */
+    float *w_ih, *w_hh;           /* txt_enc.rnn.weight_{ih,hh}_l0  [3J, E], [3J, J] */
+    float *b_ih, *b_hh;           /* txt_enc.rnn.bias_{ih,hh}_l0    [3J] */
+} cic_listener_params;
+
+typedef struct {
+    const float* fc_feats;    /* [B, F] */
+    /* caption source A: ground-truth indices (VSEFCModel.py:106) */
+    const int64_t* labels;    /* [B, Lp] or NULL */
+    const float* masks;       /* [B, Lp] */
+    /* caption source B: a decode's output (AlternatingJointModel.py:353-371) */
+    const int32_t* seq;       /* [B, T] */
+    const float* stv;         /* [B, T] straight-through values or NULL (plain indices) */
+    const int32_t* L;         /* [1] */
+    int only_one_retrieval;   /* 0 off, 1 'image', 2 'caption' (VSEFCModel.py:202-207) */
+    float* loss_rows;         /* out [B]: per-row loss (whole_batch=True) */
+    float* loss_sum;          /* out [1]: scalar loss (whole_batch=False) */
+    float* img_emb_out;       /* out [B, J] or NULL */
+    float* cap_emb_out;       /* out [B, J] or NULL */
+} cic_listener_io;
+
+typedef struct {
+    const float* g_rows;          /* [B] upstream gradient per row, or NULL */
+    const float* g_scalar;        /* [1] upstream gradient of the scalar loss (used if g_rows is NULL) */
+    const cic_listener_params* grads; /* accumulated into (+=); NULL = no parameter gradients */
+    float* d_onehot;              /* out [T, B, V+1] gradient w.r.t. the one-hot rows of the generated
+                                     tokens (time-major), or NULL */
+} cic_listener_bwd_io;
+
+size_t cic_listener_ws_bytes(const cic_listener_dims* d);
+/* VSEFCModel.forward (:230-241): EncoderImage, EncoderText (GRU, last-valid state), ContrastiveLoss. */
+int cic_listener_fwd(const cic_listener_dims* d, const cic_listener_params* p, const cic_listener_io* io,
+                     void* ws, size_t ws_bytes, cic_stream_t s);
+/* autograd of the above; ws must be the workspace of the matching forward call. */
+int cic_listener_bwd(const cic_listener_dims* d, const cic_listener_params* p, const cic_listener_io* io,
+                     const cic_listener_bwd_io* bio, void* ws, size_t ws_bytes, cic_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif
