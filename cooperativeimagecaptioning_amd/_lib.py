@@ -81,6 +81,10 @@ class DecodeIO(C.Structure):
                 ('seq', c_ptr), ('slp', c_ptr), ('stv', c_ptr), ('L', c_ptr)]
 
 
+class DecodeBwdIO(C.Structure):
+    _fields_ = [('d_onehot', c_ptr), ('dslp', c_ptr), ('grads', C.POINTER(SpeakerParams)), ('att_raw', c_ptr)]
+
+
 class ListenerDims(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('B', 'F', 'E', 'J', 'V', 'T', 'Lp')] + [
         ('margin', C.c_float), ('max_violation', C.c_int), ('no_imgnorm', C.c_int), ('use_abs', C.c_int)]

@@ -1,0 +1,532 @@
+// Speaker (att2in2) backward kernels: hand-written reverse of speaker_fwd.hip.
+//   sampler_bwd   d(one-hot rows, sampled log-probs) -> d logits          (gumbel.py:17-30, multinomial.py:4-27)
+//   cell_bwd      maxout-LSTM cell pointwise part                          (AttModel.py:515-529)
+//   attn_bwd      per-step attention: d att_res -> d att_h, d dot          (AttModel.py:465-489)
+//   attn_bwd_feats  after the time loop: d att, d p_att, d alpha_net       (sum over all steps in one pass)
+//   embed_bwd, relu_keep_bwd
+// The time loop only carries what is truly recurrent (dh, dc); every weight gradient and the
+// two [B,K,H] feature gradients are formed once after the loop from saved per-step slabs.
+#include "cic_common.h"
+#include "engine_util.h"
+
+namespace {
+
+__device__ __forceinline__ float gumbel_from_u(float u) { return -logf(-logf(u + 1e-20f) + 1e-20f); }
+
+__device__ __forceinline__ float block_sum4(float v, float* sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+__device__ __forceinline__ float block_max4(float v, float* sh) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+// One workgroup per (t, b) row of the vocabulary.
+//   y = softmax(z), z = (logp + g)/tau (gumbel-ST) or logp/tau (multinomial-ST)
+//   one_hot = (y_hard - y).detach() + y  =>  d y = G (masked by `unfinished`; finished rows were
+//   overwritten by the constant EOS one-hot, AttModel.py:416-420)
+//   d logits_j = unf * y_j (G_j - sum_i y_i G_i) / tau + dslp * ([j == it] - exp(logp_j))
+template <int RV>
+__global__ __launch_bounds__(256) void sampler_bwd_kernel(const float* __restrict__ logp_all,   // [T,B,V1]
+                                                          const float* __restrict__ U,          // [T+1,B,V1] or null
+                                                          const float* __restrict__ G,          // [T,B,V1] or null
+                                                          const int32_t* __restrict__ it_all,   // [T+1,B]
+                                                          const int32_t* __restrict__ seq,      // [B,T] or null
+                                                          const float* __restrict__ dslp,       // [B,T] or null
+                                                          const int32_t* __restrict__ Lp, int mode, float tau,
+                                                          float* __restrict__ dlogits,          // [T,B,V1] (may alias G)
+                                                          int T, int B, int V1) {
+    __shared__ float sh[4];
+    const int row = blockIdx.x, t = row / B, b = row % B, tid = threadIdx.x;
+    const int L = Lp ? *Lp : T;
+    const float* lp = logp_all + (size_t)row * V1;
+    float* out = dlogits + (size_t)row * V1;
+    const float* g = G ? G + (size_t)row * V1 : nullptr;
+    const int it = it_all[(size_t)(t + 1) * B + b];
+    const float ds = (dslp && t < L) ? dslp[(size_t)b * T + t] : 0.f;
+    const bool st_mode = (mode == CIC_SAMPLE_GUMBEL_ST || mode == CIC_SAMPLE_MULTINOMIAL_ST);
+    const bool unf = st_mode && g && seq && t < L && seq[(size_t)b * T + t] > 0;
+    const int nq = (V1 + 3) >> 2;
+    if (!unf && ds == 0.f) {   // block-uniform: nothing flows into this row
+        for (int c = tid; c < V1; c += 256) out[c] = 0.f;
+        return;
+    }
+    const float inv_t = 1.0f / tau;
+    const float* urow = U ? U + ((size_t)(t + 1) * B + b) * V1 : nullptr;
+    float x[RV][4], y[RV][4], gg[RV][4];
+    float zm = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < RV; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * (tid + 256 * r) + e;
+            const bool ok = (tid + 256 * r) < nq && c < V1;
+            x[r][e] = ok ? lp[c] : -INFINITY;
+            gg[r][e] = (ok && unf) ? g[c] : 0.f;
+            float z = -INFINITY;
+            if (ok && unf) {
+                z = (mode == CIC_SAMPLE_GUMBEL_ST) ? (x[r][e] + gumbel_from_u(urow[c])) * inv_t : x[r][e] * inv_t;
+            }
+            y[r][e] = z;
+            zm = fmaxf(zm, z);
+        }
+    float cdot = 0.f, ysum = 1.f;
+    if (unf) {
+        zm = block_max4(zm, sh);
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < RV; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[r][e] = __expf(y[r][e] - zm);
+                s += y[r][e];
+            }
+        ysum = block_sum4(s, sh);
+        const float inv = 1.0f / ysum;
+        float c = 0.f;
+#pragma unroll
+        for (int r = 0; r < RV; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[r][e] *= inv;
+                c += y[r][e] * gg[r][e];
+            }
+        cdot = block_sum4(c, sh);
+    }
+#pragma unroll
+    for (int r = 0; r < RV; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * (tid + 256 * r) + e;
+            if ((tid + 256 * r) < nq && c < V1) {
+                float v = 0.f;
+                if (unf) v = y[r][e] * (gg[r][e] - cdot) * inv_t;
+                if (ds != 0.f) v += ds * ((c == it ? 1.f : 0.f) - __expf(x[r][e]));
+                out[c] = v;
+            }
+        }
+}
+
+// ---- cell backward -----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cell_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ c_prev,
+                                                       const float* __restrict__ c_new, const float* __restrict__ d_out,
+                                                       const float* __restrict__ dh_carry, float* __restrict__ dc_carry,
+                                                       const uint8_t* __restrict__ keep, float scale,
+                                                       float* __restrict__ dpre, int B, int H, int first) {
+    // first != 0: dh_carry / dc_carry hold nothing yet (last time step)
+    const int H4 = H >> 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * H4) return;
+    const int b = idx / H4, j = idx % H4;
+    const f32x4* p = reinterpret_cast<const f32x4*>(pre + (size_t)b * 5 * H);
+    const f32x4 pi = p[j], pf = p[H4 + j], po = p[2 * H4 + j], pa = p[3 * H4 + j], pb = p[4 * H4 + j];
+    const f32x4 cp = reinterpret_cast<const f32x4*>(c_prev)[idx];
+    const f32x4 cn = reinterpret_cast<const f32x4*>(c_new)[idx];
+    const f32x4 dout = reinterpret_cast<const f32x4*>(d_out)[idx];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 dhc = first ? zero : reinterpret_cast<const f32x4*>(dh_carry)[idx];
+    const f32x4 dcc = first ? zero : reinterpret_cast<const f32x4*>(dc_carry)[idx];
+    uint32_t kp = 0x01010101u;
+    if (keep) kp = *reinterpret_cast<const uint32_t*>(keep + (size_t)idx * 4);
+    f32x4 gi, gf, go, ga, gb, dcp;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float ig = fast_sigmoid(pi[e]), fg = fast_sigmoid(pf[e]), og = fast_sigmoid(po[e]);
+        const float g = fmaxf(pa[e], pb[e]);
+        const float tc = fast_tanh(cn[e]);
+        const float kf = keep ? (float)((kp >> (8 * e)) & 0xffu) * scale : 1.0f;
+        const float dh = dout[e] * kf + dhc[e];
+        const float dc = dcc[e] + dh * og * (1.0f - tc * tc);
+        gi[e] = dc * g * ig * (1.0f - ig);
+        gf[e] = dc * cp[e] * fg * (1.0f - fg);
+        go[e] = dh * tc * og * (1.0f - og);
+        const float dg = dc * ig;
+        // torch.max(a, b) backward: larger gets it, exact tie splits it evenly
+        ga[e] = pa[e] > pb[e] ? dg : (pa[e] == pb[e] ? 0.5f * dg : 0.f);
+        gb[e] = pb[e] > pa[e] ? dg : (pa[e] == pb[e] ? 0.5f * dg : 0.f);
+        dcp[e] = dc * fg;
+    }
+    f32x4* o = reinterpret_cast<f32x4*>(dpre + (size_t)b * 5 * H);
+    o[j] = gi; o[H4 + j] = gf; o[2 * H4 + j] = go; o[3 * H4 + j] = ga; o[4 * H4 + j] = gb;
+    reinterpret_cast<f32x4*>(dc_carry)[idx] = dcp;
+}
+
+// ---- per-step attention backward ---------------------------------------------------------
+// in : d_att_res[b,:], alpha[b,:], att_h[b,:], p_att[b], att[b]
+// out: ddot[b,k] = alpha_k (dalpha_k - sum_j alpha_j dalpha_j),  dalpha_k = d_att_res . att[b,k,:]
+//      d_att_h[b,a] = w_a * sum_k ddot_k (1 - tanh^2(p_att[b,k,a] + att_h[b,a]))
+// (a masked, renormalised softmax is alpha_k ~ m_k e^{dot_k}: same Jacobian in terms of the final alpha)
+template <int NI, int KPW, bool HOLD>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ d_att_res, const float* __restrict__ alpha,
+                                                       const float* __restrict__ att_h, const float* __restrict__ p_att,
+                                                       const float* __restrict__ att, const float* __restrict__ w_alpha,
+                                                       float* __restrict__ d_att_h, float* __restrict__ ddot_out, int K,
+                                                       int A, int H) {
+    __shared__ float sd[64];
+    __shared__ __attribute__((aligned(16))) float sacc[4 * NI * 256];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int A4 = A >> 2, H4 = H >> 2;
+    const f32x4* pa4 = reinterpret_cast<const f32x4*>(p_att + (size_t)b * K * A);
+    const f32x4* at4 = reinterpret_cast<const f32x4*>(att + (size_t)b * K * H);
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 dr[NI], ah[NI], wa[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = lane + 64 * i;
+        dr[i] = c < H4 ? reinterpret_cast<const f32x4*>(d_att_res + (size_t)b * H)[c] : z4;
+        ah[i] = c < A4 ? reinterpret_cast<const f32x4*>(att_h + (size_t)b * A)[c] : z4;
+        wa[i] = c < A4 ? reinterpret_cast<const f32x4*>(w_alpha)[c] : z4;
+    }
+    f32x4 pv[HOLD ? KPW : 1][NI];
+#pragma unroll
+    for (int j = 0; j < KPW; ++j) {
+        const int k = w + 4 * j;
+        if (k < K) {
+            float part = 0.f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int c = lane + 64 * i;
+                const f32x4 a = c < H4 ? at4[(size_t)k * H4 + c] : z4;
+                if (HOLD) pv[j][i] = c < A4 ? pa4[(size_t)k * A4 + c] : z4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part += dr[i][e] * a[e];
+            }
+            part = wave_sum(part);
+            if (lane == 0) sd[k] = part;
+        }
+    }
+    __syncthreads();
+    float cs = 0.f;
+    for (int k = 0; k < K; ++k) cs += alpha[(size_t)b * K + k] * sd[k];
+    f32x4 acc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[i] = z4;
+#pragma unroll
+    for (int j = 0; j < KPW; ++j) {
+        const int k = w + 4 * j;
+        if (k < K) {
+            const float dd = alpha[(size_t)b * K + k] * (sd[k] - cs);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int c = lane + 64 * i;
+                f32x4 p;
+                if (HOLD) p = pv[j][i];
+                else p = c < A4 ? pa4[(size_t)k * A4 + c] : z4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float th = fast_tanh(p[e] + ah[i][e]);
+                    acc[i][e] += dd * (1.0f - th * th);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][e] *= wa[i][e];
+        *reinterpret_cast<f32x4*>(&sacc[(w * NI * 64 + i * 64 + lane) * 4]) = acc[i];
+    }
+    __syncthreads();
+    for (int c = tid; c < A4; c += 256) {
+        const int i = c >> 6, l = c & 63;
+        f32x4 s = *reinterpret_cast<f32x4*>(&sacc[((0 * NI + i) * 64 + l) * 4]);
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) s += *reinterpret_cast<f32x4*>(&sacc[((ww * NI + i) * 64 + l) * 4]);
+        reinterpret_cast<f32x4*>(d_att_h + (size_t)b * A)[c] = s;
+    }
+    if (tid < K) ddot_out[(size_t)b * K + tid] = alpha[(size_t)b * K + tid] * (sd[tid] - cs);
+}
+
+// ---- feature gradients after the time loop ----------------------------------------------------
+//   d_att[b,k,:]   = sum_t alpha_t[b,k] * d_att_res_t[b,:]
+//   d_p_att[b,k,a] = w_a * sum_t ddot_t[b,k] * (1 - tanh^2(p_att[b,k,a] + att_h_t[b,a]))
+//   d w_alpha[a]  += sum_{t,b,k} ddot_t[b,k] * tanh(...),   d b_alpha += sum ddot
+// One workgroup per image; the per-step row vectors (att_h_t, d_att_res_t) and scalars of that
+// image are staged once in LDS (dynamic, T*(A+H+2K) floats) and re-used by all K regions.
+template <int NI>
+__global__ __launch_bounds__(256) void attn_bwd_feats_kernel(const float* __restrict__ p_att, const float* __restrict__ att_h_all,
+                                                             const float* __restrict__ d_att_res_all,
+                                                             const float* __restrict__ alpha_all,
+                                                             const float* __restrict__ ddot_all,
+                                                             const float* __restrict__ w_alpha, float* __restrict__ d_att,
+                                                             float* __restrict__ d_p_att, float* __restrict__ dw_alpha,
+                                                             float* __restrict__ db_alpha, int T, int B, int K, int A,
+                                                             int H) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* s_ah = lds;                     // [T][A]
+    float* s_dr = s_ah + (size_t)T * A;    // [T][H]
+    float* s_al = s_dr + (size_t)T * H;    // [T][K]
+    float* s_dd = s_al + (size_t)T * K;    // [T][K]
+    float* s_dw = s_dd + (size_t)T * K;    // [4][NI*256] cross-wave reduce of dw_alpha
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int A4 = A >> 2, H4 = H >> 2;
+    for (int i = tid; i < T * A4; i += 256) {
+        const int t = i / A4, c = i % A4;
+        reinterpret_cast<f32x4*>(s_ah)[i] = reinterpret_cast<const f32x4*>(att_h_all + ((size_t)t * B + b) * A)[c];
+    }
+    for (int i = tid; i < T * H4; i += 256) {
+        const int t = i / H4, c = i % H4;
+        reinterpret_cast<f32x4*>(s_dr)[i] = reinterpret_cast<const f32x4*>(d_att_res_all + ((size_t)t * B + b) * H)[c];
+    }
+    float bsum = 0.f;
+    for (int i = tid; i < T * K; i += 256) {
+        const int t = i / K, k = i % K;
+        s_al[i] = alpha_all[((size_t)t * B + b) * K + k];
+        const float dd = ddot_all[((size_t)t * B + b) * K + k];
+        s_dd[i] = dd;
+        bsum += dd;
+    }
+    __syncthreads();
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 wa[NI], dw[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = lane + 64 * i;
+        wa[i] = c < A4 ? reinterpret_cast<const f32x4*>(w_alpha)[c] : z4;
+        dw[i] = z4;
+    }
+    for (int k = w; k < K; k += 4) {
+        f32x4 p[NI], dp[NI], da[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int c = lane + 64 * i;
+            p[i] = c < A4 ? reinterpret_cast<const f32x4*>(p_att + ((size_t)b * K + k) * A)[c] : z4;
+            dp[i] = z4;
+            da[i] = z4;
+        }
+        for (int t = 0; t < T; ++t) {
+            const float al = s_al[t * K + k], dd = s_dd[t * K + k];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int c = lane + 64 * i;
+                if (c < A4) {
+                    const f32x4 ah = reinterpret_cast<const f32x4*>(s_ah + (size_t)t * A)[c];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float th = fast_tanh(p[i][e] + ah[e]);
+                        dp[i][e] += dd * (1.0f - th * th);
+                        dw[i][e] += dd * th;
+                    }
+                }
+                if (c < H4) da[i] += al * reinterpret_cast<const f32x4*>(s_dr + (size_t)t * H)[c];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int c = lane + 64 * i;
+            if (c < A4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dp[i][e] *= wa[i][e];
+                reinterpret_cast<f32x4*>(d_p_att + ((size_t)b * K + k) * A)[c] = dp[i];
+            }
+            if (c < H4) reinterpret_cast<f32x4*>(d_att + ((size_t)b * K + k) * H)[c] = da[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<f32x4*>(&s_dw[(w * NI * 64 + i * 64 + lane) * 4]) = dw[i];
+    __syncthreads();
+    for (int a = tid; a < A; a += 256) {
+        const int c = a >> 2, e = a & 3, i = c >> 6, l = c & 63;
+        float s = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) s += s_dw[((ww * NI + i) * 64 + l) * 4 + e];
+        atomicAdd(dw_alpha + a, s);
+    }
+    bsum = wave_sum(bsum);
+    if (lane == 0) atomicAdd(db_alpha, bsum);
+}
+
+// dE[it[t,b], :] += dx[t,b,:] * [E[it] > 0] * keep * scale        (AttModel.py:74-76 reversed)
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ E, const int32_t* __restrict__ it_all,
+                                                        const uint8_t* __restrict__ keep, float scale,
+                                                        const float* __restrict__ dx, float* __restrict__ dE, int TB,
+                                                        int Ed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)TB * Ed) return;
+    const int r = (int)(i / Ed), j = (int)(i % Ed);
+    const int tok = it_all[r];
+    if (E[(size_t)tok * Ed + j] <= 0.f) return;
+    float g = dx[i];
+    if (keep) g *= (float)keep[i] * scale;
+    if (g != 0.f) atomicAdd(dE + (size_t)tok * Ed + j, g);
+}
+
+// d_pre = d_att * keep * scale * [att_pre > 0]                     (AttModel.py:82-85 reversed)
+__global__ __launch_bounds__(256) void relu_keep_bwd_kernel(const float* __restrict__ d_att, const float* __restrict__ att_pre,
+                                                            const uint8_t* __restrict__ keep, float scale,
+                                                            float* __restrict__ d_pre, int64_t n4) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n4) return;
+    f32x4 g = reinterpret_cast<const f32x4*>(d_att)[idx];
+    const f32x4 a = reinterpret_cast<const f32x4*>(att_pre)[idx];
+    uint32_t kp = 0x01010101u;
+    if (keep) kp = *reinterpret_cast<const uint32_t*>(keep + idx * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float kf = keep ? (float)((kp >> (8 * e)) & 0xffu) * scale : 1.0f;
+        g[e] = a[e] > 0.f ? g[e] * kf : 0.f;
+    }
+    reinterpret_cast<f32x4*>(d_pre)[idx] = g;
+}
+
+struct SpkBws {
+    float *dlogits, *d_out_all, *dpre_all, *d_att_h_all, *d_att_res_all, *ddot_all, *dh_a, *dh_b, *dc, *dx_all;
+    float *d_att, *d_p_att, *d_attpre;
+    size_t bytes;
+};
+SpkBws spk_bcarve(const cic_speaker_dims& d, void* base, bool own_dlogits) {
+    SpkBws w;
+    Carver c(base);
+    const size_t B = d.B, K = d.K, H = d.H, E = d.E, A = d.A, T = d.T, V1 = d.V + 1;
+    w.dlogits = own_dlogits ? c.f32(T * B * V1) : nullptr;
+    w.d_out_all = c.f32(T * B * H);
+    w.dpre_all = c.f32(T * B * 5 * H);
+    w.d_att_h_all = c.f32(T * B * A);
+    w.d_att_res_all = c.f32(T * B * H);
+    w.ddot_all = c.f32(T * B * K);
+    w.dh_a = c.f32(B * H);
+    w.dh_b = c.f32(B * H);
+    w.dc = c.f32(B * H);
+    w.dx_all = c.f32(T * B * E);
+    w.d_att = c.f32(B * K * H);
+    w.d_p_att = c.f32(B * K * A);
+    w.d_attpre = c.f32(B * K * H);
+    w.bytes = c.used();
+    return w;
+}
+
+}  // namespace
+
+extern "C" size_t cic_speaker_decode_bwd_ws_bytes(const cic_speaker_dims* d) {
+    if (!d) return 0;
+    return spk_bcarve(*d, nullptr, true).bytes;
+}
+
+extern "C" int cic_speaker_decode_bwd(const cic_speaker_dims* dp, const cic_speaker_params* p, const cic_decode_io* io,
+                                      const cic_decode_bwd_io* bio, void* ws_fwd, size_t ws_fwd_bytes, void* ws_bwd,
+                                      size_t ws_bwd_bytes, cic_stream_t s) {
+    CIC_REQUIRE(dp && p && io && bio && ws_fwd && ws_bwd && bio->grads && bio->att_raw);
+    const cic_speaker_dims& d = *dp;
+    SpkWs w = spk_carve(d, ws_fwd);
+    CIC_REQUIRE(ws_fwd_bytes >= w.bytes);
+    SpkBws g = spk_bcarve(d, ws_bwd, true);
+    CIC_REQUIRE(ws_bwd_bytes >= g.bytes);
+    CIC_REQUIRE(!(bio->d_onehot && io->mode == CIC_SAMPLE_GUMBEL_ST) || io->U);
+    CIC_REQUIRE(!bio->d_onehot || io->seq);
+    hipStream_t st = cic_s(s);
+    const int B = d.B, K = d.K, H = d.H, E = d.E, A = d.A, T = d.T, V1 = d.V + 1, D = d.D;
+    const float scale = 1.0f / (1.0f - d.p_drop);
+    const cic_speaker_params* gr = bio->grads;
+    int rc;
+#define RUN(x) if ((rc = (x)) != 0) return rc
+
+    // 1. d logits for every step at once (rows are independent of the recurrence)
+    {
+        dim3 grid(T * B), blk(256);
+#define GO(RV) hipLaunchKernelGGL((sampler_bwd_kernel<RV>), grid, blk, 0, st, w.logp_all, io->U, bio->d_onehot, w.it_all, \
+                                  io->seq, bio->dslp, io->L, io->mode, io->temp, g.dlogits, T, B, V1)
+        if (V1 <= 1024) GO(1); else if (V1 <= 4096) GO(4); else if (V1 <= 10240) GO(10);
+        else { cic_set_error("vocabulary too large"); return 1; }
+#undef GO
+        CIC_LAUNCH_CHECK();
+    }
+    // 2. logit layer, batched over time: d_out = dlogits W,  dW += dlogits^T out,  db += colsum
+    RUN(gemm_nn(g.dlogits, V1, p->logit_w, H, g.d_out_all, H, T * B, H, V1, false, st));
+    RUN(gemm_tn(g.dlogits, V1, w.out_all, H, gr->logit_w, H, V1, H, T * B, true, st));
+    RUN(cic_colsum_f32(g.dlogits, T * B, V1, V1, gr->logit_b, 1, s));
+
+    // 3. BPTT over the cell + attention (only dh, dc are carried)
+    float* dh_in = g.dh_a;
+    float* dh_out = g.dh_b;
+    for (int t = T - 1; t >= 0; --t) {
+        const uint8_t* ok = io->out_keep ? io->out_keep + (size_t)t * B * H : nullptr;
+        float* dpre = g.dpre_all + (size_t)t * B * 5 * H;
+        hipLaunchKernelGGL(cell_bwd_kernel, dim3(cic_cdiv(B * (H / 4), 256)), dim3(256), 0, st,
+                           w.pre_all + (size_t)t * B * 5 * H, w.c_all + (size_t)t * B * H,
+                           w.c_all + (size_t)(t + 1) * B * H, g.d_out_all + (size_t)t * B * H, dh_in, g.dc, ok, scale,
+                           dpre, B, H, t == T - 1 ? 1 : 0);
+        CIC_LAUNCH_CHECK();
+        // d att_res = d in_transform a2c.W            [B,2H] x [2H,H]
+        float* dres = g.d_att_res_all + (size_t)t * B * H;
+        RUN(gemm_nn(dpre + 3 * H, 5 * H, p->a2c_w, H, dres, H, B, H, 2 * H, false, st));
+        {
+            dim3 grid(B), blk(256);
+            const int mx = A > H ? A : H;
+            float* dah = g.d_att_h_all + (size_t)t * B * A;
+            float* ddot = g.ddot_all + (size_t)t * B * K;
+            const float* al = w.alpha_all + (size_t)t * B * K;
+            const float* ah = w.att_h_all + (size_t)t * B * A;
+#define GO(NI, KPW, HOLD) hipLaunchKernelGGL((attn_bwd_kernel<NI, KPW, HOLD>), grid, blk, 0, st, dres, al, ah, w.p_att, \
+                                             w.att, p->alpha_w, dah, ddot, K, A, H)
+            if (mx <= 256) { if (K <= 36) GO(1, 9, true); else GO(1, 16, false); }
+            else if (mx <= 512) { if (K <= 36) GO(2, 9, true); else GO(2, 16, false); }
+            else GO(4, 16, false);
+#undef GO
+            CIC_LAUNCH_CHECK();
+        }
+        if (t > 0) {
+            // dh_t = dpre h2h.W + d_att_h h2att.W       [B,5H]x[5H,H] + [B,A]x[A,H]
+            RUN(gemm_nn2(dpre, 5 * H, p->h2h_w, H, 5 * H, g.d_att_h_all + (size_t)t * B * A, A, p->h2att_w, H, A,
+                         dh_out, H, B, H, false, st));
+            float* tmp = dh_in; dh_in = dh_out; dh_out = tmp;
+        }
+    }
+    // 4. weight gradients of the recurrent part, batched over time
+    RUN(gemm_tn(g.dpre_all, 5 * H, w.x_all, E, gr->i2h_w, E, 5 * H, E, T * B, true, st));
+    RUN(gemm_tn(g.dpre_all, 5 * H, w.h_all, H, gr->h2h_w, H, 5 * H, H, T * B, true, st));
+    RUN(cic_colsum_f32(g.dpre_all, T * B, 5 * H, 5 * H, gr->i2h_b, 1, s));
+    RUN(cic_colsum_f32(g.dpre_all, T * B, 5 * H, 5 * H, gr->h2h_b, 1, s));
+    RUN(gemm_tn(g.dpre_all + 3 * H, 5 * H, w.att_res_all, H, gr->a2c_w, H, 2 * H, H, T * B, true, st));
+    RUN(cic_colsum_f32(g.dpre_all + 3 * H, T * B, 2 * H, 5 * H, gr->a2c_b, 1, s));
+    RUN(gemm_tn(g.d_att_h_all, A, w.h_all, H, gr->h2att_w, H, A, H, T * B, true, st));
+    RUN(cic_colsum_f32(g.d_att_h_all, T * B, A, A, gr->h2att_b, 1, s));
+    // token embedding: dx = dpre i2h.W, scattered into the embedding rows
+    RUN(gemm_nn(g.dpre_all, 5 * H, p->i2h_w, E, g.dx_all, E, T * B, E, 5 * H, false, st));
+    {
+        const int64_t n = (int64_t)T * B * E;
+        hipLaunchKernelGGL(embed_bwd_kernel, dim3(cic_cdiv(n, 256)), dim3(256), 0, st, p->embed_w, w.it_all, io->x_keep,
+                           scale, g.dx_all, gr->embed_w, T * B, E);
+        CIC_LAUNCH_CHECK();
+    }
+    // 5. attention features: d att, d p_att, d alpha_net in one pass over p_att
+    {
+        const int mx = A > H ? A : H;
+        const int NIv = mx <= 256 ? 1 : (mx <= 512 ? 2 : 4);
+        const size_t shm = sizeof(float) * ((size_t)T * (A + H + 2 * K) + 4 * NIv * 256);
+        dim3 grid(B), blk(256);
+#define GO(NI)                                                                                                       \
+    do {                                                                                                             \
+        CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_feats_kernel<NI>),                       \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));                          \
+        hipLaunchKernelGGL((attn_bwd_feats_kernel<NI>), grid, blk, shm, st, w.p_att, w.att_h_all, g.d_att_res_all,   \
+                           w.alpha_all, g.ddot_all, p->alpha_w, g.d_att, g.d_p_att, gr->alpha_w, gr->alpha_b, T, B,  \
+                           K, A, H);                                                                                 \
+    } while (0)
+        CIC_REQUIRE(shm <= 160 * 1024);
+        if (NIv == 1) GO(1); else if (NIv == 2) GO(2); else GO(4);
+#undef GO
+        CIC_LAUNCH_CHECK();
+    }
+    // ctx2att: d att += d p_att W,  dW += d p_att^T att,  db += colsum
+    RUN(gemm_nn(g.d_p_att, A, p->ctx2att_w, H, g.d_att, H, B * K, H, A, true, st));
+    RUN(gemm_tn(g.d_p_att, A, w.att, H, gr->ctx2att_w, H, A, H, B * K, true, st));
+    RUN(cic_colsum_f32(g.d_p_att, B * K, A, A, gr->ctx2att_b, 1, s));
+    // att_embed: through dropout and ReLU, then dW += d_pre^T att_raw
+    {
+        const int64_t n4 = (int64_t)B * K * H / 4;
+        hipLaunchKernelGGL(relu_keep_bwd_kernel, dim3(cic_cdiv(n4, 256)), dim3(256), 0, st, g.d_att, io->att_pre,
+                           io->att_keep, scale, g.d_attpre, n4);
+        CIC_LAUNCH_CHECK();
+    }
+    RUN(gemm_tn(g.d_attpre, H, bio->att_raw, D, gr->att_embed_w, D, H, D, B * K, true, st));
+    RUN(cic_colsum_f32(g.d_attpre, B * K, H, H, gr->att_embed_b, 1, s));
+#undef RUN
+    return 0;
+}

@@ -6,7 +6,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (lib, check, stream, SpeakerDims, SpeakerParams, DecodeIO, SPEAKER_PARAM_FIELDS,
+from ._lib import (lib, check, stream, SpeakerDims, SpeakerParams, DecodeIO, DecodeBwdIO, SPEAKER_PARAM_FIELDS,
                    ListenerDims, ListenerParams, ListenerIO, ListenerBwdIO, LISTENER_PARAM_FIELDS)
 
 P = C.c_void_p
@@ -20,6 +20,11 @@ lib.cic_speaker_decode_fwd.argtypes = [C.POINTER(SpeakerDims), C.POINTER(Speaker
 lib.cic_speaker_decode_fwd.restype = C.c_int
 
 
+lib.cic_speaker_decode_bwd_ws_bytes.argtypes = [C.POINTER(SpeakerDims)]
+lib.cic_speaker_decode_bwd_ws_bytes.restype = C.c_size_t
+lib.cic_speaker_decode_bwd.argtypes = [C.POINTER(SpeakerDims), C.POINTER(SpeakerParams), C.POINTER(DecodeIO),
+                                       C.POINTER(DecodeBwdIO), P, C.c_size_t, P, C.c_size_t, P]
+lib.cic_speaker_decode_bwd.restype = C.c_int
 lib.cic_listener_ws_bytes.argtypes = [C.POINTER(ListenerDims)]
 lib.cic_listener_ws_bytes.restype = C.c_size_t
 lib.cic_listener_fwd.argtypes = [C.POINTER(ListenerDims), C.POINTER(ListenerParams), C.POINTER(ListenerIO), P,
@@ -82,7 +87,26 @@ def speaker_decode_fwd(dims, params, att_pre, mode, temp=1.0, att_masks=None, at
     io.seq, io.slp, io.stv, io.L = _p(out['seq']), _p(out['slp']), _p(out['stv']), _p(out['L'])
     check(lib.cic_speaker_decode_fwd(C.byref(dims), C.byref(params), C.byref(io), ws.data_ptr(), ws.numel(),
                                      stream()), 'cic_speaker_decode_fwd')
+    out['io'] = io
+    out['_keep'] = (att_pre, att_masks, att_keep, x_keep, out_keep, U, pick)   # alive until the backward call
     return out
+
+
+def speaker_decode_bwd(dims, params, fwd, grads, att_raw, d_onehot=None, dslp=None, ws_bwd=None):
+    """Accumulates parameter gradients of one decode into `grads` (dict of tensors keyed like
+    the parameters).  fwd: the dict returned by speaker_decode_fwd."""
+    nbytes = lib.cic_speaker_decode_bwd_ws_bytes(C.byref(dims))
+    if ws_bwd is None or ws_bwd.numel() < nbytes:
+        ws_bwd = torch.empty(nbytes, dtype=torch.uint8, device=att_raw.device)
+    bio = DecodeBwdIO()
+    gp = speaker_params(grads)
+    bio.d_onehot, bio.dslp, bio.att_raw = _p(d_onehot), _p(dslp), _p(att_raw)
+    bio.grads = C.pointer(gp)
+    ws = fwd['ws']
+    check(lib.cic_speaker_decode_bwd(C.byref(dims), C.byref(params), C.byref(fwd['io']), C.byref(bio),
+                                     ws.data_ptr(), ws.numel(), ws_bwd.data_ptr(), ws_bwd.numel(), stream()),
+          'cic_speaker_decode_bwd')
+    return ws_bwd
 
 
 def listener_dims(B, F, E, J, V, T, Lp, margin=0.2, max_violation=1, no_imgnorm=0, use_abs=0):

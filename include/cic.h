@@ -171,6 +171,20 @@ size_t cic_speaker_decode_ws_bytes(const cic_speaker_dims* d);
 int cic_speaker_decode_fwd(const cic_speaker_dims* d, const cic_speaker_params* p, const cic_decode_io* io,
                            void* ws, size_t ws_bytes, cic_stream_t s);
 
+typedef struct {
+    const float* d_onehot;   /* [T,B,V+1] gradient w.r.t. the ST one-hot rows (from cic_listener_bwd) or NULL */
+    const float* dslp;       /* [B,T] gradient w.r.t. the sampled log-probs (io->slp) or NULL */
+    const cic_speaker_params* grads; /* accumulated into (+=) */
+    const float* att_raw;    /* [B,K,D] the raw region features (for the att_embed weight gradient) */
+} cic_decode_bwd_io;
+size_t cic_speaker_decode_bwd_ws_bytes(const cic_speaker_dims* d);
+/* autograd of cic_speaker_decode_fwd: straight-through sampler, logit layer, BPTT through
+ * Att2in2Core/Attention, embeddings, ctx2att, att_embed.  io must be the struct of the
+ * forward call (same noise pointers), ws_fwd its untouched workspace. */
+int cic_speaker_decode_bwd(const cic_speaker_dims* d, const cic_speaker_params* p, const cic_decode_io* io,
+                           const cic_decode_bwd_io* bio, void* ws_fwd, size_t ws_fwd_bytes, void* ws_bwd,
+                           size_t ws_bwd_bytes, cic_stream_t s);
+
 /* ---- listener (VSE-fc) engines: models/VSEFCModel.py:12-241 ------------------------------ */
 typedef struct {
     int B, F, E, J, V;   /* batch, fc_feat_size, input_encoding_size, vse_embed_size, vocab_size */
