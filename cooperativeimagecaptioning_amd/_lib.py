@@ -77,12 +77,19 @@ class SpeakerParams(C.Structure):
 class DecodeIO(C.Structure):
     _fields_ = [('mode', C.c_int), ('temp', C.c_float), ('decoding_constraint', C.c_int),
                 ('att_pre', c_ptr), ('att_masks', c_ptr), ('att_keep', c_ptr), ('x_keep', c_ptr),
-                ('out_keep', c_ptr), ('U', c_ptr), ('pick', c_ptr),
+                ('out_keep', c_ptr), ('U', c_ptr), ('pick', c_ptr), ('first_token', c_ptr),
                 ('seq', c_ptr), ('slp', c_ptr), ('stv', c_ptr), ('L', c_ptr)]
 
 
 class DecodeBwdIO(C.Structure):
     _fields_ = [('d_onehot', c_ptr), ('dslp', c_ptr), ('grads', C.POINTER(SpeakerParams)), ('att_raw', c_ptr)]
+
+
+class CiderdArgs(C.Structure):
+    _fields_ = [('B', C.c_int), ('T', C.c_int), ('n_images', C.c_int), ('spi', C.c_int), ('R', C.c_int),
+                ('Tr', C.c_int), ('gen', c_ptr), ('L_gen', c_ptr), ('greedy', c_ptr), ('L_greedy', c_ptr),
+                ('refs', c_ptr), ('ref_off', c_ptr), ('scores', c_ptr), ('reward', c_ptr), ('stats', c_ptr),
+                ('dbg_keys', c_ptr), ('dbg_cnt', c_ptr), ('dbg_df', c_ptr), ('dbg_nuniq', c_ptr)]
 
 
 class ListenerDims(C.Structure):

@@ -1,0 +1,324 @@
+// Self-critical CIDEr-D reward on the GPU (integer tokens in, fp64 scores out, no gradient).
+// Reference: misc/rewards.py:26-72 + cider/pyciderevalcap/ciderD/ciderD_scorer.py:13-215
+// (df mode "corpus", n = 4, sigma = 6), which runs as Python dicts of string n-grams on the host.
+//
+// MI355X design: a sentence has <= 16 tokens, hence <= 58 n-grams (16+15+14+13): exactly one
+// 64-lane wavefront per sentence, one n-gram per lane.
+//   1. ngram   : lane -> 64-bit key (order | 4 x 15-bit tokens); wave-wide bitonic sort with
+//                shuffles; run-length -> unique keys + integer term frequencies   (precook :13-30)
+//   2. df      : reference n-grams go into an open-addressing hash table (atomicCAS on the key,
+//                atomicAdd on the count), once per image (binary search in the image's earlier
+//                references removes duplicates)                         (compute_doc_freq :106-118)
+//   3. vec     : tf-idf weights and per-order norms in fp64                     (counts2vec :121-146)
+//   4. score   : one wave per hypothesis; each lane binary-searches its key in every reference
+//                of the image; clipped cosine, Gaussian length penalty          (sim :148-175, :184-201)
+// Integer quantities (n-gram counts, document frequencies, lengths) are exact.
+#include "cic_common.h"
+#include "engine_util.h"
+
+namespace {
+
+constexpr uint64_t EMPTY = 0xFFFFFFFFFFFFFFFFull;
+constexpr int NMAX = 4;
+constexpr int MAXTOK = 16;
+
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_xor(lo, m, 64);
+    hi = __shfl_xor(hi, m, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl(lo, src, 64);
+    hi = __shfl(hi, src, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint64_t u = (uint64_t)__double_as_longlong(v);
+        u = shfl_xor_u64(u, o);
+        v += __longlong_as_double((long long)u);
+    }
+    return v;
+}
+__device__ __forceinline__ uint64_t hash64(uint64_t k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return k;
+}
+
+// sentence s: [0,B) sampled rows, [B,2B) greedy rows, [2B,2B+R) reference rows
+struct Sents {
+    const int32_t *gen, *greedy, *refs;
+    const int32_t *L_gen, *L_greedy;
+    int B, T, R, Tr;
+};
+__device__ __forceinline__ const int32_t* sent_row(const Sents& s, int i, int& cols) {
+    if (i < s.B) { cols = min(*s.L_gen, s.T); return s.gen + (size_t)i * s.T; }
+    if (i < 2 * s.B) { cols = min(*s.L_greedy, s.T); return s.greedy + (size_t)(i - s.B) * s.T; }
+    cols = s.Tr;
+    return s.refs + (size_t)(i - 2 * s.B) * s.Tr;
+}
+
+// 1. one wave per sentence
+__global__ __launch_bounds__(256) void ngram_kernel(Sents s, int S, uint64_t* __restrict__ keys, int32_t* __restrict__ cnt,
+                                                    int32_t* __restrict__ nuniq, int32_t* __restrict__ blen) {
+    const int lane = threadIdx.x & 63;
+    const int sid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (sid >= S) return;
+    int cols;
+    const int32_t* row = sent_row(s, sid, cols);
+    // array_to_str (rewards.py:26-32): tokens up to AND INCLUDING the first 0
+    int len = cols;
+    for (int j = 0; j < cols; ++j)
+        if (row[j] == 0) { len = j + 1; break; }
+    // lane -> (order n, position p): unigrams 0..15, bigrams 16..30, trigrams 31..44, 4-grams 45..57
+    int n, p;
+    if (lane < 16) { n = 1; p = lane; }
+    else if (lane < 31) { n = 2; p = lane - 16; }
+    else if (lane < 45) { n = 3; p = lane - 31; }
+    else if (lane < 58) { n = 4; p = lane - 45; }
+    else { n = 5; p = 0; }
+    uint64_t key = EMPTY;
+    if (n <= NMAX && p + n <= len) {
+        key = (uint64_t)n << 60;
+        for (int j = 0; j < n; ++j) key |= (uint64_t)(row[p + j] & 0x7fff) << (45 - 15 * j);
+    }
+    // bitonic sort across the 64 lanes
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const uint64_t other = shfl_xor_u64(key, j);
+            const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+            const uint64_t mn = key < other ? key : other, mxv = key < other ? other : key;
+            key = (lower == up) ? mn : mxv;
+        }
+    const uint64_t prev = shfl_u64(key, lane == 0 ? 0 : lane - 1);
+    const bool valid = key != EMPTY;
+    const bool head = valid && (lane == 0 || key != prev);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long valids = __ballot(valid);
+    const int nvalid = __popcll(valids);
+    if (head) {
+        const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1)) << (lane + 1);
+        const int next = above ? __ffsll((long long)above) - 1 : nvalid;
+        const int rank = __popcll(heads & ((1ull << lane) - 1ull));
+        keys[(size_t)sid * 64 + rank] = key;
+        cnt[(size_t)sid * 64 + rank] = next - lane;          // term frequency (exact integer)
+    }
+    if (lane == 0) {
+        nuniq[sid] = __popcll(heads);
+        blen[sid] = len >= 2 ? len - 1 : 0;                   // "length" = number of bigrams (:143-144)
+    }
+}
+
+__device__ __forceinline__ int bsearch_key(const uint64_t* __restrict__ a, int n, uint64_t k) {
+    int lo = 0, hi = n - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const uint64_t v = a[mid];
+        if (v == k) return mid;
+        if (v < k) lo = mid + 1; else hi = mid - 1;
+    }
+    return -1;
+}
+
+// 2. document frequency: one wave per reference sentence
+__global__ __launch_bounds__(256) void df_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ nuniq,
+                                                 const int32_t* __restrict__ ref_img, const int32_t* __restrict__ ref_off,
+                                                 int B2, int R, int weight, uint64_t* __restrict__ ht_keys,
+                                                 int32_t* __restrict__ ht_df, uint32_t ht_mask) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int sid = B2 + r;
+    if (lane >= nuniq[sid]) return;
+    const uint64_t key = keys[(size_t)sid * 64 + lane];
+    const int img = ref_img[r];
+    for (int q = ref_off[img]; q < r; ++q)                     // already counted by an earlier reference
+        if (bsearch_key(keys + (size_t)(B2 + q) * 64, nuniq[B2 + q], key) >= 0) return;
+    uint32_t slot = (uint32_t)hash64(key) & ht_mask;
+    for (;;) {
+        const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(ht_keys + slot),
+                                                 (unsigned long long)EMPTY, (unsigned long long)key);
+        if (old == EMPTY || old == key) {
+            atomicAdd(ht_df + slot, weight);
+            return;
+        }
+        slot = (slot + 1) & ht_mask;
+    }
+}
+
+__device__ __forceinline__ int ht_lookup(const uint64_t* __restrict__ ht_keys, const int32_t* __restrict__ ht_df,
+                                         uint32_t ht_mask, uint64_t key) {
+    uint32_t slot = (uint32_t)hash64(key) & ht_mask;
+    for (;;) {
+        const uint64_t k = ht_keys[slot];
+        if (k == key) return ht_df[slot];
+        if (k == EMPTY) return 0;
+        slot = (slot + 1) & ht_mask;
+    }
+}
+
+// 3. tf-idf vectors + norms, one wave per sentence
+__global__ __launch_bounds__(256) void vec_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ cnt,
+                                                  const int32_t* __restrict__ nuniq, int S, double ref_len,
+                                                  const uint64_t* __restrict__ ht_keys, const int32_t* __restrict__ ht_df,
+                                                  uint32_t ht_mask, double* __restrict__ vec, double* __restrict__ norm,
+                                                  int32_t* __restrict__ df_out) {
+    const int lane = threadIdx.x & 63;
+    const int sid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (sid >= S) return;
+    const bool on = lane < nuniq[sid];
+    double v = 0.0;
+    int n = 0;
+    if (on) {
+        const uint64_t key = keys[(size_t)sid * 64 + lane];
+        const int df = ht_lookup(ht_keys, ht_df, ht_mask, key);
+        n = (int)(key >> 60);
+        const double d = log(df > 1 ? (double)df : 1.0);         // np.log(max(1.0, df))   (:132)
+        v = (double)cnt[(size_t)sid * 64 + lane] * (ref_len - d);   // tf * idf              (:136)
+        vec[(size_t)sid * 64 + lane] = v;
+        if (df_out) df_out[(size_t)sid * 64 + lane] = df;
+    }
+#pragma unroll
+    for (int k = 1; k <= NMAX; ++k) {
+        const double s = wave_sum_f64((on && n == k) ? v * v : 0.0);
+        if (lane == 0) norm[(size_t)sid * NMAX + (k - 1)] = sqrt(s);
+    }
+}
+
+// 4. one wave per hypothesis
+__global__ __launch_bounds__(256) void score_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ nuniq,
+                                                    const int32_t* __restrict__ blen, const double* __restrict__ vec,
+                                                    const double* __restrict__ norm, const int32_t* __restrict__ ref_off,
+                                                    int B, int spi, double sigma, double* __restrict__ scores) {
+    const int lane = threadIdx.x & 63;
+    const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (h >= 2 * B) return;
+    const int img = (h % B) / spi;                               // gts[i % batch_size // seq_per_img] (rewards.py:55)
+    const bool on = lane < nuniq[h];
+    const uint64_t key = on ? keys[(size_t)h * 64 + lane] : EMPTY;
+    const double vh = on ? vec[(size_t)h * 64 + lane] : 0.0;
+    const int n = on ? (int)(key >> 60) : 0;
+    double tot[NMAX] = {0.0, 0.0, 0.0, 0.0};
+    const int r0 = ref_off[img], r1 = ref_off[img + 1];
+    for (int r = r0; r < r1; ++r) {
+        const int rs = 2 * B + r;
+        double c = 0.0;
+        if (on) {
+            const int pos = bsearch_key(keys + (size_t)rs * 64, nuniq[rs], key);
+            if (pos >= 0) {
+                const double vr = vec[(size_t)rs * 64 + pos];
+                c = (vh < vr ? vh : vr) * vr;                    // min(hyp, ref) * ref  (:165)
+            }
+        }
+        const double delta = (double)(blen[h] - blen[rs]);
+        const double pen = exp(-(delta * delta) / (2.0 * sigma * sigma));
+#pragma unroll
+        for (int k = 1; k <= NMAX; ++k) {
+            double val = wave_sum_f64(n == k ? c : 0.0);
+            const double nh = norm[(size_t)h * NMAX + k - 1], nr = norm[(size_t)rs * NMAX + k - 1];
+            if (nh != 0.0 && nr != 0.0) val /= (nh * nr);        // (:167-168)
+            tot[k - 1] += val * pen;                             // (:172)
+        }
+    }
+    if (lane == 0) {
+        double avg = (tot[0] + tot[1] + tot[2] + tot[3]) / (double)NMAX;   // np.mean over n  (:194)
+        avg /= (double)(r1 - r0);
+        scores[h] = avg * 10.0;
+    }
+}
+
+__global__ void reward_kernel(const double* __restrict__ scores, int B, float* __restrict__ reward,
+                              double* __restrict__ stats) {
+    __shared__ double sh[2][4];
+    double a = 0.0, g = 0.0;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const double d = scores[b] - scores[B + b];               // rewards.py:66
+        reward[b] = (float)d;
+        a += scores[b];
+        g += scores[B + b];
+    }
+    a = wave_sum_f64(a);
+    g = wave_sum_f64(g);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = g; }
+    __syncthreads();
+    if (threadIdx.x == 0 && stats) {
+        stats[0] = (sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]) / B;   // mean CIDEr-D of the sampled captions
+        stats[1] = (sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]) / B;   // cider_greedy
+    }
+}
+
+__global__ void ref_img_kernel(const int32_t* __restrict__ ref_off, int n_images, int32_t* __restrict__ ref_img) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_images) return;
+    for (int r = ref_off[i]; r < ref_off[i + 1]; ++r) ref_img[r] = i;
+}
+
+struct CidWs {
+    uint64_t *keys, *ht_keys;
+    int32_t *cnt, *nuniq, *blen, *ht_df, *ref_img, *df;
+    double *vec, *norm;
+    uint32_t ht_size;
+    size_t bytes;
+};
+CidWs cid_carve(int B, int R, void* base) {
+    CidWs w;
+    Carver c(base);
+    const size_t S = (size_t)2 * B + R;
+    uint32_t ht = 1024;
+    while (ht < 4u * (uint32_t)R * 64u) ht <<= 1;
+    w.ht_size = ht;
+    w.keys = c.u64(S * 64);
+    w.ht_keys = c.u64(ht);
+    w.vec = c.f64(S * 64);
+    w.norm = c.f64(S * NMAX);
+    w.cnt = c.i32(S * 64);
+    w.df = c.i32(S * 64);
+    w.nuniq = c.i32(S);
+    w.blen = c.i32(S);
+    w.ht_df = c.i32(ht);
+    w.ref_img = c.i32(R);
+    w.bytes = c.used();
+    return w;
+}
+
+}  // namespace
+
+extern "C" size_t cic_ciderd_ws_bytes(int B, int R) { return cid_carve(B, R, nullptr).bytes; }
+
+extern "C" int cic_ciderd_reward(const cic_ciderd_args* a, void* ws, size_t ws_bytes, cic_stream_t s) {
+    CIC_REQUIRE(a && ws && a->gen && a->greedy && a->L_gen && a->L_greedy && a->refs && a->ref_off && a->scores);
+    CIC_REQUIRE(a->B > 0 && a->R > 0 && a->n_images > 0 && a->spi > 0 && a->B == a->n_images * a->spi);
+    CIC_REQUIRE(a->T > 0 && a->T <= MAXTOK && a->Tr > 0 && a->Tr <= MAXTOK);
+    CidWs w = cid_carve(a->B, a->R, ws);
+    CIC_REQUIRE(ws_bytes >= w.bytes);
+    hipStream_t st = cic_s(s);
+    const int B = a->B, R = a->R, S = 2 * B + R;
+    Sents sn = {a->gen, a->greedy, a->refs, a->L_gen, a->L_greedy, B, a->T, R, a->Tr};
+    CIC_HIP(hipMemsetAsync(w.ht_keys, 0xFF, sizeof(uint64_t) * w.ht_size, st));
+    CIC_HIP(hipMemsetAsync(w.ht_df, 0, sizeof(int32_t) * w.ht_size, st));
+    hipLaunchKernelGGL(ref_img_kernel, dim3(cic_cdiv(a->n_images, 256)), dim3(256), 0, st, a->ref_off, a->n_images,
+                       w.ref_img);
+    hipLaunchKernelGGL(ngram_kernel, dim3(cic_cdiv(S, 4)), dim3(256), 0, st, sn, S, w.keys, w.cnt, w.nuniq, w.blen);
+    // every image's reference set is seen by 2*spi hypothesis entries (sampled + greedy halves, rewards.py:53-56)
+    hipLaunchKernelGGL(df_kernel, dim3(cic_cdiv(R, 4)), dim3(256), 0, st, w.keys, w.nuniq, w.ref_img, a->ref_off, 2 * B,
+                       R, 2 * a->spi, w.ht_keys, w.ht_df, w.ht_size - 1);
+    const double ref_len = log((double)(2 * B));                  // np.log(float(len(self.crefs)))  (:178-179)
+    hipLaunchKernelGGL(vec_kernel, dim3(cic_cdiv(S, 4)), dim3(256), 0, st, w.keys, w.cnt, w.nuniq, S, ref_len, w.ht_keys,
+                       w.ht_df, w.ht_size - 1, w.vec, w.norm, w.df);
+    hipLaunchKernelGGL(score_kernel, dim3(cic_cdiv(2 * B, 4)), dim3(256), 0, st, w.keys, w.nuniq, w.blen, w.vec, w.norm,
+                       a->ref_off, B, a->spi, 6.0, a->scores);
+    if (a->reward) hipLaunchKernelGGL(reward_kernel, dim3(1), dim3(256), 0, st, a->scores, B, a->reward, a->stats);
+    CIC_LAUNCH_CHECK();
+    if (a->dbg_keys) {   // exact-integer tables for the parity tests
+        CIC_HIP(hipMemcpyAsync(a->dbg_keys, w.keys, sizeof(uint64_t) * S * 64, hipMemcpyDeviceToDevice, st));
+        CIC_HIP(hipMemcpyAsync(a->dbg_cnt, w.cnt, sizeof(int32_t) * S * 64, hipMemcpyDeviceToDevice, st));
+        CIC_HIP(hipMemcpyAsync(a->dbg_df, w.df, sizeof(int32_t) * S * 64, hipMemcpyDeviceToDevice, st));
+        CIC_HIP(hipMemcpyAsync(a->dbg_nuniq, w.nuniq, sizeof(int32_t) * S, hipMemcpyDeviceToDevice, st));
+    }
+    return 0;
+}

@@ -1,0 +1,140 @@
+// Sequence-level loss assembly (self-critical / REINFORCE / masked NLL) and the fused
+// clamp + Adam update over a flat parameter buffer.
+#include "cic_common.h"
+
+namespace {
+
+// loss = sum_{b, t<L} slp[b,t] * coef[b] * m[b,t] / sum m,   m[b,0] = 1, m[b,t] = seq[b,t-1] > 0
+//   (gen_masks[:, 1:] of models/AlternatingJointModel.py:353-355; :292-297,:321-325,:421-428)
+// dslp (+)= weight * coef[b] * m[b,t] / sum m
+__global__ __launch_bounds__(256) void seq_loss_kernel(const float* __restrict__ slp, const int32_t* __restrict__ seq,
+                                                       const int32_t* __restrict__ Lp, const float* __restrict__ coef,
+                                                       float coef_sign, float weight, int B, int T,
+                                                       float* __restrict__ loss_out, float* __restrict__ dslp,
+                                                       int accumulate) {
+    __shared__ float sh[2][4];
+    const int L = min(*Lp, T);
+    float num = 0.f, den = 0.f;
+    for (int i = threadIdx.x; i < B * T; i += 256) {
+        const int b = i / T, t = i % T;
+        const bool m = t < L && (t == 0 || seq[(size_t)b * T + t - 1] > 0);
+        if (m) {
+            num += slp[i] * (coef_sign * coef[b]);
+            den += 1.f;
+        }
+    }
+    num = wave_sum(num);
+    den = wave_sum(den);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = num; sh[1][threadIdx.x >> 6] = den; }
+    __syncthreads();
+    num = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    den = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    if (threadIdx.x == 0 && loss_out) *loss_out = num / den;
+    if (dslp) {
+        const float k = weight / den;
+        for (int i = threadIdx.x; i < B * T; i += 256) {
+            const int b = i / T, t = i % T;
+            const bool m = t < L && (t == 0 || seq[(size_t)b * T + t - 1] > 0);
+            const float g = m ? k * coef_sign * coef[b] : 0.f;
+            dslp[i] = accumulate ? dslp[i] + g : g;
+        }
+    }
+}
+
+// LanguageModelCriterion (misc/utils.py:49-58): loss = -sum slp*mask / sum mask; dslp = -weight*mask/sum mask
+__global__ __launch_bounds__(256) void masked_nll_kernel(const float* __restrict__ slp, const float* __restrict__ mask,
+                                                         int mask_ld, float weight, int B, int T,
+                                                         float* __restrict__ loss_out, float* __restrict__ dslp) {
+    __shared__ float sh[2][4];
+    float num = 0.f, den = 0.f;
+    for (int i = threadIdx.x; i < B * T; i += 256) {
+        const int b = i / T, t = i % T;
+        const float m = mask[(size_t)b * mask_ld + t];
+        num -= slp[i] * m;
+        den += m;
+    }
+    num = wave_sum(num);
+    den = wave_sum(den);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = num; sh[1][threadIdx.x >> 6] = den; }
+    __syncthreads();
+    num = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    den = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    if (threadIdx.x == 0 && loss_out) *loss_out = num / den;
+    if (dslp)
+        for (int i = threadIdx.x; i < B * T; i += 256) {
+            const int b = i / T, t = i % T;
+            dslp[i] = -weight * mask[(size_t)b * mask_ld + t] / den;
+        }
+}
+
+// clip_gradient (elementwise clamp, misc/utils.py:65-69) + torch.optim.Adam.step (optimizer.py:25-27)
+__global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                         float clip, float wd, float b1, float b2, float eps,
+                                                         float step_size, float bc2_sqrt, float gscale) {
+    const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = i4 * 4;
+    if (i >= n) return;
+    if (i + 3 < n) {
+        f32x4 pp = *reinterpret_cast<f32x4*>(p + i);
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(g + i);
+        f32x4 mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = fminf(fmaxf(gg[e] * gscale, -clip), clip);
+            if (wd != 0.f) x += wd * pp[e];
+            mm[e] = mm[e] * b1 + (1.0f - b1) * x;
+            vv[e] = vv[e] * b2 + (1.0f - b2) * x * x;
+            const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+            pp[e] = pp[e] - step_size * (mm[e] / denom);
+        }
+        *reinterpret_cast<f32x4*>(p + i) = pp;
+        *reinterpret_cast<f32x4*>(m + i) = mm;
+        *reinterpret_cast<f32x4*>(v + i) = vv;
+    } else {
+        for (int64_t j = i; j < n; ++j) {
+            float x = fminf(fmaxf(g[j] * gscale, -clip), clip);
+            if (wd != 0.f) x += wd * p[j];
+            m[j] = m[j] * b1 + (1.0f - b1) * x;
+            v[j] = v[j] * b2 + (1.0f - b2) * x * x;
+            const float denom = sqrtf(v[j]) / bc2_sqrt + eps;
+            p[j] = p[j] - step_size * (m[j] / denom);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int cic_seq_loss(const float* slp, const int32_t* seq, const int32_t* L, const float* coef, float coef_sign,
+                            float weight, int B, int T, float* loss_out, float* dslp, int accumulate, cic_stream_t s) {
+    CIC_REQUIRE(slp && seq && L && coef && B > 0 && T > 0);
+    hipLaunchKernelGGL(seq_loss_kernel, dim3(1), dim3(256), 0, cic_s(s), slp, seq, L, coef, coef_sign, weight, B, T,
+                       loss_out, dslp, accumulate);
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cic_masked_nll(const float* slp, const float* mask, int mask_ld, float weight, int B, int T,
+                              float* loss_out, float* dslp, cic_stream_t s) {
+    CIC_REQUIRE(slp && mask && B > 0 && T > 0 && mask_ld >= T);
+    hipLaunchKernelGGL(masked_nll_kernel, dim3(1), dim3(256), 0, cic_s(s), slp, mask, mask_ld, weight, B, T, loss_out,
+                       dslp);
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cic_clamp_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
+                              double beta2, double eps, double weight_decay, double grad_clip, int step,
+                              double grad_scale, cic_stream_t s) {
+    CIC_REQUIRE(p && g && m && v && n > 0 && step >= 1 && grad_clip > 0.0);
+    CIC_REQUIRE(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                  reinterpret_cast<uintptr_t>(v)) & 15) == 0);
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+    const float step_size = (float)(lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    hipLaunchKernelGGL(clamp_adam_kernel, dim3(cic_cdiv((n + 3) / 4, 256)), dim3(256), 0, cic_s(s), p, g, m, v, n,
+                       (float)grad_clip, (float)weight_decay, (float)beta1, (float)beta2, (float)eps, step_size, bc2_sqrt,
+                       (float)grad_scale);
+    CIC_LAUNCH_CHECK();
+    return 0;
+}

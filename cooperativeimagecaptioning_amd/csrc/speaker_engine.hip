@@ -12,6 +12,10 @@ __global__ void fill_i32_kernel(int32_t* p, int n, int32_t v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
+__global__ void i64_to_i32_kernel(const int64_t* a, int32_t* o, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = (int32_t)a[i];
+}
 __global__ void add_vec_kernel(const float* a, const float* b, float* o, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) o[i] = a[i] + b[i];
@@ -99,7 +103,12 @@ extern "C" int cic_speaker_decode_fwd(const cic_speaker_dims* dp, const cic_spea
     CIC_HIP(hipMemsetAsync(w.c_all, 0, sizeof(float) * B * H, st));
     CIC_HIP(hipMemsetAsync(w.any_unf, 0, sizeof(int32_t) * (T + 1), st));
     RUN(cic_fill_i32(w.unfinished, B, 1, st));
-    RUN(cic_fill_i32(w.it_all, B, d.V + 1, st));                              // <bos> = vocab_size + 1 (:324-326)
+    if (io->first_token) {                                                    // AttModel.forward: seq[:, 0]  (:131)
+        hipLaunchKernelGGL(i64_to_i32_kernel, dim3(cic_cdiv(B, 256)), dim3(256), 0, st, io->first_token, w.it_all, B);
+        CIC_LAUNCH_CHECK();
+    } else {
+        RUN(cic_fill_i32(w.it_all, B, d.V + 1, st));                          // <bos> = vocab_size + 1 (:324-326)
+    }
 
     for (int t = 0; t < T; ++t) {
         float* x = w.x_all + (size_t)t * B * E;

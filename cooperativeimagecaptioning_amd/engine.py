@@ -7,7 +7,7 @@ import torch
 
 from . import _lib
 from ._lib import (lib, check, stream, SpeakerDims, SpeakerParams, DecodeIO, DecodeBwdIO, SPEAKER_PARAM_FIELDS,
-                   ListenerDims, ListenerParams, ListenerIO, ListenerBwdIO, LISTENER_PARAM_FIELDS)
+                   ListenerDims, ListenerParams, ListenerIO, ListenerBwdIO, LISTENER_PARAM_FIELDS, CiderdArgs)
 
 P = C.c_void_p
 
@@ -33,6 +33,17 @@ lib.cic_listener_fwd.restype = C.c_int
 lib.cic_listener_bwd.argtypes = [C.POINTER(ListenerDims), C.POINTER(ListenerParams), C.POINTER(ListenerIO),
                                  C.POINTER(ListenerBwdIO), P, C.c_size_t, P]
 lib.cic_listener_bwd.restype = C.c_int
+
+lib.cic_ciderd_ws_bytes.argtypes = [C.c_int, C.c_int]
+lib.cic_ciderd_ws_bytes.restype = C.c_size_t
+lib.cic_ciderd_reward.argtypes = [C.POINTER(CiderdArgs), P, C.c_size_t, P]
+lib.cic_ciderd_reward.restype = C.c_int
+lib.cic_seq_loss.argtypes = [P, P, P, P, C.c_float, C.c_float, C.c_int, C.c_int, P, P, C.c_int, P]
+lib.cic_seq_loss.restype = C.c_int
+lib.cic_masked_nll.argtypes = [P, P, C.c_int, C.c_float, C.c_int, C.c_int, P, P, P]
+lib.cic_masked_nll.restype = C.c_int
+lib.cic_clamp_adam.argtypes = [P, P, P, P, C.c_int64] + [C.c_double] * 6 + [C.c_int, C.c_double, P]
+lib.cic_clamp_adam.restype = C.c_int
 
 ONLY_ONE = {'off': 0, 'image': 1, 'caption': 2}
 
@@ -69,7 +80,8 @@ def speaker_att_embed_fwd(dims, params, att_raw, att_pre=None):
 
 
 def speaker_decode_fwd(dims, params, att_pre, mode, temp=1.0, att_masks=None, att_keep=None, x_keep=None,
-                       out_keep=None, U=None, pick=None, decoding_constraint=0, want_stv=False, ws=None):
+                       out_keep=None, U=None, pick=None, decoding_constraint=0, want_stv=False, ws=None,
+                       first_token=None):
     """-> dict(seq i32[B,T], slp f32[B,T], stv f32[B,T]|None, L i32[1], ws)."""
     dev = att_pre.device
     B, T = dims.B, dims.T
@@ -83,12 +95,12 @@ def speaker_decode_fwd(dims, params, att_pre, mode, temp=1.0, att_masks=None, at
     io.mode, io.temp, io.decoding_constraint = mode, float(temp), int(decoding_constraint)
     io.att_pre, io.att_masks = _p(att_pre), _p(att_masks)
     io.att_keep, io.x_keep, io.out_keep = _p(att_keep), _p(x_keep), _p(out_keep)
-    io.U, io.pick = _p(U), _p(pick)
+    io.U, io.pick, io.first_token = _p(U), _p(pick), _p(first_token)
     io.seq, io.slp, io.stv, io.L = _p(out['seq']), _p(out['slp']), _p(out['stv']), _p(out['L'])
     check(lib.cic_speaker_decode_fwd(C.byref(dims), C.byref(params), C.byref(io), ws.data_ptr(), ws.numel(),
                                      stream()), 'cic_speaker_decode_fwd')
     out['io'] = io
-    out['_keep'] = (att_pre, att_masks, att_keep, x_keep, out_keep, U, pick)   # alive until the backward call
+    out['_keep'] = (att_pre, att_masks, att_keep, x_keep, out_keep, U, pick, first_token)   # alive until the backward call
     return out
 
 
@@ -156,3 +168,67 @@ def listener_bwd(dims, params, fwd, g_rows=None, g_scalar=None, grads=None, d_on
     ws = fwd['ws']
     check(lib.cic_listener_bwd(C.byref(dims), C.byref(params), C.byref(fwd['io']), C.byref(bio), ws.data_ptr(),
                                ws.numel(), stream()), 'cic_listener_bwd')
+
+
+def pack_refs(gts, device):
+    """data['gts'] (list of int arrays [ncap, Tr]) -> (refs i32[R,Tr], ref_off i32[n_images+1]) on device."""
+    import numpy as np
+    off = np.zeros(len(gts) + 1, np.int32)
+    off[1:] = np.cumsum([len(g) for g in gts])
+    refs = np.concatenate([np.asarray(g) for g in gts], 0).astype(np.int32)
+    return (torch.from_numpy(np.ascontiguousarray(refs)).to(device),
+            torch.from_numpy(off).to(device))
+
+
+def ciderd_reward(gen, L_gen, greedy, L_greedy, refs, ref_off, spi=None, debug=False, ws=None):
+    """get_self_critical_reward on the GPU.  gen/greedy: i32[B,T]; refs/ref_off from pack_refs.
+    -> dict(scores f64[2B], reward f32[B], stats f64[2] = (mean sampled score, cider_greedy))."""
+    dev = gen.device
+    B, T = gen.shape
+    n_images = ref_off.numel() - 1
+    spi = spi or B // n_images
+    R, Tr = refs.shape
+    nbytes = lib.cic_ciderd_ws_bytes(B, R)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    out = dict(scores=torch.empty(2 * B, dtype=torch.float64, device=dev), reward=torch.empty(B, device=dev),
+               stats=torch.empty(2, dtype=torch.float64, device=dev), ws=ws)
+    a = CiderdArgs()
+    a.B, a.T, a.n_images, a.spi, a.R, a.Tr = B, T, n_images, spi, R, Tr
+    a.gen, a.L_gen, a.greedy, a.L_greedy = _p(gen), _p(L_gen), _p(greedy), _p(L_greedy)
+    a.refs, a.ref_off = _p(refs), _p(ref_off)
+    a.scores, a.reward, a.stats = _p(out['scores']), _p(out['reward']), _p(out['stats'])
+    if debug:
+        S = 2 * B + R
+        out['dbg_keys'] = torch.zeros(S, 64, dtype=torch.int64, device=dev)
+        out['dbg_cnt'] = torch.zeros(S, 64, dtype=torch.int32, device=dev)
+        out['dbg_df'] = torch.zeros(S, 64, dtype=torch.int32, device=dev)
+        out['dbg_nuniq'] = torch.zeros(S, dtype=torch.int32, device=dev)
+        a.dbg_keys, a.dbg_cnt, a.dbg_df, a.dbg_nuniq = (_p(out['dbg_keys']), _p(out['dbg_cnt']), _p(out['dbg_df']),
+                                                      _p(out['dbg_nuniq']))
+    check(lib.cic_ciderd_reward(C.byref(a), ws.data_ptr(), ws.numel(), stream()), 'cic_ciderd_reward')
+    return out
+
+
+def seq_loss(slp, seq, L, coef, coef_sign, weight, dslp=None, accumulate=False, loss_out=None):
+    B, T = slp.shape
+    if loss_out is None:
+        loss_out = torch.empty(1, device=slp.device)
+    check(lib.cic_seq_loss(_p(slp), _p(seq), _p(L), _p(coef), float(coef_sign), float(weight), B, T, _p(loss_out),
+                           _p(dslp), int(accumulate), stream()), 'cic_seq_loss')
+    return loss_out
+
+
+def masked_nll(slp, mask, weight, dslp=None, loss_out=None):
+    B, T = slp.shape
+    assert mask.stride(1) == 1
+    if loss_out is None:
+        loss_out = torch.empty(1, device=slp.device)
+    check(lib.cic_masked_nll(_p(slp), mask.data_ptr(), mask.stride(0), float(weight), B, T, _p(loss_out), _p(dslp),
+                             stream()), 'cic_masked_nll')
+    return loss_out
+
+
+def clamp_adam(p, g, m, v, lr, step, grad_clip=0.1, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    check(lib.cic_clamp_adam(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay,
+                             grad_clip, int(step), grad_scale, stream()), 'cic_clamp_adam')

@@ -156,7 +156,11 @@ typedef struct {
     const uint8_t* x_keep;    /* [T+1,B,E] row t: token-embedding dropout of core step t */
     const uint8_t* out_keep;  /* [T+1,B,H] row t: core-output dropout of step t */
     const float* U;           /* [T+1,B,V+1] row t (t>=1): Gumbel uniforms used to pick the input of step t */
-    const int64_t* pick;      /* [T+1,B] row t: externally chosen tokens (multinomial modes) or NULL */
+    const int64_t* pick;      /* [T+1,B] row t: externally chosen tokens (multinomial modes) or NULL.
+                                 Teacher forcing (AttModel.forward, :103-148) = CIC_SAMPLE_MULTINOMIAL with
+                                 pick[t] = labels[:, t]: slp then holds log p(target) of every step. */
+    const int64_t* first_token; /* [B] input token of step 0; NULL = <bos> = vocab_size+1 (:324-326).
+                                 AttModel.forward starts from labels[:, 0] = 0 instead (:131). */
     int32_t* seq;             /* out [B,T]  it * unfinished          (AttModel.py:409-415) */
     float* slp;               /* out [B,T]  sampled log-probs        (AttModel.py:413,423) */
     float* stv;               /* out [B,T]  straight-through values, or NULL */
@@ -234,6 +238,44 @@ int cic_listener_fwd(const cic_listener_dims* d, const cic_listener_params* p, c
 /* autograd of the above; ws must be the workspace of the matching forward call. */
 int cic_listener_bwd(const cic_listener_dims* d, const cic_listener_params* p, const cic_listener_io* io,
                      const cic_listener_bwd_io* bio, void* ws, size_t ws_bytes, cic_stream_t s);
+
+/* ---- loss assembly and optimiser ------------------------------------------------------- */
+/* loss = sum_{b,t<L} slp[b,t] * (coef_sign*coef[b]) * m[b,t] / sum m with m = gen_masks[:, 1:]
+ * (m[b,0] = 1, m[b,t] = seq[b,t-1] > 0): the self-critical CIDEr term (coef = reward, sign -1;
+ * AlternatingJointModel.py:421-428) and the REINFORCE term (coef = retrieval_loss - baseline, sign +1;
+ * :292-297,:321-325).  dslp (+)= weight * d loss / d slp.  loss_out / dslp may be NULL. */
+int cic_seq_loss(const float* slp, const int32_t* seq, const int32_t* L, const float* coef, float coef_sign,
+                 float weight, int B, int T, float* loss_out, float* dslp, int accumulate, cic_stream_t s);
+/* LanguageModelCriterion, misc/utils.py:49-58: loss = -sum slp*mask / sum mask (slp = log p(target));
+ * dslp = weight * d loss / d slp. */
+int cic_masked_nll(const float* slp, const float* mask, int mask_ld, float weight, int B, int T,
+                   float* loss_out, float* dslp, cic_stream_t s);
+/* clip_gradient (elementwise clamp to +-grad_clip, misc/utils.py:65-69) followed by one
+ * torch.optim.Adam step (optimizer.py:25-27,233-242) over a flat buffer of n floats.  The gradient is
+ * first multiplied by grad_scale (1/world_size after a sum all-reduce).  step >= 1 is Adam's t. */
+int cic_clamp_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
+                   double beta2, double eps, double weight_decay, double grad_clip, int step,
+                   double grad_scale, cic_stream_t s);
+
+/* ---- self-critical CIDEr-D reward: misc/rewards.py:26-72, ciderD_scorer.py:13-215 ---------- */
+typedef struct {
+    int B, T;                 /* hypotheses per decode and their columns (T <= 16) */
+    int n_images, spi;        /* len(data['gts']) and seq_per_img; B == n_images * spi */
+    int R, Tr;                /* reference sentences in total and their columns (Tr <= 16) */
+    const int32_t* gen;       /* [B,T] sampled captions (it * unfinished) */
+    const int32_t* L_gen;     /* [1] columns the reference would have returned for them */
+    const int32_t* greedy;    /* [B,T] greedy captions */
+    const int32_t* L_greedy;  /* [1] */
+    const int32_t* refs;      /* [R,Tr] ground-truth captions, image after image */
+    const int32_t* ref_off;   /* [n_images+1] first reference row of each image */
+    double* scores;           /* out [2B] CIDEr-D of sampled then greedy captions (x10, as the reference) */
+    float* reward;            /* out [B] scores[:B] - scores[B:] (rewards.py:66) or NULL */
+    double* stats;            /* out [2] mean sampled score, mean greedy score, or NULL */
+    /* optional dumps of the exact integer tables (tests): sentence-major, 64 slots each */
+    uint64_t* dbg_keys; int32_t* dbg_cnt; int32_t* dbg_df; int32_t* dbg_nuniq;
+} cic_ciderd_args;
+size_t cic_ciderd_ws_bytes(int B, int R);
+int cic_ciderd_reward(const cic_ciderd_args* a, void* ws, size_t ws_bytes, cic_stream_t s);
 
 #ifdef __cplusplus
 }
