@@ -146,7 +146,11 @@ extern "C" int cic_speaker_decode_fwd(const cic_speaker_dims* dp, const cic_spea
         a.any_unfinished = w.any_unf;
         RUN(cic_logsoftmax_sample(&a, s));
     }
-    RUN(cic_finalize_len(w.any_unf, T, io->L, s));
+    if (io->first_token) {
+        RUN(cic_fill_i32(io->L, 1, T, st));      // teacher forcing: every step carries a target
+    } else {
+        RUN(cic_finalize_len(w.any_unf, T, io->L, s));
+    }
 #undef RUN
     return 0;
 }

@@ -1,0 +1,71 @@
+"""Flat parameter / gradient / Adam-state buffers for one agent (speaker or listener).
+
+MI355X-first layout: all parameters of an agent live in ONE contiguous f32 buffer (the
+nn.Parameters are views into it, so state-dict names and shapes stay those of the
+reference), and so do their gradients.  Consequences: the clamp+Adam update is one kernel
+launch per agent and the data-parallel gradient exchange is one RCCL all-reduce per agent
+ instead of one per tensor.
+"""
+import torch
+
+
+class FlatAgent:
+    ALIGN = 64  # floats: every parameter starts on a 256-byte boundary (float4 / MFMA tile loads)
+
+    def __init__(self, module):
+        self.module = module
+        self.params = [p for p in module.parameters()]
+        self.names = [n for n, _ in module.named_parameters()]
+        self.offsets = []
+        off = 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.numel = off
+        self.flat = None
+        self.grad = None
+        self.exp_avg = None
+        self.exp_avg_sq = None
+        self.step = 0
+
+    def attached(self):
+        if self.flat is None:
+            return False
+        return all(p.data_ptr() == self.flat.data_ptr() + 4 * o for p, o in zip(self.params, self.offsets))
+
+    def attach(self):
+        """(Re-)create the flat buffers on the parameters' current device and re-point the views."""
+        dev = self.params[0].device
+        flat = torch.zeros(self.numel, device=dev)
+        grad = torch.zeros(self.numel, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            flat[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = flat[o:o + p.numel()].view(p.shape)
+            g_old = p.grad
+            p.grad = grad[o:o + p.numel()].view(p.shape)
+            if g_old is not None:
+                p.grad.copy_(g_old)
+        self.flat, self.grad = flat, grad
+        if self.exp_avg is None or self.exp_avg.device != dev:
+            self.exp_avg = torch.zeros(self.numel, device=dev)
+            self.exp_avg_sq = torch.zeros(self.numel, device=dev)
+
+    def ensure(self):
+        if not self.attached():
+            self.attach()
+        else:
+            # a caller may have replaced p.grad (zero_grad(set_to_none=True)); re-point it
+            for p, o in zip(self.params, self.offsets):
+                if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                    p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+    def tensors(self, prefix=''):
+        return {prefix + n: p.data for n, p in zip(self.names, self.params)}
+
+    def grad_tensors(self, prefix=''):
+        return {prefix + n: self.grad[o:o + p.numel()].view(p.shape)
+                for n, p, o in zip(self.names, self.params, self.offsets)}
+
+    def zero_grad(self):
+        self.ensure()
+        self.grad.zero_()

@@ -1,0 +1,265 @@
+"""AlternatingJointModel with the reference's constructor signature, call signature, loss-flag
+logic and state-dict layout (models/AlternatingJointModel.py:71-686), with every tensor
+computation delegated to the HIP engines.
+
+One call = one joint training step's forward: sampled decode -> listener on the generated
+(straight-through) captions -> greedy decode -> CIDEr-D reward -> loss; ``loss.backward()``
+launches the backward engines.  Nothing synchronises with the host inside the step (the
+reference syncs once per decode step, AttModel.py:407).
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from .. import engine
+from ..autograd_glue import EngineLoss
+from ..misc import utils
+from ..misc import rewards
+
+
+class AlternatingJointModel(nn.Module):
+    def __init__(self, opt, iteration=None):
+        super().__init__()
+        from . import setup, load
+        self.opt = opt
+        self.use_word_weights = getattr(opt, 'use_word_weights', 0)
+        self.caption_generator = setup(opt, opt.caption_model, 'caption_model')
+        if opt.vse_model != 'None':
+            self.vse = setup(opt, opt.vse_model, 'vse_model')
+            self.share_embed = opt.share_embed
+            if self.share_embed:
+                raise NotImplementedError('share_embed=1 is not supported on the MI355X path (scripts use 0)')
+        else:
+            self.vse = None
+            self.share_embed = 0
+        if opt.retrieval_reward == 'reinforce':                       # :95-98
+            if opt.vse_loss_weight == 0 and isinstance(self.vse, nn.Module):
+                for p in self.vse.parameters():
+                    p.requires_grad = False
+        self.batch_size = opt.batch_size
+        self.vse_loss_weight = opt.vse_loss_weight
+        self.caption_loss_weight = opt.caption_loss_weight
+        self.df = getattr(opt, 'df', 'coco-val')
+        self.retrieval_reward = opt.retrieval_reward
+        if opt.alternating_turn is not None:                          # :110-114
+            if len(opt.alternating_turn) == 1 and opt.retrieval_reward == 'reinforce':
+                if opt.alternating_turn[0] == 'listener':
+                    opt.retrieval_reward_weight = 0
+        self.retrieval_reward_weight = opt.retrieval_reward_weight
+        self.reinforce_baseline_type = getattr(opt, 'reinforce_baseline_type', 'greedy')
+        self.sheriff_baseline_type = getattr(opt, 'sheriff_baseline_type', 'greedy')
+        self.only_one_retrieval = getattr(opt, 'only_one_retrieval', 'off')
+        self.cider_optimization = getattr(opt, 'cider_optimization', 0)
+        self.use_gen_cider_scores = getattr(opt, 'use_gen_cider_scores', 0)
+        self._loss = {}
+        # Load model (:131-177)
+        if opt.is_alternating:
+            if getattr(opt, 'continue_from_existing_models', False):
+                path = None
+                if opt.start_from and os.path.isfile(os.path.join(opt.start_from, 'alternatingModel.pth')):
+                    name = 'alternatingModel-' + iteration + '.pth' if iteration else 'alternatingModel.pth'
+                    path = os.path.join(opt.start_from, name)
+                    msg = f'Loaded alternating model from {path}'
+                else:
+                    path = opt.speaker_stage_2_model_path
+                    msg = f'Loaded pre-trained "speaker" model, after stage 2 from {path}'
+                utils.load_state_dict(self, torch.load(path, map_location='cpu', weights_only=True))
+                print(msg)
+        else:
+            load(self, opt, iteration)
+            if getattr(opt, 'initialize_retrieval', None) is not None:
+                print("Make sure the vse opt are the same !!!!!")
+                sd = torch.load(opt.initialize_retrieval, map_location='cpu', weights_only=True)
+                utils.load_state_dict(self, {k: v for k, v in sd.items() if 'vse.' in k})
+
+    # ---- flags (:180-194) ---------------------------------------------------------------------
+    def getLossFlags(self):
+        return [self.vse_loss_weight, self.caption_loss_weight, self.cider_optimization, self.retrieval_reward_weight]
+
+    def setLossFlages(self, VSEWeight, MLEWeight, ciderFlag, DISCWeight):
+        self.vse_loss_weight = VSEWeight
+        self.caption_loss_weight = MLEWeight
+        self.cider_optimization = ciderFlag
+        self.retrieval_reward_weight = DISCWeight
+
+    def changeModelUpdateStatus(self, gradDic, printWeights=False):
+        """:571-685 — only the requires_grad effect; the deep-copy/compare diagnostics of the reference
+        (26 M parameters copied per turn) are not reproduced."""
+        if 'vseModel' in gradDic and self.vse is not None:
+            for p in self.vse.parameters():
+                p.requires_grad = gradDic['vseModel']
+        if 'captionModel' in gradDic:
+            for p in self.caption_generator.parameters():
+                p.requires_grad = gradDic['captionModel']
+
+    # ---- the step -------------------------------------------------------------------------------
+    def _refs(self, data, device):
+        key = id(data.get('gts')) if isinstance(data, dict) else None
+        return engine.pack_refs(data['gts'], device)
+
+    def _plain_forward(self, fc_feats, seq, masks, data, att_feats, att_masks, gen_override=None):
+        """The non-alternating branch, :443-504.  Returns a 0-dim loss whose backward() runs the
+        backward engines."""
+        cg, vse = self.caption_generator, self.vse
+        dev = fc_feats.device
+        rr = self.retrieval_reward
+        oor = self.only_one_retrieval
+        spk_grad = any(p.requires_grad for p in cg.parameters()) and torch.is_grad_enabled()
+        lst_grad = vse is not None and any(p.requires_grad for p in vse.parameters()) and torch.is_grad_enabled()
+        use_att = att_feats is not None
+        if not use_att:
+            raise NotImplementedError("caption_model 'fc' (no attention features) is plumbing-only in the reference "
+                                      "and not on the MI355X path")
+        B = fc_feats.shape[0]
+        T = cg.seq_length
+        terms = []          # (weight, device scalar)
+        bwd_steps = []      # closures run in order by backward(go)
+        att_pre = cg.att_embed_pre(att_feats)
+        cw, vw, dw, ciw = self.caption_loss_weight, self.vse_loss_weight, self.retrieval_reward_weight, self.cider_optimization
+
+        # MLE (ce_loss :196-207)
+        if cw > 0:
+            if cg.training and cg.ss_prob > 0.0:
+                raise NotImplementedError('scheduled sampling (ss_prob > 0) is not on the MI355X path yet')
+            Tm = seq.shape[1] - 1
+            mle = cg.decode(att_feats, att_masks, 'multinomial', 1.0, att_pre=att_pre, grad=True, T=Tm,
+                            pick=seq.t().contiguous().long(), first_token=seq[:, 0].contiguous().long(), tag='mle',
+                            decoding_constraint=0, want_stv=False)
+            d_mle = torch.empty(B, Tm, device=dev)
+            l_mle = engine.masked_nll(mle.slp, masks.float()[:, 1:], cw, dslp=d_mle)
+            cg._loss['xe'] = l_mle.detach()[0]
+            self._loss['loss_cap'] = l_mle.detach()[0]
+            terms.append((cw, l_mle))
+            if spk_grad:
+                bwd_steps.append(lambda go: cg.decode_backward(mle, dslp=d_mle * go))
+        # VSE on ground-truth captions (vse_loss :209-224)
+        if vw > 0:
+            gt = vse.run(fc_feats, labels=seq, masks=masks, only_one_retrieval=oor, slot=1)
+            self._loss['loss_vse'] = gt.loss_sum.detach()[0]
+            vse._loss['contrastive'] = gt.loss_sum.detach()[0]
+            terms.append((vw, gt.loss_sum))
+            if lst_grad:
+                bwd_steps.append(lambda go: vse.run_backward(gt, g_scalar=(go * vw).reshape(1).contiguous()))
+
+        sample = None
+        greedy = None
+        dslp = None
+        if dw > 0:                                                     # DISC loss :455-488
+            if rr == 'reinforce':
+                sample = cg.decode(att_feats, att_masks, 'multinomial', 1.0, att_pre=att_pre, grad=spk_grad)  # :226-247
+                gen = vse.run(fc_feats, decode=sample, only_one_retrieval=oor, slot=2)
+                btype = self.reinforce_baseline_type
+                if btype == 'greedy':                                  # :250-298
+                    greedy = cg.decode(att_feats, att_masks, 'greedy', att_pre=att_pre, tag='greedy')
+                    base = vse.run(fc_feats, decode=greedy, only_one_retrieval=oor, slot=3).loss_rows
+                elif btype == 'gt':                                    # :300-310
+                    base = vse.run(fc_feats, labels=seq, masks=masks, only_one_retrieval=oor, slot=3).loss_rows
+                else:                                                  # :312-319
+                    base = torch.zeros(B, device=dev)
+                coef = (gen.loss_rows - base).contiguous()
+                dslp = torch.zeros(B, T, device=dev)
+                sc = engine.seq_loss(sample.slp, sample.seq, sample.L, coef, 1.0, dw, dslp=dslp)   # :321-325
+                terms.append((dw, sc))
+                self._loss['retrieval_sc_loss'] = sc.detach()[0]
+                self._loss['retrieval_loss'] = gen.loss_rows.sum().detach()
+                self._loss['retrieval_loss_greedy'] = base.sum().detach()
+            elif rr in ('gumbel', 'multinomial'):                      # st_and_ps_methods :343-376
+                mode = 'gumbel' if rr == 'gumbel' else 'multinomial_st'
+                temp = cg.gumbel_temp if rr == 'gumbel' else cg.multinomial_temp
+                sample = cg.decode(att_feats, att_masks, mode, temp, att_pre=att_pre, grad=spk_grad)
+                gen = vse.run(fc_feats, decode=sample, only_one_retrieval=oor, slot=2)
+                vse._loss['contrastive'] = gen.loss_sum.detach()[0]
+                terms.append((dw, gen.loss_sum))
+                d_onehot = torch.empty(T, B, cg.vocab_size + 1, device=dev) if spk_grad else None
+
+                def bwd_listener(go, gen=gen, d_onehot=d_onehot):
+                    vse.run_backward(gen, g_scalar=(go * dw).reshape(1).contiguous(), param_grads=lst_grad,
+                                     d_onehot=d_onehot)
+                if spk_grad or lst_grad:
+                    bwd_steps.append(bwd_listener)
+                sample.d_onehot = d_onehot
+            else:
+                raise NotImplementedError(f"retrieval_reward='{rr}' (partial sampling) is not on the MI355X path yet")
+        if ciw:                                                        # CIDEr loss :490-503
+            if sample is None or rr in ('multinomial_soft', 'gumbel_softmax'):
+                sample = cg.decode(att_feats, att_masks, 'multinomial', 1.0, att_pre=att_pre, grad=spk_grad,
+                                   tag='cider_gen')                    # gen_result_for_cider :378-389
+            if greedy is None:
+                greedy = cg.decode(att_feats, att_masks, 'greedy', att_pre=att_pre, tag='greedy')   # :391-403
+            refs, ref_off = self._refs(data, dev)
+            rw = rewards.get_self_critical_reward_device(refs, ref_off, sample, greedy)
+            coef = rw['scores'][:B].float().contiguous() if self.use_gen_cider_scores else rw['reward']
+            if dslp is None:
+                dslp = torch.zeros(B, T, device=dev)
+            lc = engine.seq_loss(sample.slp, sample.seq, sample.L, coef, -1.0, ciw, dslp=dslp, accumulate=True)
+            terms.append((ciw, lc))
+            self._loss['avg_reward'] = coef.mean().detach()
+            self._loss['cider_greedy'] = rw['stats'][1].detach()
+            self._loss['loss_cider'] = lc.detach()[0]
+        if sample is not None and spk_grad and (dslp is not None or getattr(sample, 'd_onehot', None) is not None):
+            def bwd_speaker(go, sample=sample, dslp=dslp):
+                cg.decode_backward(sample, d_onehot=getattr(sample, 'd_onehot', None),
+                                   dslp=(dslp * go) if dslp is not None else None)
+            bwd_steps.append(bwd_speaker)
+
+        if not terms:
+            return torch.zeros((), device=dev)
+        loss = sum(w * t[0] for w, t in terms)
+        anchor = next((p for p in self.parameters() if p.requires_grad), None)
+        if anchor is None or not torch.is_grad_enabled() or not bwd_steps:
+            return loss.detach()
+
+        def backward(go):
+            for step in bwd_steps:
+                step(go)
+        return EngineLoss.apply(loss, anchor, backward)
+
+    def forward(self, fc_feats, seq, masks, data, att_feats, att_masks, is_alternating=False, alternating_turn=None):
+        """:433-555."""
+        if not is_alternating:
+            return self._plain_forward(fc_feats, seq, masks, data, att_feats, att_masks)
+        oldVSE, oldMLE, oldCider, oldDISC = self.getLossFlags()
+        try:
+            if alternating_turn == 'speaker':                          # :508-526
+                if self.retrieval_reward == 'reinforce':
+                    self.changeModelUpdateStatus({'vseModel': False, 'captionModel': True})
+                self.setLossFlages(VSEWeight=0, MLEWeight=oldMLE, ciderFlag=oldCider, DISCWeight=oldDISC)
+                return self._plain_forward(fc_feats, seq, masks, data, att_feats, att_masks)
+            elif alternating_turn == 'listener':                       # :528-555
+                self.changeModelUpdateStatus({'vseModel': True, 'captionModel': False})
+                self.setLossFlages(VSEWeight=oldVSE, MLEWeight=0, ciderFlag=0, DISCWeight=0)
+                cg = self.caption_generator
+                gen = cg.decode(att_feats, att_masks, 'multinomial', 1.0, grad=False)
+                return self._listener_on_generated(fc_feats, gen)
+            raise ValueError(f'unknown alternating_turn {alternating_turn!r}')
+        finally:
+            self.setLossFlages(VSEWeight=oldVSE, MLEWeight=oldMLE, ciderFlag=oldCider, DISCWeight=oldDISC)
+
+    def _listener_on_generated(self, fc_feats, gen):
+        """Listener turn: VSE loss on sampled captions fed as plain indices (:539-551)."""
+        vse = self.vse
+        vw = self.vse_loss_weight
+        if not vw > 0:
+            return torch.zeros((), device=fc_feats.device)
+        gen.stv = None                                               # plain index input, no straight-through values
+        res = vse.run(fc_feats, decode=gen, only_one_retrieval=self.only_one_retrieval, slot=2)
+        self._loss['loss_vse'] = res.loss_sum.detach()[0]
+        vse._loss['contrastive'] = res.loss_sum.detach()[0]
+        loss = vw * res.loss_sum[0]
+        anchor = next((p for p in vse.parameters() if p.requires_grad), None)
+        if anchor is None or not torch.is_grad_enabled():
+            return loss.detach()
+        return EngineLoss.apply(loss, anchor, lambda go: vse.run_backward(res, g_scalar=(go * vw).reshape(1).contiguous()))
+
+    def sample(self, fc_feats, att_feats, att_masks, opt={}):
+        return self.caption_generator.sample(fc_feats, att_feats, att_masks, opt)
+
+    def loss(self):
+        """:562-568."""
+        out = {}
+        out.update(self._loss)
+        out.update({'cap_' + k: v for k, v in self.caption_generator._loss.items()})
+        if self.vse is not None:
+            out.update({'vse_' + k: v for k, v in self.vse._loss.items()})
+        return out

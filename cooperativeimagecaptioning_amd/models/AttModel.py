@@ -1,0 +1,219 @@
+"""Speaker: Att2in2Model with the reference's constructor signature, attributes and
+state-dict names (models/AttModel.py:53-94,456-463,492-508,534-539), computing through the
+HIP engines of libcic_hip.so instead of torch ops.
+
+The nn.Modules below are parameter containers only (so that ``state_dict()`` has exactly the
+reference's keys and the default initialisers draw the same numbers for the same seed);
+none of their ``forward`` methods is on the path.
+"""
+import torch
+import torch.nn as nn
+
+from .. import _lib, engine
+from ..flat import FlatAgent
+from ..noise import NoiseSource
+from ..autograd_glue import EngineLoss
+
+
+class Attention(nn.Module):
+    """Parameter container of models/AttModel.py:456-463."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.rnn_size = opt.rnn_size
+        self.att_hid_size = opt.att_hid_size
+        self.h2att = nn.Linear(self.rnn_size, self.att_hid_size)
+        self.alpha_net = nn.Linear(self.att_hid_size, 1)
+
+
+class Att2in2Core(nn.Module):
+    """Parameter container of models/AttModel.py:492-508."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.input_encoding_size = opt.input_encoding_size
+        self.rnn_size = opt.rnn_size
+        self.drop_prob_lm = opt.drop_prob_lm
+        self.a2c = nn.Linear(self.rnn_size, 2 * self.rnn_size)
+        self.i2h = nn.Linear(self.input_encoding_size, 5 * self.rnn_size)
+        self.h2h = nn.Linear(self.rnn_size, 5 * self.rnn_size)
+        self.dropout = nn.Dropout(self.drop_prob_lm)
+        self.attention = Attention(opt)
+
+
+MODES = {'greedy': _lib.SAMPLE_GREEDY, 'multinomial': _lib.SAMPLE_MULTINOMIAL,
+         'gumbel': _lib.SAMPLE_GUMBEL_ST, 'multinomial_st': _lib.SAMPLE_MULTINOMIAL_ST}
+
+
+class DecodeResult:
+    """What one decode leaves on the device (no host sync): seq/slp/stv are padded to
+    seq_length columns, L is the number of columns the reference would have returned."""
+
+    def __init__(self, fwd, mode, dims, params, att_raw, grad):
+        self.fwd, self.mode, self.dims, self.params, self.att_raw, self.grad = fwd, mode, dims, params, att_raw, grad
+        self.seq, self.slp, self.stv, self.L = fwd['seq'], fwd['slp'], fwd['stv'], fwd['L']
+
+
+class AttModel(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.vocab_size = opt.vocab_size
+        self.input_encoding_size = opt.input_encoding_size
+        self.rnn_size = opt.rnn_size
+        self.num_layers = opt.num_layers
+        self.drop_prob_lm = opt.drop_prob_lm
+        self.seq_length = opt.seq_length
+        self.fc_feat_size = opt.fc_feat_size
+        self.att_feat_size = opt.att_feat_size
+        self.att_hid_size = opt.att_hid_size
+        self.retrieval_reward = opt.retrieval_reward
+        self.gumbel_temp = opt.gumbel_temp
+        self.multinomial_temp = opt.multinomial_temp
+        self.prob_gumbel_softmax = getattr(opt, 'prob_gumbel_softmax', 1)
+        self.prob_multinomial_soft = getattr(opt, 'prob_multinomial_soft', 1)
+        self.use_bn = getattr(opt, 'use_bn', 0)
+        if self.use_bn:
+            raise NotImplementedError('use_bn=1 (BatchNorm1d in att_embed) is outside the MI355X hot path')
+        if self.num_layers != 1:
+            raise NotImplementedError('att2in2 is a single-layer maxout LSTM (models/AttModel.py:492-531)')
+        self.ss_prob = 0.0
+        # same construction order as the reference so that the same seed draws the same weights
+        self.embed = nn.Sequential(nn.Embedding(self.vocab_size + 2, self.input_encoding_size), nn.ReLU(),
+                                   nn.Dropout(self.drop_prob_lm))
+        self.relu_dropout = nn.Sequential(nn.ReLU(), nn.Dropout(self.drop_prob_lm))
+        _ = nn.Linear(self.fc_feat_size, self.rnn_size)   # fc_embed: created then deleted by Att2in2Model (:538)
+        self.att_embed = nn.Sequential(nn.Linear(self.att_feat_size, self.rnn_size), nn.ReLU(),
+                                       nn.Dropout(self.drop_prob_lm))
+        self.logit = nn.Linear(self.rnn_size, self.vocab_size + 1)
+        self.ctx2att = nn.Linear(self.rnn_size, self.att_hid_size)
+        self.decoding_constraint = getattr(opt, 'decoding_constraint', 0)
+        self._loss = {}
+        self._flat = None
+        self.noise = NoiseSource()
+        self._ws = {}
+
+    # ---- engine plumbing -----------------------------------------------------------------
+    def flat(self):
+        if self._flat is None:
+            self._flat = FlatAgent(self)
+        self._flat.ensure()
+        return self._flat
+
+    def _dims(self, B, K, T):
+        return engine.speaker_dims(B, K, self.att_feat_size, self.rnn_size, self.input_encoding_size,
+                                   self.att_hid_size, self.vocab_size, T, self.drop_prob_lm)
+
+    def _check_inputs(self, att_feats):
+        if not att_feats.is_cuda:
+            raise _lib.CicError('cooperativeimagecaptioning_amd runs on the GPU only: att_feats is on ' +
+                                str(att_feats.device) + ' (there is no CPU fallback path)')
+        assert att_feats.dim() == 3 and att_feats.shape[2] == self.att_feat_size
+
+    def att_embed_pre(self, att_feats):
+        """relu(att_embed(att_feats)) before the dropout — computed once per training step and shared
+        by all decodes of the step (AttModel.py:315; their dropout masks differ)."""
+        self._check_inputs(att_feats)
+        fl = self.flat()
+        B, K, _ = att_feats.shape
+        dims = self._dims(B, K, self.seq_length)
+        params = engine.speaker_params(fl.tensors())
+        return engine.speaker_att_embed_fwd(dims, params, att_feats.contiguous().float())
+
+    def decode(self, att_feats, att_masks, mode, temp=1.0, att_pre=None, grad=False, T=None, pick=None,
+               first_token=None, decoding_constraint=None, tag='sample', want_stv=None):
+        """One AttModel.sample / AttModel.forward pass on the device -> DecodeResult."""
+        self._check_inputs(att_feats)
+        fl = self.flat()
+        B, K, _ = att_feats.shape
+        T = T or self.seq_length
+        dims = self._dims(B, K, T)
+        params = engine.speaker_params(fl.tensors())
+        att_raw = att_feats.contiguous().float()
+        if att_pre is None:
+            att_pre = engine.speaker_att_embed_fwd(dims, params, att_raw)
+        p = self.drop_prob_lm if self.training else 0.0
+        dims.p_drop = p
+        nz = self.noise.decode_noise(tag, B, K, self.rnn_size, self.input_encoding_size, self.vocab_size + 1, T, p,
+                                     need_u=(mode == 'gumbel') or (mode in ('multinomial', 'multinomial_st') and pick is None),
+                                     device=att_raw.device)
+        if pick is None:
+            pick = nz.get('pick')
+        if want_stv is None:
+            want_stv = mode in ('gumbel', 'multinomial_st')
+        # a decode whose activations must survive until backward() gets its own workspace
+        ws_key = (tag, B, K, T, grad)
+        fwd = engine.speaker_decode_fwd(dims, params, att_pre, MODES[mode], temp,
+                                        att_masks.contiguous().float() if att_masks is not None else None,
+                                        nz.get('att_keep'), nz.get('x_keep'), nz.get('out_keep'), nz.get('gumbel_u'),
+                                        pick, self.decoding_constraint if decoding_constraint is None else decoding_constraint,
+                                        want_stv=want_stv, ws=self._ws.get(ws_key), first_token=first_token)
+        self._ws[ws_key] = fwd['ws']
+        return DecodeResult(fwd, mode, dims, params, att_raw, grad)
+
+    def decode_backward(self, res, d_onehot=None, dslp=None):
+        fl = self.flat()
+        key = ('bwd', res.dims.B, res.dims.K, res.dims.T)
+        self._ws[key] = engine.speaker_decode_bwd(res.dims, res.params, res.fwd, fl.grad_tensors(), res.att_raw,
+                                                  d_onehot=d_onehot, dslp=dslp, ws_bwd=self._ws.get(key))
+
+    # ---- reference API ---------------------------------------------------------------------
+    def forward(self, fc_feats, att_feats, att_masks, seq, masks):
+        """Teacher-forced MLE loss, models/AttModel.py:103-148."""
+        if self.training and self.ss_prob > 0.0:
+            raise NotImplementedError('scheduled sampling (ss_prob > 0) is not on the MI355X path yet')
+        B, Lp = seq.shape
+        T = Lp - 1
+        res = self.decode(att_feats, att_masks, 'multinomial', 1.0, grad=True, T=T,
+                          pick=seq.t().contiguous().long(), first_token=seq[:, 0].contiguous().long(), tag='mle',
+                          decoding_constraint=0, want_stv=False)
+        dslp = torch.empty(B, T, device=att_feats.device)
+        loss = engine.masked_nll(res.slp, masks.float()[:, 1:], 1.0, dslp=dslp)
+        self._loss['xe'] = loss.detach()[0]
+
+        def bwd(go):
+            self.decode_backward(res, dslp=dslp * go)
+        anchor = next((p for p in self.parameters() if p.requires_grad), None)
+        if anchor is None or not torch.is_grad_enabled():
+            return loss[0].detach().clone()
+        return EngineLoss.apply(loss[0], anchor, bwd)
+
+    def sample(self, fc_feats, att_feats, att_masks, opt={}):
+        """models/AttModel.py:291-452 (beam_size 1).  Outputs are detached (evaluation use); the joint
+        model differentiates through decode()/decode_backward() directly."""
+        use_one_hot = opt.get('use_one_hot', 0)
+        sample_max = opt.get('sample_max', 1)
+        beam_size = opt.get('beam_size', 1)
+        temperature = opt.get('temperature', 1.0)
+        if beam_size > 1:
+            raise NotImplementedError('sample_beam (eval-only, SURVEY.md §8f N1) is not on the MI355X path yet')
+        dc = opt.get('decoding_constraint', self.decoding_constraint)
+        plain = self.retrieval_reward == 'reinforce' or not use_one_hot
+        if sample_max:
+            res = self.decode(att_feats, att_masks, 'greedy', decoding_constraint=dc, tag='greedy')
+        elif plain:
+            res = self.decode(att_feats, att_masks, 'multinomial', temperature, decoding_constraint=dc)
+        elif self.retrieval_reward == 'gumbel':
+            res = self.decode(att_feats, att_masks, 'gumbel', self.gumbel_temp, decoding_constraint=dc)
+        elif self.retrieval_reward == 'multinomial':
+            res = self.decode(att_feats, att_masks, 'multinomial_st', self.multinomial_temp, decoding_constraint=dc)
+        else:
+            raise NotImplementedError(f"retrieval_reward='{self.retrieval_reward}' (partial sampling) is not on the "
+                                      f"MI355X path yet")
+        L = int(res.L.item())                      # the one host sync of a decode (the reference syncs every step)
+        if L == 0:
+            raise ValueError('every caption ended at the first step (the reference raises here too: '
+                             'torch.cat of an empty list, AttModel.py:446)')
+        seq = res.seq[:, :L].long()
+        slp = res.slp[:, :L].clone()
+        if sample_max or plain:
+            return seq, slp
+        one_hot = torch.zeros(seq.shape[0], L, self.vocab_size + 2, device=seq.device)
+        one_hot.scatter_(2, seq.unsqueeze(2), res.stv[:, :L].unsqueeze(2))
+        return seq, one_hot, slp
+
+
+class Att2in2Model(AttModel):
+    def __init__(self, opt):
+        super().__init__(opt)
+        self.core = Att2in2Core(opt)
+        self.fc_embed = lambda x: x

@@ -1,0 +1,57 @@
+"""Random draws of the training step (dropout keep masks, Gumbel uniforms) from the library's
+Philox4x32-10 counter RNG, or injected by the caller.
+
+The reference draws Gumbel noise from torch's CPU generator and dropout masks from the device
+generator (models/gumbel.py:6-11, nn.Dropout); neither stream can be reproduced on another
+device, so parity tests inject the very arrays the reference/oracle used (``override``) and
+production runs draw from (seed, call counter) so that a run is reproducible.
+"""
+import torch
+
+from . import ops
+
+
+class NoiseSource:
+    def __init__(self, seed=0):
+        self.seed = int(seed)
+        self.counter = 0          # Philox offset in units of 2^32 calls: one fresh sub-stream per tensor
+        self.override = None      # {tag: {att_keep,x_keep,out_keep,gumbel_u,pick}} numpy/torch arrays
+
+    def manual_seed(self, seed):
+        self.seed, self.counter = int(seed), 0
+
+    def _next_offset(self):
+        self.counter += 1
+        return self.counter << 32
+
+    def decode_noise(self, tag, B, K, H, E, V1, T, p, need_u, device):
+        if self.override is not None:
+            ov = self.override.get(tag)
+            if ov is None:
+                raise KeyError(f'noise override has no entry for decode "{tag}"')
+            out = {}
+            for k, v in ov.items():
+                if v is None:
+                    continue
+                t = torch.as_tensor(v)
+                if k.endswith('_keep'):
+                    if p == 0.0:
+                        continue
+                    t = t.to(torch.uint8)
+                elif k == 'pick':
+                    t = t.long()
+                else:
+                    t = t.float()
+                out[k] = t.to(device).contiguous()
+            return out
+        out = {}
+        if p > 0.0:
+            for key, shape in (('att_keep', (B, K, H)), ('x_keep', (T + 1, B, E)), ('out_keep', (T + 1, B, H))):
+                t = torch.empty(shape, dtype=torch.uint8, device=device)
+                ops.dropout_keep_(t, p, self.seed, self._next_offset())
+                out[key] = t
+        if need_u:
+            u = torch.empty(T + 1, B, V1, device=device)
+            ops.uniform_(u, self.seed, self._next_offset())
+            out['gumbel_u'] = u
+        return out

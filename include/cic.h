@@ -160,7 +160,8 @@ typedef struct {
                                  Teacher forcing (AttModel.forward, :103-148) = CIC_SAMPLE_MULTINOMIAL with
                                  pick[t] = labels[:, t]: slp then holds log p(target) of every step. */
     const int64_t* first_token; /* [B] input token of step 0; NULL = <bos> = vocab_size+1 (:324-326).
-                                 AttModel.forward starts from labels[:, 0] = 0 instead (:131). */
+                                 AttModel.forward starts from labels[:, 0] = 0 instead (:131).  When set
+                                 (teacher forcing) all T steps count: L is written as T. */
     int32_t* seq;             /* out [B,T]  it * unfinished          (AttModel.py:409-415) */
     float* slp;               /* out [B,T]  sampled log-probs        (AttModel.py:413,423) */
     float* stv;               /* out [B,T]  straight-through values, or NULL */

@@ -89,3 +89,25 @@ def gts_list(z):
         out.append(z['gts_flat'][o:o + int(n)])
         o += int(n)
     return out
+
+
+def make_opt(cfg, B, **kw):
+    """argparse.Namespace with the fields the reference constructors read (golden-fixture sizes)."""
+    import argparse
+    d = dict(vocab_size=97, input_encoding_size=64, rnn_size=64, num_layers=1, drop_prob_lm=0.0,
+             seq_length=16, fc_feat_size=96, att_feat_size=96, att_hid_size=64,
+             retrieval_reward='gumbel', gumbel_temp=1.0, multinomial_temp=1.0,
+             prob_gumbel_softmax=0.5, prob_multinomial_soft=0.5, use_bn=0, decoding_constraint=0,
+             rnn_type='lstm', caption_model='att2in2', vse_model='fc', share_embed=0, phase=None,
+             vse_embed_size=128, vse_no_imgnorm=0, vse_use_abs=0, vse_num_layers=1,
+             vse_rnn_type='gru', vse_pool_type='last', vse_margin=0.2, vse_measure='cosine',
+             vse_max_violation=1, vse_loss_type='contrastive', batch_size=B, vse_loss_weight=0,
+             caption_loss_weight=0, alternating_turn=['speaker', 'listener'],
+             retrieval_reward_weight=0.01, reinforce_baseline_type='gt', only_one_retrieval='off',
+             cider_optimization=0.99, use_gen_cider_scores=0, is_alternating=0, start_from=None,
+             initialize_retrieval=None, df='corpus')
+    for k, v in cfg.items():
+        if k in d:
+            d[k] = v
+    d.update(kw)
+    return argparse.Namespace(**d)
