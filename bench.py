@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Headline benchmark: joint-step images/sec of the AlternatingJointModel speaker<->listener
+training step (att2in2 speaker + VSE-fc listener, straight-through Gumbel tau=1, CIDEr-D
+self-critical term, B=128 per GPU, seq_len 16, 36x2048 region features, vocab 9487).
+
+One step = zero_grad -> forward (sampled decode, listener on the generated captions, greedy
+decode, CIDEr-D reward, loss) -> backward -> [RCCL all-reduce of the two flat gradient buffers]
+-> fused clamp+Adam for both agents, with the batch already resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line (rank 0).  `roofline` is the per-timestep attention kernel (HBM-bound):
+algorithmic bytes per launch / average in-situ launch duration (HIP events recorded by the
+engine around every attention launch of the timed steps) / 8 TB/s.  `cpu_baseline` is the CPU
+oracle (oracle/, a restatement of the reference pinned by golden vectors) timed on this host
+for a bounded number of steps of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ATTN_BYTES_PER_IMAGE = 151696          # p_att + att rows + att_h + att_res + alpha, f32
+HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+
+def cpu_baseline(opt, steps_budget_s=20.0):
+    """The oracle's joint step (fwd + bwd + clamp + Adam), same workload, on the host cores."""
+    from oracle import joint as J
+    from cooperativeimagecaptioning_amd import synthetic
+    import numpy as np
+    torch.manual_seed(0)
+    B = opt.batch_size
+    batch = synthetic.make_batch(opt, seed=1234)
+    g = torch.Generator().manual_seed(0)
+
+    def lin(o, i):
+        r = 1.0 / np.sqrt(i)
+        return ((torch.rand(o, i, generator=g) * 2 - 1) * r).requires_grad_(True), \
+               ((torch.rand(o, generator=g) * 2 - 1) * r).requires_grad_(True)
+    H, E, A, D, V, Jd = opt.rnn_size, opt.input_encoding_size, opt.att_hid_size, opt.att_feat_size, opt.vocab_size, opt.vse_embed_size
+    Ps = {'embed.0.weight': torch.randn(V + 2, E, generator=g).requires_grad_(True)}
+    for nm, (o, i) in {'att_embed.0': (H, D), 'logit': (V + 1, H), 'ctx2att': (A, H), 'core.a2c': (2 * H, H),
+                       'core.i2h': (5 * H, E), 'core.h2h': (5 * H, H), 'core.attention.h2att': (A, H),
+                       'core.attention.alpha_net': (1, A)}.items():
+        Ps[nm + '.weight'], Ps[nm + '.bias'] = lin(o, i)
+    Pl = {'txt_enc.embed.weight': ((torch.rand(V + 2, E, generator=g) - .5) * .2).requires_grad_(True)}
+    Pl['img_enc.fc.weight'], Pl['img_enc.fc.bias'] = lin(Jd, opt.fc_feat_size)
+    Pl['txt_enc.rnn.weight_ih_l0'], Pl['txt_enc.rnn.bias_ih_l0'] = lin(3 * Jd, E)
+    Pl['txt_enc.rnn.weight_hh_l0'], Pl['txt_enc.rnn.bias_hh_l0'] = lin(3 * Jd, Jd)
+    cfg = {k: getattr(opt, k) for k in vars(opt)}
+    st_s, st_l = {}, {}
+    p = opt.drop_prob_lm
+    T = opt.seq_length
+    times = []
+    t_all = time.time()
+    n = 0
+    while True:
+        rs = torch.Generator().manual_seed(100 + n)
+
+        def keeps():
+            return dict(att_keep=(torch.rand(B, 36, H, generator=rs) >= p).float(),
+                        x_keep=(torch.rand(T + 1, B, E, generator=rs) >= p).float(),
+                        out_keep=(torch.rand(T + 1, B, H, generator=rs) >= p).float())
+        t0 = time.time()
+        noise = {'sample': keeps(), 'greedy': keeps()}      # Gumbel uniforms are drawn inside (torch.rand)
+        for P in (Ps, Pl):
+            for v in P.values():
+                v.grad = None
+        loss, _ = J.joint_forward(Ps, Pl, cfg, batch, noise, 'speaker', True)
+        loss.backward()
+        with torch.no_grad():
+            J.clamp_adam_step({k: v for k, v in Ps.items()}, {k: v.grad for k, v in Ps.items()}, st_s, opt.learning_rate, opt.grad_clip)
+            J.clamp_adam_step({k: v for k, v in Pl.items()}, {k: v.grad for k, v in Pl.items()}, st_l, opt.learning_rate, opt.grad_clip)
+        times.append(time.time() - t0)
+        n += 1
+        if n >= 2 and (time.time() - t_all > steps_budget_s or n >= 12):
+            break
+    steady = sorted(times[1:])[len(times[1:]) // 2]
+    return dict(value=B / steady, unit='images/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'{n} joint steps (first discarded, median of the rest) of the same B={B} gumbel+CIDEr-D '
+                       f'workload on the CPU oracle, {steady * 1e3:.0f} ms/step')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=128)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl')        # RCCL over xGMI
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device('cuda', local_rank)
+
+    from cooperativeimagecaptioning_amd import models, optimizer as optim, synthetic, engine
+    from cooperativeimagecaptioning_amd.misc import rewards
+
+    opt = synthetic.default_opt(batch_size=args.batch)
+    torch.manual_seed(0)                       # identical initial weights on every rank
+    rewards.init_scorer('corpus')
+    model = models.AlternatingJointModel(opt).to(dev).train()
+    model.caption_generator.noise.manual_seed(1000 + rank)
+    optimizer_dict = optim.load_optimizer(model, opt)
+    batch = synthetic.make_batch(opt, seed=1234 + rank, device=dev)    # per-rank shard of the global batch
+    turn = opt.alternating_turn[0]
+    optimizer = optimizer_dict[turn]
+
+    def step():
+        optim.zeroing_optimizer(opt, optimizer_dict, optimizer)
+        loss = model(batch['fc_feats'], batch['labels'], batch['masks'], batch, batch['att_feats'], batch['att_masks'],
+                     is_alternating=True, alternating_turn=turn)
+        loss.backward()
+        optim.update_optimizer(optimizer_dict, optimizer, opt)
+        return loss
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    engine.prof_reset()
+    engine.prof_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    engine.prof_enable(False)
+    prof = engine.prof_collect()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    final_loss = float(loss)
+    assert final_loss == final_loss, 'loss is NaN'
+
+    if rank == 0:
+        B = args.batch
+        attn = prof.get('attn_fwd', dict(ms=0.0, n=0))
+        attn_us = attn['ms'] * 1e3 / max(attn['n'], 1)
+        achieved = (ATTN_BYTES_PER_IMAGE * B) / (attn_us * 1e-6) / 1e9 if attn_us > 0 else 0.0
+        out = {
+            'metric': 'joint-step images/sec (B=128, seq16)', 'value': B * world * args.steps / dt, 'unit': 'images/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'AlternatingJointModel joint step, att2in2 speaker + VSE-fc listener, ST-Gumbel '
+                                   'tau=1 + self-critical CIDEr-D, 36x2048 att_feats, vocab 9487, seq_len 16, '
+                                   'dropout 0.5, clamp 0.1 + Adam both agents (BASELINE configs[2])',
+                       'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': f'dp{world}',
+                       'final_loss': final_loss},
+            'roofline': {'bound': 'hbm', 'kernel': 'attn_fwd_kernel (per-timestep top-down attention)',
+                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': None, 'avg_launch_us': attn_us, 'launches_timed': attn['n'],
+                         'algorithmic_bytes_per_launch': ATTN_BYTES_PER_IMAGE * B},
+        }
+        for k, v in prof.items():
+            if k != 'attn_fwd' and v['n']:
+                out.setdefault('kernel_us', {})[k] = v['ms'] * 1e3 / v['n']
+        if world == 1 and not args.no_cpu_baseline:
+            torch.cuda.synchronize()
+            out['cpu_baseline'] = cpu_baseline(opt, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

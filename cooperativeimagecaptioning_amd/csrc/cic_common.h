@@ -30,6 +30,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// in-situ timing hooks (core.hip); no-ops unless cic_prof_enable(1)
+void* cic_prof_begin(int id, hipStream_t st);
+void cic_prof_end(void* h, hipStream_t st);
+#define CIC_PROF(id, st, stmt)                   \
+    do {                                         \
+        void* ph_ = cic_prof_begin((id), (st));  \
+        stmt;                                    \
+        cic_prof_end(ph_, (st));                 \
+    } while (0)
+
 static inline hipStream_t cic_s(cic_stream_t s) { return (hipStream_t)s; }
 static inline int cic_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

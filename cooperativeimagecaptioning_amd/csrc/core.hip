@@ -15,6 +15,56 @@ void cic_set_error(const char* fmt, ...) {
 extern "C" int cic_version(void) { return 100; }
 extern "C" const char* cic_last_error(void) { return g_err; }
 
+// ---- in-situ kernel timing -------------------------------------------------------------------
+#include <vector>
+namespace {
+struct ProfPair { hipEvent_t a, b; int id; };
+bool g_prof_on = false;
+std::vector<ProfPair> g_prof_pairs;      // recorded since the last reset
+std::vector<hipEvent_t> g_prof_pool;     // recycled events
+hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+}  // namespace
+
+bool cic_prof_on() { return g_prof_on; }
+void* cic_prof_begin(int id, hipStream_t st) {
+    if (!g_prof_on) return nullptr;
+    ProfPair p{prof_event(), prof_event(), id};
+    if (!p.a || !p.b) return nullptr;
+    (void)hipEventRecord(p.a, st);
+    g_prof_pairs.push_back(p);
+    return p.b;
+}
+void cic_prof_end(void* h, hipStream_t st) {
+    if (h) (void)hipEventRecord(static_cast<hipEvent_t>(h), st);
+}
+extern "C" int cic_prof_enable(int on) { g_prof_on = on != 0; return 0; }
+extern "C" int cic_prof_reset(void) {
+    for (auto& p : g_prof_pairs) { g_prof_pool.push_back(p.a); g_prof_pool.push_back(p.b); }
+    g_prof_pairs.clear();
+    return 0;
+}
+extern "C" int cic_prof_collect(int id, double* total_ms, int* launches) {
+    CIC_REQUIRE(total_ms && launches && id >= 0 && id < CIC_PROF_COUNT);
+    double tot = 0.0;
+    int n = 0;
+    for (auto& p : g_prof_pairs) {
+        if (p.id != id) continue;
+        CIC_HIP(hipEventSynchronize(p.b));
+        float ms = 0.f;
+        CIC_HIP(hipEventElapsedTime(&ms, p.a, p.b));
+        tot += ms;
+        ++n;
+    }
+    *total_ms = tot;
+    *launches = n;
+    return 0;
+}
+
 namespace {
 
 __global__ __launch_bounds__(256) void uniform_kernel(float* __restrict__ out, int64_t n, uint64_t seed,

@@ -186,6 +186,140 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(cic_gemm_args g) {
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Skinny GEMM for the per-timestep products (M = batch <= 128): one 32-column output strip per
+// workgroup, the K range split over KS wave groups INSIDE the workgroup (each group owns its own
+// LDS tiles and keeps its own global loads in flight), partial accumulators combined through LDS.
+// A per-step GEMM is latency-bound (a single wave's MFMA chain over K and one L2 round trip per
+// K-tile), so the lever is more independent chains and more loads in flight per CU, not tile reuse.
+//   waves = WM * KS;  wave -> (ks = wave / WM, wm = wave % WM);  BM = 32*WM, BN = 32, BK = 32
+// K-tiles are dealt round-robin to the groups (tile j -> group j % KS), so the summation order is
+// fixed: deterministic run to run.
+// ---------------------------------------------------------------------------------------------
+template <int WM, int KS, bool KCA, bool KCB, bool VEC>
+__global__ __launch_bounds__(WM* KS * 64) void gemm_skinny_kernel(cic_gemm_args g) {
+    constexpr int BM = 32 * WM, BN = 32;
+    constexpr int GT = WM * 64;   // threads per K-group
+    using TA = Tile<BM, KCA, VEC, GT>;
+    using TB = Tile<BN, KCB, VEC, GT>;
+    constexpr int GROUP_FLOATS = TA::LDS_FLOATS + TB::LDS_FLOATS;
+    constexpr int RED_FLOATS = KS * WM * 16 * 64;
+    constexpr int LDS_FLOATS = GROUP_FLOATS * KS > RED_FLOATS ? GROUP_FLOATS * KS : RED_FLOATS;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ks = wave / WM, wm = wave % WM;
+    const int gtid = tid - ks * GT;
+    const int h = lane >> 5, r = lane & 31;
+    float* LA = lds + ks * GROUP_FLOATS;
+    float* LB = LA + TA::LDS_FLOATS;
+
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+
+    const int nk1 = (g.K + BK - 1) / BK, nk2 = g.K2 > 0 ? (g.K2 + BK - 1) / BK : 0;
+    const int nk = nk1 + nk2;
+    const int iters = (nk + KS - 1) / KS;
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    f32x4 ra[TA::NV], rb[TB::NV];
+
+    auto load_tile = [&](int j) {
+        if (j < nk1) {
+            TA::load(ra, g.A, g.lda, m0, g.M, j * BK, g.K, gtid);
+            TB::load(rb, g.B, g.ldb, n0, g.N, j * BK, g.K, gtid);
+        } else if (j < nk) {
+            TA::load(ra, g.A2, g.lda2, m0, g.M, (j - nk1) * BK, g.K2, gtid);
+            TB::load(rb, g.B2, g.ldb2, n0, g.N, (j - nk1) * BK, g.K2, gtid);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TA::NV; ++i) ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < TB::NV; ++i) rb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    load_tile(ks);
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+        __syncthreads();
+        TA::store(ra, LA, gtid);
+        TB::store(rb, LB, gtid);
+        __syncthreads();
+        if (it + 1 < iters) load_tile((it + 1) * KS + ks);
+        if (it * KS + ks < nk) {
+#pragma unroll
+            for (int grp = 0; grp < BK / 8; ++grp) {
+                const f32x4 af = TA::frag(LA, wm * 32 + r, grp, h);
+                const f32x4 bf = TB::frag(LB, r, grp, h);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc, 0, 0, 0);
+            }
+        }
+    }
+    // combine the KS partial tiles through LDS: red[ks][wm][reg][lane]
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) lds[((ks * WM + wm) * 16 + e) * 64 + lane] = acc[e];
+    __syncthreads();
+    // wave (ks, wm) finishes registers e = ks, ks+KS, ... of row tile wm
+    const int n = n0 + r;
+    if (n < g.N) {
+        const float bv = g.bias ? g.bias[n] : 0.f;
+        for (int e = ks; e < 16; e += KS) {
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < KS; ++q) v += lds[((q * WM + wm) * 16 + e) * 64 + lane];
+            const int m = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (m < g.M) {
+                float* c = g.C + (size_t)m * g.ldc + n;
+                v += bv;
+                if (g.accumulate) v += *c;
+                if (g.relu) v = fmaxf(v, 0.f);
+                *c = v;
+            }
+        }
+    }
+}
+
+template <int WM, int KS>
+int launch_skinny(const cic_gemm_args& g, bool vec, hipStream_t st) {
+    constexpr int BM = 32 * WM;
+    const int grid = cic_cdiv(g.M, BM) * cic_cdiv(g.N, 32);
+    dim3 blk(WM * KS * 64);
+    const int code = (g.a_kc ? 4 : 0) | (g.b_kc ? 2 : 0) | (vec ? 1 : 0);
+#define CIC_SK_GO(KA, KB, V)                                                                                  \
+    do {                                                                                                      \
+        using TA = Tile<BM, KA, V, WM * 64>;                                                                  \
+        using TB = Tile<32, KB, V, WM * 64>;                                                                  \
+        constexpr int GF = (TA::LDS_FLOATS + TB::LDS_FLOATS) * KS, RF = KS * WM * 16 * 64;                    \
+        constexpr size_t shm = sizeof(float) * (GF > RF ? GF : RF);                                           \
+        static bool attr_set = false;                                                                         \
+        if (!attr_set) {                                                                                      \
+            CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<WM, KS, KA, KB, V>), \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));               \
+            attr_set = true;                                                                                  \
+        }                                                                                                     \
+        hipLaunchKernelGGL((gemm_skinny_kernel<WM, KS, KA, KB, V>), dim3(grid), blk, shm, st, g);             \
+    } while (0)
+    switch (code) {
+        case 7: CIC_SK_GO(true, true, true); break;
+        case 6: CIC_SK_GO(true, true, false); break;
+        case 5: CIC_SK_GO(true, false, true); break;
+        case 4: CIC_SK_GO(true, false, false); break;
+        case 3: CIC_SK_GO(false, true, true); break;
+        case 2: CIC_SK_GO(false, true, false); break;
+        case 1: CIC_SK_GO(false, false, true); break;
+        default: CIC_SK_GO(false, false, false); break;
+    }
+#undef CIC_SK_GO
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_shape(const cic_gemm_args& g, bool vec, hipStream_t st) {
     const int grid = cic_cdiv(g.M, BM) * cic_cdiv(g.N, BN);
@@ -252,7 +386,12 @@ extern "C" int cic_gemm_f32(const cic_gemm_args* a, cic_stream_t s) {
     if (g.K2 > 0)
         vec = vec && operand_vec_ok(g.A2, g.lda2, g.a_kc, g.M, g.K2) && operand_vec_ok(g.B2, g.ldb2, g.b_kc, g.N, g.K2);
     const int64_t big_tiles = (int64_t)cic_cdiv(g.M, 128) * cic_cdiv(g.N, 128);
-    if (g.M <= 128 && g.M > 64) return launch_shape<128, 32, 4, 1>(g, vec, cic_s(s));
+    if (g.M <= 128) {
+        // per-timestep products: in-workgroup split-K (see gemm_skinny_kernel)
+        const int ktot = g.K + g.K2;
+        if (g.M > 64 && (cic_cdiv(g.N, 32) >= 128 || ktot < 2048)) return launch_skinny<4, 4>(g, vec, cic_s(s));
+        return launch_skinny<2, 8>(g, vec, cic_s(s));
+    }
     if (big_tiles >= 192) return launch_shape<128, 128, 2, 2>(g, vec, cic_s(s));
     return launch_shape<64, 64, 2, 2>(g, vec, cic_s(s));
 }

@@ -13,19 +13,26 @@ namespace {
 
 __device__ __forceinline__ float gumbel_from_u(float u) { return -logf(-logf(u + 1e-20f) + 1e-20f); }
 
+constexpr int SNW = 16;   // waves per row workgroup of sampler_bwd_kernel
 __device__ __forceinline__ float block_sum4(float v, float* sh) {
     v = wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
-    return sh[0] + sh[1] + sh[2] + sh[3];
+    float r = 0.f;
+#pragma unroll
+    for (int w = 0; w < SNW; ++w) r += sh[w];
+    return r;
 }
 __device__ __forceinline__ float block_max4(float v, float* sh) {
     v = wave_max(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
-    return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    float r = sh[0];
+#pragma unroll
+    for (int w = 1; w < SNW; ++w) r = fmaxf(r, sh[w]);
+    return r;
 }
 
 // One workgroup per (t, b) row of the vocabulary.
@@ -34,7 +41,7 @@ __device__ __forceinline__ float block_max4(float v, float* sh) {
 //   overwritten by the constant EOS one-hot, AttModel.py:416-420)
 //   d logits_j = unf * y_j (G_j - sum_i y_i G_i) / tau + dslp * ([j == it] - exp(logp_j))
 template <int RV>
-__global__ __launch_bounds__(256) void sampler_bwd_kernel(const float* __restrict__ logp_all,   // [T,B,V1]
+__global__ __launch_bounds__(SNW * 64) void sampler_bwd_kernel(const float* __restrict__ logp_all,   // [T,B,V1]
                                                           const float* __restrict__ U,          // [T+1,B,V1] or null
                                                           const float* __restrict__ G,          // [T,B,V1] or null
                                                           const int32_t* __restrict__ it_all,   // [T+1,B]
@@ -43,7 +50,8 @@ __global__ __launch_bounds__(256) void sampler_bwd_kernel(const float* __restric
                                                           const int32_t* __restrict__ Lp, int mode, float tau,
                                                           float* __restrict__ dlogits,          // [T,B,V1] (may alias G)
                                                           int T, int B, int V1) {
-    __shared__ float sh[4];
+    constexpr int NT = SNW * 64;
+    __shared__ float sh[SNW];
     const int row = blockIdx.x, t = row / B, b = row % B, tid = threadIdx.x;
     const int L = Lp ? *Lp : T;
     const float* lp = logp_all + (size_t)row * V1;
@@ -55,7 +63,7 @@ __global__ __launch_bounds__(256) void sampler_bwd_kernel(const float* __restric
     const bool unf = st_mode && g && seq && t < L && seq[(size_t)b * T + t] > 0;
     const int nq = (V1 + 3) >> 2;
     if (!unf && ds == 0.f) {   // block-uniform: nothing flows into this row
-        for (int c = tid; c < V1; c += 256) out[c] = 0.f;
+        for (int c = tid; c < V1; c += NT) out[c] = 0.f;
         return;
     }
     const float inv_t = 1.0f / tau;
@@ -66,8 +74,8 @@ __global__ __launch_bounds__(256) void sampler_bwd_kernel(const float* __restric
     for (int r = 0; r < RV; ++r)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int c = 4 * (tid + 256 * r) + e;
-            const bool ok = (tid + 256 * r) < nq && c < V1;
+            const int c = 4 * (tid + NT * r) + e;
+            const bool ok = (tid + NT * r) < nq && c < V1;
             x[r][e] = ok ? lp[c] : -INFINITY;
             gg[r][e] = (ok && unf) ? g[c] : 0.f;
             float z = -INFINITY;
@@ -104,8 +112,8 @@ __global__ __launch_bounds__(256) void sampler_bwd_kernel(const float* __restric
     for (int r = 0; r < RV; ++r)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int c = 4 * (tid + 256 * r) + e;
-            if ((tid + 256 * r) < nq && c < V1) {
+            const int c = 4 * (tid + NT * r) + e;
+            if ((tid + NT * r) < nq && c < V1) {
                 float v = 0.f;
                 if (unf) v = y[r][e] * (gg[r][e] - cdot) * inv_t;
                 if (ds != 0.f) v += ds * ((c == it ? 1.f : 0.f) - __expf(x[r][e]));
@@ -163,14 +171,15 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(const float* __restrict__
 // out: ddot[b,k] = alpha_k (dalpha_k - sum_j alpha_j dalpha_j),  dalpha_k = d_att_res . att[b,k,:]
 //      d_att_h[b,a] = w_a * sum_k ddot_k (1 - tanh^2(p_att[b,k,a] + att_h[b,a]))
 // (a masked, renormalised softmax is alpha_k ~ m_k e^{dot_k}: same Jacobian in terms of the final alpha)
-template <int NI, int KPW, bool HOLD>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ d_att_res, const float* __restrict__ alpha,
+template <int NI, int KPW, int NW, bool HOLD>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const float* __restrict__ d_att_res, const float* __restrict__ alpha,
                                                        const float* __restrict__ att_h, const float* __restrict__ p_att,
                                                        const float* __restrict__ att, const float* __restrict__ w_alpha,
                                                        float* __restrict__ d_att_h, float* __restrict__ ddot_out, int K,
                                                        int A, int H) {
     __shared__ float sd[64];
-    __shared__ __attribute__((aligned(16))) float sacc[4 * NI * 256];
+    __shared__ __attribute__((aligned(16))) float sacc[NW * NI * 256];
+    __shared__ __attribute__((aligned(16))) float sacc2[4 * NI * 256];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int A4 = A >> 2, H4 = H >> 2;
     const f32x4* pa4 = reinterpret_cast<const f32x4*>(p_att + (size_t)b * K * A);
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     f32x4 pv[HOLD ? KPW : 1][NI];
 #pragma unroll
     for (int j = 0; j < KPW; ++j) {
-        const int k = w + 4 * j;
+        const int k = w + NW * j;
         if (k < K) {
             float part = 0.f;
 #pragma unroll
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     for (int i = 0; i < NI; ++i) acc[i] = z4;
 #pragma unroll
     for (int j = 0; j < KPW; ++j) {
-        const int k = w + 4 * j;
+        const int k = w + NW * j;
         if (k < K) {
             const float dd = alpha[(size_t)b * K + k] * (sd[k] - cs);
 #pragma unroll
@@ -234,11 +243,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         *reinterpret_cast<f32x4*>(&sacc[(w * NI * 64 + i * 64 + lane) * 4]) = acc[i];
     }
     __syncthreads();
-    for (int c = tid; c < A4; c += 256) {
+    for (int t = tid; t < 4 * A4; t += NW * 64) {
+        const int part = t / A4, c = t % A4;
         const int i = c >> 6, l = c & 63;
-        f32x4 s = *reinterpret_cast<f32x4*>(&sacc[((0 * NI + i) * 64 + l) * 4]);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ww = 1; ww < 4; ++ww) s += *reinterpret_cast<f32x4*>(&sacc[((ww * NI + i) * 64 + l) * 4]);
+        for (int q = 0; q < NW / 4; ++q)
+            s += *reinterpret_cast<f32x4*>(&sacc[(((part * (NW / 4) + q) * NI + i) * 64 + l) * 4]);
+        *reinterpret_cast<f32x4*>(&sacc2[((part * NI + i) * 64 + l) * 4]) = s;
+    }
+    __syncthreads();
+    for (int c = tid; c < A4; c += NW * 64) {
+        const int i = c >> 6, l = c & 63;
+        f32x4 s = *reinterpret_cast<f32x4*>(&sacc2[((0 * NI + i) * 64 + l) * 4]);
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) s += *reinterpret_cast<f32x4*>(&sacc2[((ww * NI + i) * 64 + l) * 4]);
         reinterpret_cast<f32x4*>(d_att_h + (size_t)b * A)[c] = s;
     }
     if (tid < K) ddot_out[(size_t)b * K + tid] = alpha[(size_t)b * K + tid] * (sd[tid] - cs);
@@ -429,10 +448,10 @@ extern "C" int cic_speaker_decode_bwd(const cic_speaker_dims* dp, const cic_spea
 
     // 1. d logits for every step at once (rows are independent of the recurrence)
     {
-        dim3 grid(T * B), blk(256);
+        dim3 grid(T * B), blk(1024);
 #define GO(RV) hipLaunchKernelGGL((sampler_bwd_kernel<RV>), grid, blk, 0, st, w.logp_all, io->U, bio->d_onehot, w.it_all, \
                                   io->seq, bio->dslp, io->L, io->mode, io->temp, g.dlogits, T, B, V1)
-        if (V1 <= 1024) GO(1); else if (V1 <= 4096) GO(4); else if (V1 <= 10240) GO(10);
+        if (V1 <= 4096) GO(1); else if (V1 <= 12288) GO(3); else if (V1 <= 32768) GO(8);
         else { cic_set_error("vocabulary too large"); return 1; }
 #undef GO
         CIC_LAUNCH_CHECK();
@@ -457,18 +476,20 @@ extern "C" int cic_speaker_decode_bwd(const cic_speaker_dims* dp, const cic_spea
         float* dres = g.d_att_res_all + (size_t)t * B * H;
         RUN(gemm_nn(dpre + 3 * H, 5 * H, p->a2c_w, H, dres, H, B, H, 2 * H, false, st));
         {
-            dim3 grid(B), blk(256);
+            dim3 grid(B), blk(1024);
             const int mx = A > H ? A : H;
             float* dah = g.d_att_h_all + (size_t)t * B * A;
             float* ddot = g.ddot_all + (size_t)t * B * K;
             const float* al = w.alpha_all + (size_t)t * B * K;
             const float* ah = w.att_h_all + (size_t)t * B * A;
-#define GO(NI, KPW, HOLD) hipLaunchKernelGGL((attn_bwd_kernel<NI, KPW, HOLD>), grid, blk, 0, st, dres, al, ah, w.p_att, \
-                                             w.att, p->alpha_w, dah, ddot, K, A, H)
-            if (mx <= 256) { if (K <= 36) GO(1, 9, true); else GO(1, 16, false); }
-            else if (mx <= 512) { if (K <= 36) GO(2, 9, true); else GO(2, 16, false); }
-            else GO(4, 16, false);
+#define GO(NI, KPW, HOLD) hipLaunchKernelGGL((attn_bwd_kernel<NI, KPW, 16, HOLD>), grid, blk, 0, st, dres, al, ah, \
+                                             w.p_att, w.att, p->alpha_w, dah, ddot, K, A, H)
+            void* ph = cic_prof_begin(CIC_PROF_ATTN_BWD, st);
+            if (mx <= 256) { if (K <= 48) GO(1, 3, true); else GO(1, 4, true); }
+            else if (mx <= 512) { if (K <= 48) GO(2, 3, true); else GO(2, 4, true); }
+            else GO(4, 4, false);
 #undef GO
+            cic_prof_end(ph, st);
             CIC_LAUNCH_CHECK();
         }
         if (t > 0) {

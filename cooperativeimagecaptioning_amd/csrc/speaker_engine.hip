@@ -125,14 +125,18 @@ extern "C" int cic_speaker_decode_fwd(const cic_speaker_dims* dp, const cic_spea
         RUN(cic_embed_fwd(p->embed_w, w.it_all + (size_t)t * B, xk, xk ? p_drop : 0.f, x, B, E, s));
         // attention                                                        (:465-489)
         RUN(gemm_nt(h, H, p->h2att_w, H, att_h, A, B, A, H, p->h2att_b, false, false, st));
-        RUN(cic_attn_fwd(att_h, w.p_att, w.att, p->alpha_w, p->alpha_b, io->att_masks, att_res,
-                         w.alpha_all + (size_t)t * B * K, w.dot_all + (size_t)t * B * K, B, K, A, H, s));
+        CIC_PROF(CIC_PROF_ATTN_FWD, st,
+                 rc = cic_attn_fwd(att_h, w.p_att, w.att, p->alpha_w, p->alpha_b, io->att_masks, att_res,
+                                   w.alpha_all + (size_t)t * B * K, w.dot_all + (size_t)t * B * K, B, K, A, H, s));
+        if (rc) return rc;
         // all_input_sums = i2h(xt) + h2h(h);  in_transform += a2c(att_res)   (:514,521-522)
         RUN(gemm_nt2(x, E, p->i2h_w, E, E, h, H, p->h2h_w, H, H, pre, 5 * H, B, 5 * H, w.bias_ih, st));
         RUN(gemm_nt(att_res, H, p->a2c_w, H, pre + 3 * H, 5 * H, B, 2 * H, H, p->a2c_b, true, false, st));
         RUN(cic_cell_fwd(pre, c, ok, ok ? p_drop : 0.f, h + (size_t)B * H, c + (size_t)B * H, out, B, H, s));
         // logprobs = log_softmax(logit(output)); choose the input of step t+1   (:328-365,444)
-        RUN(gemm_nt(out, H, p->logit_w, H, logp, V1, B, V1, H, p->logit_b, false, false, st));
+        CIC_PROF(CIC_PROF_LOGIT_GEMM, st,
+                 rc = gemm_nt(out, H, p->logit_w, H, logp, V1, B, V1, H, p->logit_b, false, false, st));
+        if (rc) return rc;
         cic_sampler_args a;
         a.logits = logp; a.B = B; a.V1 = V1; a.ld = V1;
         a.mode = io->mode; a.temp = io->temp;
@@ -144,7 +148,8 @@ extern "C" int cic_speaker_decode_fwd(const cic_speaker_dims* dp, const cic_spea
         a.it_next = w.it_all + (size_t)(t + 1) * B;
         a.seq = io->seq; a.slp = io->slp; a.stv = io->stv; a.seq_ld = T;
         a.any_unfinished = w.any_unf;
-        RUN(cic_logsoftmax_sample(&a, s));
+        CIC_PROF(CIC_PROF_SAMPLER, st, rc = cic_logsoftmax_sample(&a, s));
+        if (rc) return rc;
     }
     if (io->first_token) {
         RUN(cic_fill_i32(io->L, 1, T, st));      // teacher forcing: every step carries a target

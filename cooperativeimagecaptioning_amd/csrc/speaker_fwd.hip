@@ -19,8 +19,8 @@ namespace {
 // coalesced 1-KiB wave loads.  HOLD=true keeps the att tile of the wave's regions in
 // registers across the softmax barrier (one pass over HBM/L2 for both operands).
 // ---------------------------------------------------------------------------------------
-template <int NI, int KPW, bool HOLD>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ att_h,   // [B,A]
+template <int NI, int KPW, int NW, bool HOLD>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const float* __restrict__ att_h,   // [B,A]
                                                        const float* __restrict__ p_att,   // [B,K,A]
                                                        const float* __restrict__ att,     // [B,K,H]
                                                        const float* __restrict__ w_alpha, // [A]
@@ -31,7 +31,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
                                                        float* __restrict__ dot_out,       // [B,K] or null
                                                        int K, int A, int H) {
     __shared__ float sdot[64];
-    __shared__ __attribute__((aligned(16))) float sacc[4 * NI * 256];
+    __shared__ __attribute__((aligned(16))) float sacc[NW * NI * 256];
+    __shared__ __attribute__((aligned(16))) float sacc2[4 * NI * 256];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int A4 = A >> 2, H4 = H >> 2;
     const f32x4* pa4 = reinterpret_cast<const f32x4*>(p_att + (size_t)b * K * A);
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     f32x4 av[HOLD ? KPW : 1][NI];
 #pragma unroll
     for (int j = 0; j < KPW; ++j) {
-        const int k = w + 4 * j;
+        const int k = w + NW * j;
         if (k < K) {   // wave-uniform
             f32x4 p[NI];
 #pragma unroll
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     for (int i = 0; i < NI; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < KPW; ++j) {
-        const int k = w + 4 * j;
+        const int k = w + NW * j;
         if (k < K) {
             float a = __expf(sdot[k] - mx) * inv;
             if (masks) a = a * masks[(size_t)b * K + k] * minv;
@@ -111,11 +112,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     for (int i = 0; i < NI; ++i)
         *reinterpret_cast<f32x4*>(&sacc[(w * NI * 64 + i * 64 + lane) * 4]) = acc[i];
     __syncthreads();
-    for (int c = tid; c < H4; c += 256) {
+    // two-level cross-wave sum: 4 partial groups of NW/4 waves, then the 4 partials
+    for (int t = tid; t < 4 * H4; t += NW * 64) {
+        const int part = t / H4, c = t % H4;
         const int i = c >> 6, l = c & 63;
-        f32x4 s = *reinterpret_cast<f32x4*>(&sacc[((0 * NI + i) * 64 + l) * 4]);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ww = 1; ww < 4; ++ww) s += *reinterpret_cast<f32x4*>(&sacc[((ww * NI + i) * 64 + l) * 4]);
+        for (int q = 0; q < NW / 4; ++q)
+            s += *reinterpret_cast<f32x4*>(&sacc[(((part * (NW / 4) + q) * NI + i) * 64 + l) * 4]);
+        *reinterpret_cast<f32x4*>(&sacc2[((part * NI + i) * 64 + l) * 4]) = s;
+    }
+    __syncthreads();
+    for (int c = tid; c < H4; c += NW * 64) {
+        const int i = c >> 6, l = c & 63;
+        f32x4 s = *reinterpret_cast<f32x4*>(&sacc2[((0 * NI + i) * 64 + l) * 4]);
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) s += *reinterpret_cast<f32x4*>(&sacc2[((ww * NI + i) * 64 + l) * 4]);
         reinterpret_cast<f32x4*>(att_res + (size_t)b * H)[c] = s;
     }
     if (tid < K) {
@@ -219,19 +231,26 @@ __device__ __forceinline__ ArgMax wave_argmax(ArgMax a) {
     }
     return a;
 }
+constexpr int SNW = 16;   // waves per row workgroup of the sampler kernel
 __device__ __forceinline__ float block_sum(float v, float* sh) {
     v = wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
-    return sh[0] + sh[1] + sh[2] + sh[3];
+    float r = 0.f;
+#pragma unroll
+    for (int w = 0; w < SNW; ++w) r += sh[w];
+    return r;
 }
 __device__ __forceinline__ float block_max(float v, float* sh) {
     v = wave_max(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
-    return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    float r = sh[0];
+#pragma unroll
+    for (int w = 1; w < SNW; ++w) r = fmaxf(r, sh[w]);
+    return r;
 }
 __device__ __forceinline__ ArgMax block_argmax(ArgMax a, float* shv, int* shi) {
     a = wave_argmax(a);
@@ -243,7 +262,7 @@ __device__ __forceinline__ ArgMax block_argmax(ArgMax a, float* shv, int* shi) {
     __syncthreads();
     ArgMax r = {shv[0], shi[0]};
 #pragma unroll
-    for (int w = 1; w < 4; ++w) r = amax_better(r, ArgMax{shv[w], shi[w]});
+    for (int w = 1; w < SNW; ++w) r = amax_better(r, ArgMax{shv[w], shi[w]});
     return r;
 }
 
@@ -252,10 +271,11 @@ __device__ __forceinline__ float gumbel_from_u(float u) {
     return -logf(-logf(u + 1e-20f) + 1e-20f);
 }
 
-template <int RV>   // RV float4 per thread: rows up to RV*1024 floats
-__global__ __launch_bounds__(256) void logsoftmax_sample_kernel(cic_sampler_args a) {
-    __shared__ float shf[4];
-    __shared__ int shi[4];
+template <int RV>   // RV float4 per thread: rows up to RV*4096 floats
+__global__ __launch_bounds__(SNW * 64) void logsoftmax_sample_kernel(cic_sampler_args a) {
+    constexpr int NT = SNW * 64;
+    __shared__ float shf[SNW];
+    __shared__ int shi[SNW];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int V1 = a.V1;
     float* row = a.logits + (size_t)b * a.ld;
@@ -267,7 +287,7 @@ __global__ __launch_bounds__(256) void logsoftmax_sample_kernel(cic_sampler_args
     float mx = -INFINITY;
 #pragma unroll
     for (int r = 0; r < RV; ++r) {
-        const int q = tid + 256 * r;
+        const int q = tid + NT * r;
 #pragma unroll
         for (int e = 0; e < 4; ++e) x[r][e] = -INFINITY;
         if (q < nq) {
@@ -298,7 +318,7 @@ __global__ __launch_bounds__(256) void logsoftmax_sample_kernel(cic_sampler_args
     // log-probs back to memory (saved for the backward pass) and kept in registers
 #pragma unroll
     for (int r = 0; r < RV; ++r) {
-        const int q = tid + 256 * r;
+        const int q = tid + NT * r;
 #pragma unroll
         for (int e = 0; e < 4; ++e) x[r][e] -= lse;
         if (q < nq) {
@@ -322,7 +342,7 @@ __global__ __launch_bounds__(256) void logsoftmax_sample_kernel(cic_sampler_args
     float z[RV][4];
 #pragma unroll
     for (int r = 0; r < RV; ++r) {
-        const int q = tid + 256 * r;
+        const int q = tid + NT * r;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int col = 4 * q + e;
@@ -351,7 +371,7 @@ __global__ __launch_bounds__(256) void logsoftmax_sample_kernel(cic_sampler_args
     for (int r = 0; r < RV; ++r)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (4 * (tid + 256 * r) + e == it) slp_part = x[r][e];
+            if (4 * (tid + NT * r) + e == it) slp_part = x[r][e];
     const float slp = block_sum(slp_part, shf);
     float v = 1.0f;
     if (a.mode == CIC_SAMPLE_GUMBEL_ST || a.mode == CIC_SAMPLE_MULTINOMIAL_ST) {
@@ -365,7 +385,7 @@ __global__ __launch_bounds__(256) void logsoftmax_sample_kernel(cic_sampler_args
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     s2 += __expf(z[r][e] - zm);
-                    if (4 * (tid + 256 * r) + e == it) zi = z[r][e];
+                    if (4 * (tid + NT * r) + e == it) zi = z[r][e];
                 }
         } else {
             float m2 = -INFINITY;
@@ -380,7 +400,7 @@ __global__ __launch_bounds__(256) void logsoftmax_sample_kernel(cic_sampler_args
                 for (int e = 0; e < 4; ++e) {
                     const float t = x[r][e] * inv_t;
                     s2 += __expf(t - zm);
-                    if (4 * (tid + 256 * r) + e == it) zi = t;
+                    if (4 * (tid + NT * r) + e == it) zi = t;
                 }
         }
         s2 = block_sum(s2, shf);
@@ -427,17 +447,18 @@ extern "C" int cic_attn_fwd(const float* att_h, const float* p_att, const float*
     CIC_REQUIRE(B > 0 && K > 0 && K <= 64 && (A & 3) == 0 && (H & 3) == 0);
     const int mx = A > H ? A : H;
     CIC_REQUIRE(mx <= 1024);
-    dim3 grid(B), blk(256);
+    dim3 grid(B);
     hipStream_t st = cic_s(s);
-#define GO(NI, KPW, HOLD)                                                                              \
-    hipLaunchKernelGGL((attn_fwd_kernel<NI, KPW, HOLD>), grid, blk, 0, st, att_h, p_att, att, w_alpha, \
+    // 16 waves per image: each wave owns <= 4 regions, whose p_att and att rows are all in flight at once
+#define GO(NI, KPW, HOLD)                                                                                        \
+    hipLaunchKernelGGL((attn_fwd_kernel<NI, KPW, 16, HOLD>), grid, dim3(1024), 0, st, att_h, p_att, att, w_alpha, \
                        b_alpha, masks, att_res, alpha, dot, K, A, H)
     if (mx <= 256) {
-        if (K <= 36) GO(1, 9, true); else GO(1, 16, false);
+        if (K <= 48) GO(1, 3, true); else GO(1, 4, true);
     } else if (mx <= 512) {
-        if (K <= 36) GO(2, 9, true); else GO(2, 16, false);
+        if (K <= 48) GO(2, 3, true); else GO(2, 4, true);
     } else {
-        GO(4, 16, false);
+        GO(4, 4, false);
     }
 #undef GO
     CIC_LAUNCH_CHECK();
@@ -482,13 +503,13 @@ extern "C" int cic_logsoftmax_sample(const cic_sampler_args* a, cic_stream_t s) 
                              ((a->mode == CIC_SAMPLE_MULTINOMIAL || a->mode == CIC_SAMPLE_MULTINOMIAL_ST) && !a->pick);
         CIC_REQUIRE(!needs_u || (a->U && a->ldu >= a->V1));
     }
-    dim3 grid(a->B), blk(256);
+    dim3 grid(a->B), blk(1024);
     hipStream_t st = cic_s(s);
-    if (a->V1 <= 1024) hipLaunchKernelGGL((logsoftmax_sample_kernel<1>), grid, blk, 0, st, *a);
-    else if (a->V1 <= 4096) hipLaunchKernelGGL((logsoftmax_sample_kernel<4>), grid, blk, 0, st, *a);
-    else if (a->V1 <= 10240) hipLaunchKernelGGL((logsoftmax_sample_kernel<10>), grid, blk, 0, st, *a);
+    if (a->V1 <= 4096) hipLaunchKernelGGL((logsoftmax_sample_kernel<1>), grid, blk, 0, st, *a);
+    else if (a->V1 <= 12288) hipLaunchKernelGGL((logsoftmax_sample_kernel<3>), grid, blk, 0, st, *a);
+    else if (a->V1 <= 32768) hipLaunchKernelGGL((logsoftmax_sample_kernel<8>), grid, blk, 0, st, *a);
     else {
-        cic_set_error("cic_logsoftmax_sample: vocabulary %d too large (max 10240)", a->V1);
+        cic_set_error("cic_logsoftmax_sample: vocabulary %d too large (max 32768)", a->V1);
         return 1;
     }
     CIC_LAUNCH_CHECK();

@@ -232,3 +232,26 @@ def masked_nll(slp, mask, weight, dslp=None, loss_out=None):
 def clamp_adam(p, g, m, v, lr, step, grad_clip=0.1, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
     check(lib.cic_clamp_adam(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay,
                              grad_clip, int(step), grad_scale, stream()), 'cic_clamp_adam')
+
+
+PROF_IDS = {'attn_fwd': 0, 'logit_gemm': 1, 'attn_bwd': 2, 'sampler': 3}
+lib.cic_prof_enable.argtypes = [C.c_int]
+lib.cic_prof_collect.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+
+
+def prof_enable(on):
+    check(lib.cic_prof_enable(int(bool(on))), 'cic_prof_enable')
+
+
+def prof_reset():
+    check(lib.cic_prof_reset(), 'cic_prof_reset')
+
+
+def prof_collect():
+    """-> {kernel: dict(ms=total elapsed, n=launches)} for the launches bracketed since prof_reset()."""
+    out = {}
+    for name, i in PROF_IDS.items():
+        ms, n = C.c_double(0.0), C.c_int(0)
+        check(lib.cic_prof_collect(i, C.byref(ms), C.byref(n)), 'cic_prof_collect')
+        out[name] = dict(ms=ms.value, n=n.value)
+    return out

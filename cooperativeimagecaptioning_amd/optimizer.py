@@ -1,0 +1,189 @@
+"""Mirror of the reference's optimizer.py (define/load/zero/update/save, :25-242) on top of
+FlatAdam: Adam with torch's default betas/eps (the reference ignores its --optim* flags,
+optimizer.py:25-27) whose step is ONE fused clamp+Adam kernel over the agent's flat parameter
+buffer (cic_clamp_adam), preceded — when torch.distributed is initialised — by ONE RCCL
+all-reduce of the agent's flat gradient buffer (data-parallel replicas).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import engine
+from .misc import utils
+
+
+class FlatAdam:
+    """torch.optim.Adam look-alike for one agent (a module owning a FlatAgent via .flat())."""
+
+    def __init__(self, module, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8):
+        self.module = module
+        self.param_groups = [dict(params=list(module.parameters()), lr=lr, weight_decay=weight_decay,
+                                  betas=betas, eps=eps)]
+        self._grad_clip = None
+
+    @property
+    def flat(self):
+        return self.module.flat()
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.zero_grad()
+
+    def set_grad_clip(self, grad_clip):
+        """utils.clip_gradient() on a FlatAdam defers the clamp into the fused step kernel."""
+        self._grad_clip = float(grad_clip)
+
+    def all_reduce_grads(self):
+        """One collective per agent over the flat f32 gradient (sum); the 1/world scale is folded
+        into the Adam kernel."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM)
+            return 1.0 / dist.get_world_size()
+        return 1.0
+
+    def step(self):
+        fl = self.flat
+        g = self.param_groups[0]
+        scale = self.all_reduce_grads()
+        if not any(p.requires_grad for p in fl.params):
+            return
+        fl.step += 1
+        clip = self._grad_clip if self._grad_clip is not None else 3.0e38
+        engine.clamp_adam(fl.flat, fl.grad, fl.exp_avg, fl.exp_avg_sq, g['lr'], fl.step, clip, g['betas'], g['eps'],
+                          g['weight_decay'], scale)
+
+    # torch-compatible checkpoints: per-parameter state in parameter order
+    def state_dict(self):
+        fl = self.flat
+        state = {}
+        for i, (p, o) in enumerate(zip(fl.params, fl.offsets)):
+            n = p.numel()
+            state[i] = dict(step=torch.tensor(float(fl.step)),
+                            exp_avg=fl.exp_avg[o:o + n].view(p.shape).clone(),
+                            exp_avg_sq=fl.exp_avg_sq[o:o + n].view(p.shape).clone())
+        g = self.param_groups[0]
+        pg = dict(lr=g['lr'], betas=g['betas'], eps=g['eps'], weight_decay=g['weight_decay'], amsgrad=False,
+                  params=list(range(len(fl.params))))
+        return dict(state=state, param_groups=[pg])
+
+    def load_state_dict(self, sd):
+        fl = self.flat
+        for i, (p, o) in enumerate(zip(fl.params, fl.offsets)):
+            st = sd['state'].get(i)
+            if st is None:
+                continue
+            n = p.numel()
+            fl.exp_avg[o:o + n].copy_(st['exp_avg'].reshape(-1))
+            fl.exp_avg_sq[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
+            fl.step = int(st['step'])
+        if sd.get('param_groups'):
+            self.param_groups[0]['lr'] = sd['param_groups'][0].get('lr', self.param_groups[0]['lr'])
+
+
+def load_optimizer_path(opt, curr_turn=None):
+    """optimizer.py:9-22."""
+    if opt.is_alternating:
+        p = os.path.join(opt.start_from, curr_turn + '_optimizer.pth')
+        return p if os.path.isfile(p) else None
+    if opt.start_from is not None:
+        return os.path.join(opt.start_from, 'optimizer.pth')
+    return None
+
+
+def define_optimizer(model, opt):
+    """optimizer.py:25-27."""
+    return FlatAdam(model, lr=opt.learning_rate, weight_decay=opt.weight_decay)
+
+
+def load_state_dict(optimizer, optimizer_path, agent=''):
+    """optimizer.py:30-40 (tensors only: weights_only=True)."""
+    sd = torch.load(optimizer_path, map_location='cpu', weights_only=True)
+    optimizer.load_state_dict(sd)
+    print(f'\n Loaded {agent} optimizer from {optimizer_path} \n')
+    return optimizer
+
+
+def load_optimizer(model, opt):
+    """optimizer.py:149-188.  In gumbel/multinomial alternating mode the listener turn is removed and
+    both agents step every iteration (:90-95)."""
+    start_from_exist = (vars(opt).get('start_from', None) is not None)
+    optimizer_dict = {}
+    if opt.is_alternating:
+        for curr_turn in list(opt.alternating_turn):
+            if curr_turn == 'speaker':
+                o = define_optimizer(model.caption_generator, opt)
+                if start_from_exist:
+                    path = load_optimizer_path(opt, curr_turn)
+                    if path:
+                        o = load_state_dict(o, path, curr_turn)
+                    elif not opt.share_embed and os.path.isfile(str(opt.speaker_stage_2_optimizer_path)):
+                        o = load_state_dict(o, opt.speaker_stage_2_optimizer_path, curr_turn)
+                else:
+                    print('Loaded new "speaker" optimizer')
+                optimizer_dict[curr_turn] = o
+            elif curr_turn == 'listener':
+                o = define_optimizer(model.vse, opt)
+                if start_from_exist:
+                    path = load_optimizer_path(opt, curr_turn)
+                    if path:
+                        o = load_state_dict(o, path, curr_turn)
+                    elif not opt.share_embed and opt.initialize_retrieval:
+                        p2 = os.path.join(os.path.split(opt.initialize_retrieval)[0], 'optimizer.pth')
+                        if os.path.isfile(p2):
+                            o = load_state_dict(o, p2, curr_turn)
+                    else:
+                        print('\n Using new "listener" optimizer \n')
+                if opt.retrieval_reward == 'reinforce':
+                    optimizer_dict[curr_turn] = o
+                else:
+                    optimizer_dict['speaker'] = {'speaker': optimizer_dict['speaker'], 'listener': o}
+                    opt.alternating_turn.remove('listener')
+    else:
+        exist = load_optimizer_path(opt)
+        if opt.phase == 1:
+            o = define_optimizer(model.vse, opt)
+        elif opt.phase in (2, 3):
+            o = define_optimizer(model.caption_generator, opt)
+        else:
+            raise AssertionError(f'phase has to be 1,2 or 3 but got {opt.phase}')
+        if start_from_exist and exist and os.path.isfile(exist):
+            o = load_state_dict(o, exist)
+        optimizer_dict['optimizer'] = o
+    return optimizer_dict
+
+
+def save_optimizer(opt, optimizer_dict):
+    """optimizer.py:191-221."""
+    def _save(o, name):
+        path = os.path.join(opt.checkpoint_path, name)
+        torch.save(o.state_dict(), path)
+        print(f'\n optimizer saved to {path}')
+    if opt.is_alternating:
+        if opt.retrieval_reward == 'reinforce':
+            for agent, o in optimizer_dict.items():
+                _save(o, agent + '_optimizer.pth')
+        else:
+            for agent, o in optimizer_dict['speaker'].items():
+                _save(o, agent + '_optimizer.pth')
+    else:
+        _save(optimizer_dict['optimizer'], 'optimizer.pth')
+
+
+def zeroing_optimizer(opt, optimizer_dict, optimizer):
+    """optimizer.py:224-230."""
+    if opt.retrieval_reward != 'reinforce' and opt.is_alternating:
+        for agent in optimizer_dict['speaker'].keys():
+            optimizer_dict['speaker'][agent].zero_grad()
+    else:
+        optimizer.zero_grad()
+
+
+def update_optimizer(optimizer_dict, optimizer, opt):
+    """optimizer.py:233-242: clamp then step, for one or both agents."""
+    if opt.retrieval_reward != 'reinforce' and opt.is_alternating:
+        for agent in optimizer_dict['speaker'].keys():
+            utils.clip_gradient(optimizer_dict['speaker'][agent], opt.grad_clip)
+            optimizer_dict['speaker'][agent].step()
+    else:
+        utils.clip_gradient(optimizer, opt.grad_clip)
+        optimizer.step()

@@ -1,0 +1,51 @@
+"""Synthetic COCO-shaped batches and reference-default options: what bench.py,
+smoke() and the scaling tests feed the step when no dataset is present."""
+import argparse
+
+import numpy as np
+import torch
+
+
+def default_opt(**kw):
+    """The fields the model constructors read, at the reference's run_joint.sh defaults
+    (bash_scripts/run_joint.sh:36-61,285-326; opts.py)."""
+    d = dict(vocab_size=9487, input_encoding_size=512, rnn_size=512, num_layers=1, drop_prob_lm=0.5,
+             seq_length=16, fc_feat_size=2048, att_feat_size=2048, att_hid_size=512,
+             retrieval_reward='gumbel', gumbel_temp=1.0, multinomial_temp=1.0,
+             prob_gumbel_softmax=0.25, prob_multinomial_soft=0.25, use_bn=0, decoding_constraint=0,
+             rnn_type='lstm', caption_model='att2in2', vse_model='fc', share_embed=0, phase=None,
+             vse_embed_size=1024, vse_no_imgnorm=0, vse_use_abs=0, vse_num_layers=1,
+             vse_rnn_type='gru', vse_pool_type='last', vse_margin=0.2, vse_measure='cosine',
+             vse_max_violation=1, vse_loss_type='contrastive', batch_size=128, vse_loss_weight=0,
+             caption_loss_weight=0, alternating_turn=['speaker', 'listener'],
+             retrieval_reward_weight=0.01, reinforce_baseline_type='gt', only_one_retrieval='off',
+             cider_optimization=0.99, use_gen_cider_scores=0, is_alternating=1, start_from=None,
+             initialize_retrieval=None, df='corpus', continue_from_existing_models=False,
+             learning_rate=5e-4, weight_decay=0.0, grad_clip=0.1, seq_per_img=1, cached_tokens='corpus')
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+def make_batch(opt, K=36, seed=1234, ncap=5, device='cpu'):
+    """att_feats ~ 0.5*|N(0,1)| (ReLU-like pooled CNN features), fc = mean over regions, labels with
+    Zipf(1.1) tokens and lengths U{6..16}, 5 ground-truth captions per image (dataloader.py:171-245
+    output contract)."""
+    g = torch.Generator().manual_seed(seed)
+    B, V, SL = opt.batch_size, opt.vocab_size, opt.seq_length
+    att = torch.randn(B, K, opt.att_feat_size, generator=g).abs() * 0.5
+    fc = att.mean(1)
+    rs = np.random.RandomState(seed)
+
+    def cap():
+        ln = rs.randint(6, SL + 1)
+        row = np.zeros(SL, np.int64)
+        row[:ln] = np.minimum(rs.zipf(1.1, size=ln), V)
+        return row
+    gts = [np.stack([cap() for _ in range(ncap)]) for _ in range(B)]
+    labels = np.zeros((B, SL + 2), np.int64)
+    masks = np.zeros((B, SL + 2), np.float32)
+    for i in range(B):
+        labels[i, 1:SL + 1] = gts[i][0]
+        masks[i, :int((gts[i][0] > 0).sum()) + 2] = 1
+    return dict(fc_feats=fc.to(device), att_feats=att.to(device), att_masks=None,
+                labels=torch.from_numpy(labels).to(device), masks=torch.from_numpy(masks).to(device), gts=gts)

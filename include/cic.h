@@ -34,6 +34,15 @@ typedef void* cic_stream_t; /* hipStream_t */
 int cic_version(void);
 const char* cic_last_error(void);
 
+/* ---- in-situ kernel timing (HIP events recorded by the engines around selected launches) ---- */
+enum { CIC_PROF_ATTN_FWD = 0, CIC_PROF_LOGIT_GEMM = 1, CIC_PROF_ATTN_BWD = 2, CIC_PROF_SAMPLER = 3, CIC_PROF_COUNT = 4 };
+/* While enabled, every launch of the listed kernels inside the sequence engines is bracketed by a
+ * pair of HIP events on the engine's stream.  cic_prof_collect synchronises those events and
+ * returns the summed elapsed time and launch count of one kernel id since the last reset. */
+int cic_prof_enable(int on);
+int cic_prof_reset(void);
+int cic_prof_collect(int id, double* total_ms, int* launches);
+
 /* ---- RNG (replaces torch.rand / nn.Dropout's bernoulli_ draws) ---------------------- */
 /* Philox4x32-10 counter RNG.  u[i] = (r >> 8) * 2^-24 in [0,1), as torch.rand does
  * (models/gumbel.py:6-11).  Element i uses counter (offset + i/4), lane i%4. */
