@@ -64,8 +64,11 @@ class AlternatingJointModel(nn.Module):
                 else:
                     path = opt.speaker_stage_2_model_path
                     msg = f'Loaded pre-trained "speaker" model, after stage 2 from {path}'
-                utils.load_state_dict(self, torch.load(path, map_location='cpu', weights_only=True))
-                print(msg)
+                if path and os.path.isfile(str(path)):
+                    utils.load_state_dict(self, torch.load(path, map_location='cpu', weights_only=True))
+                    print(msg)
+                else:
+                    print(f'no pre-trained model at {path!r}: starting the joint model from its random initialisation')
         else:
             load(self, opt, iteration)
             if getattr(opt, 'initialize_retrieval', None) is not None:

@@ -49,3 +49,19 @@ def make_batch(opt, K=36, seed=1234, ncap=5, device='cpu'):
         masks[i, :int((gts[i][0] > 0).sum()) + 2] = 1
     return dict(fc_feats=fc.to(device), att_feats=att.to(device), att_masks=None,
                 labels=torch.from_numpy(labels).to(device), masks=torch.from_numpy(masks).to(device), gts=gts)
+
+
+class SyntheticLoader:
+    """get_batch('train') with the reference loader's output contract (dataloader.py:171-245): numpy
+    arrays on the host, a fresh random batch per call, `bounds.wrapped` every `iters_per_epoch` calls."""
+
+    def __init__(self, opt, seed=1234, K=36, iters_per_epoch=100):
+        self.opt, self.seed, self.K, self.n, self.ipe = opt, seed, K, 0, iters_per_epoch
+        self.vocab_size, self.seq_length = opt.vocab_size, opt.seq_length
+
+    def get_batch(self, split):
+        b = make_batch(self.opt, K=self.K, seed=self.seed + self.n)
+        self.n += 1
+        return dict(fc_feats=b['fc_feats'].numpy(), att_feats=b['att_feats'].numpy(), att_masks=None,
+                    labels=b['labels'].numpy(), masks=b['masks'].numpy(), gts=b['gts'],
+                    bounds=dict(it_pos_now=self.n, it_max=self.ipe, wrapped=(self.n % self.ipe == 0)), infos=[])

@@ -1,0 +1,71 @@
+"""CPU, world_size 2, gloo: the data-parallel exchange of the step (one all-reduce per agent over
+its flat gradient buffer, 1/world folded into the update) — the same code path bench.py and
+train.py use with backend nccl (= RCCL) on the GPUs."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import golden_util as GU
+    from cooperativeimagecaptioning_amd import models, optimizer as optim
+    z = GU.load_case('joint_gumbel')
+    opt = GU.make_opt(GU.cfg_dict(z), 6, is_alternating=1, learning_rate=5e-4, weight_decay=0.0,
+                      continue_from_existing_models=False)
+    torch.manual_seed(0)                                   # every rank: identical initial replicas
+    model = models.AlternatingJointModel(opt)
+    od = optim.load_optimizer(model, opt)
+    res = {}
+    for agent, o in od['speaker'].items():
+        fl = o.flat
+        # replicas start identical
+        chk = torch.tensor([float(fl.flat.double().sum())], dtype=torch.float64)
+        both = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(both, chk)
+        assert all(float(b) == float(both[0]) for b in both)
+        g = torch.Generator().manual_seed(100 + rank)
+        local = torch.randn(fl.numel, generator=g)
+        fl.grad.copy_(local)
+        scale = o.all_reduce_grads()
+        assert scale == 1.0 / world
+        res[agent] = (local.numpy(), fl.grad.numpy().copy())
+        # p.grad views alias the reduced buffer
+        p0 = fl.params[0]
+        assert p0.grad.data_ptr() == fl.grad.data_ptr() + 4 * fl.offsets[0]
+    np.savez(os.path.join(out_dir, f'r{rank}.npz'), **{f'{a}_{i}': v for a, t in res.items() for i, v in enumerate(t)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gradient_allreduce(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(os.path.join(str(tmp_path), f'r{i}.npz')) for i in range(world)]
+    for agent in ('speaker', 'listener'):
+        total = r[0][f'{agent}_0'] + r[1][f'{agent}_0']
+        for i in range(world):
+            # every rank holds the SUM; scaled by 1/world in the update it equals the mean of the
+            # per-rank gradients = one rank accumulating both micro-batches and dividing by 2
+            np.testing.assert_allclose(r[i][f'{agent}_1'], total, rtol=1e-6, atol=1e-6)
+        np.testing.assert_array_equal(r[0][f'{agent}_1'], r[1][f'{agent}_1'])

@@ -1,0 +1,162 @@
+"""CPU: host-side logic of the mirrored module API (no kernels are launched)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+import golden_util as GU
+
+
+def test_opts_flags_match_reference_defaults():
+    from cooperativeimagecaptioning_amd import opts
+    o = opts.parse_opt(['--caption_model', 'att2in2', '--vse_model', 'fc', '--is_alternating', '1',
+                        '--alternating_turn', 'speaker', '--alternating_turn', 'listener',
+                        '--retrieval_reward', 'gumbel', '--gumbel_temp', '1', '--batch_size', '128'])
+    assert o.alternating_turn == ['speaker', 'listener'] and o.batch_size == 128 and o.gumbel_temp == 1.0
+    # defaults the reference scripts rely on (opts.py:27,65,142-149,190-207,238-243)
+    assert o.cached_tokens == 'corpus' and o.grad_clip == 0.1 and o.drop_prob_lm == 0.5
+    assert o.learning_rate == 4e-4 and o.vse_margin == 0.2 and o.vse_embed_size == 1024
+    assert o.reinforce_baseline_type == 'greedy' and o.continue_from_existing_models is True
+    assert o.scheduled_sampling_start == -1 and o.seq_per_img == 1 and o.beam_size == 1
+    with pytest.raises(AssertionError):
+        opts.parse_opt(['--drop_prob_lm', '1.5'])
+
+
+def test_state_dict_keys_and_seeded_init_match_reference():
+    """Same constructor signature, same state-dict names, and the same seed draws the same weights as
+    the reference did (weights_s5.npz was dumped from the reference after torch.manual_seed(5))."""
+    from cooperativeimagecaptioning_amd import models
+    z = GU.load_case('joint_gumbel')
+    cfg = GU.cfg_dict(z)
+    opt = GU.make_opt(cfg, z['fc'].shape[0])
+    torch.manual_seed(5)
+    m = models.AlternatingJointModel(opt)
+    base = np.load(os.path.join(GU.GOLDEN, 'weights_s5.npz'))
+    sd = m.state_dict()
+    assert sorted(sd.keys()) == sorted(base.files)
+    for k in base.files:
+        np.testing.assert_array_equal(sd[k].numpy(), base[k], err_msg=k)
+
+
+def test_flat_agent_views_and_state_dict_roundtrip():
+    from cooperativeimagecaptioning_amd import models
+    from cooperativeimagecaptioning_amd.flat import FlatAgent
+    z = GU.load_case('joint_gumbel')
+    opt = GU.make_opt(GU.cfg_dict(z), 6)
+    m = models.AlternatingJointModel(opt)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    fl = FlatAgent(m.vse)
+    fl.attach()
+    assert fl.attached()
+    for p, o in zip(fl.params, fl.offsets):
+        assert p.data_ptr() == fl.flat.data_ptr() + 4 * o and o % 64 == 0
+        assert p.grad.data_ptr() == fl.grad.data_ptr() + 4 * o
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k])
+    # loading a state dict writes through the views into the flat buffer
+    sd = {k: torch.full_like(v, 0.5) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    used = sum(p.numel() for p in fl.params)
+    assert float(fl.flat.sum()) == pytest.approx(0.5 * used)
+    # writing the flat gradient buffer is visible through p.grad
+    fl.grad.fill_(2.0)
+    assert all(float(p.grad.min()) == 2.0 for p in fl.params)
+    fl.zero_grad()
+    assert all(float(p.grad.abs().max()) == 0.0 for p in fl.params)
+
+
+def test_loss_flag_logic_matches_reference():
+    from cooperativeimagecaptioning_amd import models
+    z = GU.load_case('joint_gumbel')
+    opt = GU.make_opt(GU.cfg_dict(z), 6, vse_loss_weight=0.3, caption_loss_weight=0.2)
+    m = models.AlternatingJointModel(opt)
+    assert m.getLossFlags() == [0.3, 0.2, 0.99, 0.01]
+    m.setLossFlages(VSEWeight=0, MLEWeight=1, ciderFlag=2, DISCWeight=3)
+    assert m.getLossFlags() == [0, 1, 2, 3]
+    m.changeModelUpdateStatus({'vseModel': False, 'captionModel': True})
+    assert not any(p.requires_grad for p in m.vse.parameters())
+    assert all(p.requires_grad for p in m.caption_generator.parameters())
+    # reinforce with vse_loss_weight == 0 freezes the listener at construction (AlternatingJointModel.py:95-98)
+    opt2 = GU.make_opt(GU.cfg_dict(z), 6, retrieval_reward='reinforce', vse_loss_weight=0)
+    m2 = models.AlternatingJointModel(opt2)
+    assert not any(p.requires_grad for p in m2.vse.parameters())
+
+
+def test_unsupported_configurations_fail_loudly():
+    from cooperativeimagecaptioning_amd import models
+    z = GU.load_case('joint_gumbel')
+    cfg = GU.cfg_dict(z)
+    with pytest.raises(NotImplementedError):
+        models.setup(GU.make_opt(cfg, 6), 'fc', 'caption_model')
+    with pytest.raises(NotImplementedError):
+        models.AlternatingJointModel(GU.make_opt(cfg, 6, vse_pool_type='mean'))
+    with pytest.raises(Exception):
+        models.setup(GU.make_opt(cfg, 6), 'topdown', 'caption_model')
+
+
+def test_optimizer_dict_layout_and_checkpoint_roundtrip(tmp_path):
+    """gumbel alternating mode: both agents under optimizer_dict['speaker'], the listener turn removed
+    (optimizer.py:90-95); state_dict round trip through torch.save / weights_only load."""
+    from cooperativeimagecaptioning_amd import models, optimizer as optim
+    z = GU.load_case('joint_gumbel')
+    opt = GU.make_opt(GU.cfg_dict(z), 6, is_alternating=1, learning_rate=5e-4, weight_decay=0.0,
+                      checkpoint_path=str(tmp_path), continue_from_existing_models=False)
+    m = models.AlternatingJointModel(opt)
+    od = optim.load_optimizer(m, opt)
+    assert set(od.keys()) == {'speaker'} and set(od['speaker'].keys()) == {'speaker', 'listener'}
+    assert opt.alternating_turn == ['speaker']
+    o = od['speaker']['listener']
+    fl = o.flat
+    fl.exp_avg.uniform_()
+    fl.exp_avg_sq.uniform_()
+    fl.step = 7
+    optim.save_optimizer(opt, od)
+    sd = torch.load(os.path.join(str(tmp_path), 'listener_optimizer.pth'), weights_only=True)
+    assert len(sd['state']) == len(fl.params) and sd['param_groups'][0]['lr'] == 5e-4
+    want = fl.exp_avg.clone()
+    fl.exp_avg.zero_()
+    fl.step = 0
+    o.load_state_dict(sd)
+    assert fl.step == 7
+    for p, off in zip(fl.params, fl.offsets):
+        assert torch.equal(fl.exp_avg[off:off + p.numel()], want[off:off + p.numel()])
+    # reinforce: one optimizer per turn
+    opt2 = GU.make_opt(GU.cfg_dict(z), 6, is_alternating=1, retrieval_reward='reinforce', learning_rate=5e-4,
+                       weight_decay=0.0, continue_from_existing_models=False)
+    od2 = optim.load_optimizer(models.AlternatingJointModel(opt2), opt2)
+    assert set(od2.keys()) == {'speaker', 'listener'}
+
+
+def test_schedules():
+    from cooperativeimagecaptioning_amd import train as T, models, optimizer as optim
+    z = GU.load_case('joint_gumbel')
+    opt = GU.make_opt(GU.cfg_dict(z), 6, is_alternating=1, learning_rate=4e-4, weight_decay=0.0,
+                      continue_from_existing_models=False, learning_rate_decay_start=0, learning_rate_decay_every=3,
+                      learning_rate_decay_rate=0.8, scheduled_sampling_start=-1, retrieval_reward_weight_decay_start=0,
+                      retrieval_reward_weight_decay_every=15, retrieval_reward_weight_decay_rate=0.8,
+                      softmax_cooling_decay_factor=0, gumbel_temperature_annealing_factor=0,
+                      num_iteration_for_annealing=500, scheduled_sampling_increase_every=5,
+                      scheduled_sampling_increase_prob=0.05, scheduled_sampling_max_prob=0.25)
+    m = models.AlternatingJointModel(opt)
+    od = optim.load_optimizer(m, opt)
+    T.apply_schedules(True, opt, 7, od, od['speaker'], m, 0, 0)
+    assert opt.current_lr == pytest.approx(4e-4 * 0.8 ** 2)
+    assert od['speaker']['speaker'].param_groups[0]['lr'] == pytest.approx(4e-4 * 0.8 ** 2)
+    T.apply_schedules(True, opt, 31, od, od['speaker'], m, 0, 0)
+    assert m.retrieval_reward_weight == pytest.approx(0.01 * 0.8 ** 2)
+
+
+def test_synthetic_batch_contract():
+    from cooperativeimagecaptioning_amd import synthetic
+    opt = synthetic.default_opt(batch_size=4)
+    b = synthetic.SyntheticLoader(opt).get_batch('train')
+    assert b['att_feats'].shape == (4, 36, 2048) and b['fc_feats'].shape == (4, 2048)
+    assert b['labels'].shape == (4, 18) and b['masks'].shape == (4, 18) and b['att_masks'] is None
+    assert (b['labels'][:, 0] == 0).all() and (b['labels'][:, -1] == 0).all()
+    nnz = (b['labels'] > 0).sum(1)
+    assert (b['masks'].sum(1) == nnz + 2).all() and len(b['gts']) == 4 and b['gts'][0].shape == (5, 16)
+    assert b['labels'].max() <= 9487 and b['att_feats'].min() >= 0
