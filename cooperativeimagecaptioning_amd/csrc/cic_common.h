@@ -60,13 +60,13 @@ __device__ __forceinline__ float fast_tanh(float x) {
     // tanh(x) = sign(x) * (1 - e) / (1 + e),  e = exp(-2|x|)
     float ax = fabsf(x);
     float e = __expf(-2.0f * ax);
-    float t = (1.0f - e) / (1.0f + e);
+    float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);   // v_rcp_f32: 1 ulp, no div fix-up sequence
     return copysignf(t, x);
 }
 __device__ __forceinline__ float fast_sigmoid(float x) {
     // stable on both sides: 1/(1+e^-x) for x>=0, e^x/(1+e^x) for x<0
     float e = __expf(-fabsf(x));
-    float r = 1.0f / (1.0f + e);
+    float r = __builtin_amdgcn_rcpf(1.0f + e);
     return x >= 0.0f ? r : e * r;
 }
 

@@ -18,6 +18,8 @@
 
 namespace {
 
+bool aligned16(const void* p);
+
 constexpr int BK = 32;
 constexpr int KCS = BK + 4;  // row stride of a K-contiguous LDS image (floats)
 
@@ -320,6 +322,118 @@ int launch_skinny(const cic_gemm_args& g, bool vec, hipStream_t st) {
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Register-streaming GEMM for the per-timestep products (M = batch, K-contiguous activations):
+// no LDS staging at all.  A wave (wm, ks) loads its MFMA A fragments for 32 rows x one K slice
+// straight from global memory into registers, the matching B fragments of ONE 32-column strip the
+// same way, runs the MFMA chain, and the KS partial 32x32 tiles of a strip are summed through LDS
+// (wave ks finishes accumulator register ks of the tile: 16 registers <-> 16 waves).
+// Why: at M = 128 a product is a few hundred thousand MFMAs; what matters is that every SIMD of the
+// chip gets an equal, short chain (K slice of 32..256) and that each wave issues ALL its loads up
+// front (one memory round trip per wave), not tile reuse through LDS.
+//   fragments: lane (r = lane&31, h = lane>>5) holds op[row r][8g + 4h .. +3] for group g of 8 k's,
+//   i.e. one float4 per group when the operand is K-contiguous (weights W[N,K], activations x[M,K]);
+//   a K-strided B (dX = dY W) is read as 4 row-coalesced dwords per group.
+// ---------------------------------------------------------------------------------------------
+template <int KS, bool KCB>   // waves = KS (one 32-row strip per workgroup)
+__global__ __launch_bounds__(KS * 64) void gemm_rega_kernel(cic_gemm_args g, int gps) {
+    // gps = groups (of 8 k) per K slice, a multiple of CH; processed in chunks of CH groups with a
+    // register double buffer (next chunk's loads in flight under the current chunk's MFMAs)
+    constexpr int CH = 4;
+    __shared__ float red[KS * 16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
+    const int h = lane >> 5, r = lane & 31;
+    const int tiles_n = (g.N + 31) / 32;
+    const int m0 = (blockIdx.x / tiles_n) * 32, n0 = (blockIdx.x % tiles_n) * 32;
+    const int m = m0 + r, n = n0 + r;
+    const int K1 = g.K, Kt = g.K + g.K2;
+    const bool mok = m < g.M, nok = n < g.N;
+
+    auto load_chunk = [&](f32x4 (&af)[CH], f32x4 (&bf)[CH], int c) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int k = 8 * (ks * gps + c * CH + i) + 4 * h;   // first of this lane's 4 k's (K1 % 8 == 0)
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+            if (k < Kt) {
+                const bool second = k >= K1;
+                const float* A = second ? g.A2 : g.A;
+                const float* B = second ? g.B2 : g.B;
+                const int lda = second ? g.lda2 : g.lda, ldb = second ? g.ldb2 : g.ldb;
+                const int kk = second ? k - K1 : k;
+                if (mok) a = *reinterpret_cast<const f32x4*>(A + (size_t)m * lda + kk);
+                if (nok) {
+                    // (non-temporal weight loads were measured: -45 % on these kernels, the four row strips of a
+                    //  column tile re-read the same weights through L2, and the attention kernel did not gain)
+                    if (KCB) {
+                        b = *reinterpret_cast<const f32x4*>(B + (size_t)n * ldb + kk);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) b[j] = B[(size_t)(kk + j) * ldb + n];
+                    }
+                }
+            }
+            af[i] = a;
+            bf[i] = b;
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    auto mma_chunk = [&](const f32x4 (&af)[CH], const f32x4 (&bf)[CH]) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[i][s], acc, 0, 0, 0);
+    };
+    const int nch = gps / CH;
+    f32x4 a0[CH], b0[CH], a1[CH], b1[CH];
+    load_chunk(a0, b0, 0);
+#pragma unroll 1
+    for (int c = 0; c < nch; c += 2) {
+        if (c + 1 < nch) load_chunk(a1, b1, c + 1);
+        mma_chunk(a0, b0);
+        if (c + 2 < nch) load_chunk(a0, b0, c + 2);
+        if (c + 1 < nch) mma_chunk(a1, b1);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(ks * 16 + e) * 64 + lane] = acc[e];
+    __syncthreads();
+    // wave ks sums accumulator register e = ks, ks + KS, ... over the KS partial tiles (fixed order)
+    for (int e = ks; e < 16; e += KS) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < KS; ++q) v += red[(q * 16 + e) * 64 + lane];
+        const int mm = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (mm < g.M && nok) {
+            float* c = g.C + (size_t)mm * g.ldc + n;
+            if (g.bias) v += g.bias[n];
+            if (g.accumulate) v += *c;
+            if (g.relu) v = fmaxf(v, 0.f);
+            *c = v;
+        }
+    }
+}
+
+bool rega_ok(const cic_gemm_args& g) {
+    if (!g.a_kc || g.M > 128) return false;
+    if ((g.K & 7) || (g.K2 & 7)) return false;
+    if (!aligned16(g.A) || (g.lda & 3) || !aligned16(g.B) || (g.ldb & 3)) return false;
+    if (g.K2 > 0 && (!aligned16(g.A2) || (g.lda2 & 3) || !aligned16(g.B2) || (g.ldb2 & 3))) return false;
+    return true;
+}
+
+int launch_rega(const cic_gemm_args& g, hipStream_t st) {
+    const int Kt = g.K + g.K2;
+    const int grid = cic_cdiv(g.M, 32) * cic_cdiv(g.N, 32);
+    const int groups = cic_cdiv(Kt, 8);
+    const int gps = cic_cdiv(cic_cdiv(groups, 16), 4) * 4;   // groups per K slice, multiple of the chunk size
+    if (g.b_kc) hipLaunchKernelGGL((gemm_rega_kernel<16, true>), dim3(grid), dim3(1024), 0, st, g, gps);
+    else hipLaunchKernelGGL((gemm_rega_kernel<16, false>), dim3(grid), dim3(1024), 0, st, g, gps);
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_shape(const cic_gemm_args& g, bool vec, hipStream_t st) {
     const int grid = cic_cdiv(g.M, BM) * cic_cdiv(g.N, BN);
@@ -386,6 +500,7 @@ extern "C" int cic_gemm_f32(const cic_gemm_args* a, cic_stream_t s) {
     if (g.K2 > 0)
         vec = vec && operand_vec_ok(g.A2, g.lda2, g.a_kc, g.M, g.K2) && operand_vec_ok(g.B2, g.ldb2, g.b_kc, g.N, g.K2);
     const int64_t big_tiles = (int64_t)cic_cdiv(g.M, 128) * cic_cdiv(g.N, 128);
+    if (rega_ok(g)) return launch_rega(g, cic_s(s));
     if (g.M <= 128) {
         // per-timestep products: in-workgroup split-K (see gemm_skinny_kernel)
         const int ktot = g.K + g.K2;

@@ -263,6 +263,74 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(const float* __restri
     if (tid < K) ddot_out[(size_t)b * K + tid] = alpha[(size_t)b * K + tid] * (sd[tid] - cs);
 }
 
+
+// column-owner layout of attn_bwd (see attn_fwd_cols_kernel in speaker_fwd.hip): A == H, H % 32 == 0
+template <int JMAX>
+__global__ __launch_bounds__(1024) void attn_bwd_cols_kernel(const float* __restrict__ d_att_res, const float* __restrict__ alpha,
+                                                             const float* __restrict__ att_h, const float* __restrict__ p_att,
+                                                             const float* __restrict__ att, const float* __restrict__ w_alpha,
+                                                             float* __restrict__ d_att_h, float* __restrict__ ddot_out, int K,
+                                                             int H) {
+    __shared__ float sp[16 * 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int NW = blockDim.x >> 6;
+    const int c = lane & 7, rg = lane >> 3;
+    const int H4 = H >> 2;
+    const int col4 = 8 * w + c;
+    const f32x4* pa4 = reinterpret_cast<const f32x4*>(p_att + (size_t)b * K * H);
+    const f32x4* at4 = reinterpret_cast<const f32x4*>(att + (size_t)b * K * H);
+    const f32x4 dr = reinterpret_cast<const f32x4*>(d_att_res + (size_t)b * H)[col4];
+    const f32x4 ah = reinterpret_cast<const f32x4*>(att_h + (size_t)b * H)[col4];
+    const f32x4 wa = reinterpret_cast<const f32x4*>(w_alpha)[col4];
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 pv[JMAX], av[JMAX];
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        const int k = 8 * j + rg;
+        av[j] = k < K ? at4[(size_t)k * H4 + col4] : z4;
+        pv[j] = k < K ? pa4[(size_t)k * H4 + col4] : z4;
+    }
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        float part = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part += dr[e] * av[j][e];
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        part += __shfl_xor(part, 4, 64);
+        const int k = 8 * j + rg;
+        if (c == 0 && k < K) sp[w * 64 + k] = part;
+    }
+    __syncthreads();
+    float dal = 0.f, al = 0.f;
+    if (lane < K) {
+        for (int q = 0; q < NW; ++q) dal += sp[q * 64 + lane];
+        al = alpha[(size_t)b * K + lane];
+    }
+    const float cs = wave_sum(al * dal);
+    const float dd = al * (dal - cs);                  // 0 for lanes >= K
+    if (w == 0 && lane < K) ddot_out[(size_t)b * K + lane] = dd;
+    f32x4 acc = z4;
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        const float d = __shfl(dd, 8 * j + rg, 64);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float th = fast_tanh(pv[j][e] + ah[e]);
+            acc[e] += d * (1.0f - th * th);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float v = acc[e];
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        acc[e] = v * wa[e];
+    }
+    if (rg == 0) reinterpret_cast<f32x4*>(d_att_h + (size_t)b * H)[col4] = acc;
+}
+
 // ---- feature gradients after the time loop ----------------------------------------------------
 //   d_att[b,k,:]   = sum_t alpha_t[b,k] * d_att_res_t[b,:]
 //   d_p_att[b,k,a] = w_a * sum_t ddot_t[b,k] * (1 - tanh^2(p_att[b,k,a] + att_h_t[b,a]))
@@ -485,6 +553,14 @@ extern "C" int cic_speaker_decode_bwd(const cic_speaker_dims* dp, const cic_spea
 #define GO(NI, KPW, HOLD) hipLaunchKernelGGL((attn_bwd_kernel<NI, KPW, 16, HOLD>), grid, blk, 0, st, dres, al, ah, \
                                              w.p_att, w.att, p->alpha_w, dah, ddot, K, A, H)
             void* ph = cic_prof_begin(CIC_PROF_ATTN_BWD, st);
+            if (A == H && (H & 31) == 0 && H <= 512 && K <= 64) {
+                dim3 blkc((H / 32) * 64);
+#define GOC(J) hipLaunchKernelGGL((attn_bwd_cols_kernel<J>), grid, blkc, 0, st, dres, al, ah, w.p_att, w.att, p->alpha_w, dah, \
+                                  ddot, K, H)
+                if (K <= 8) GOC(1); else if (K <= 16) GOC(2); else if (K <= 24) GOC(3); else if (K <= 32) GOC(4);
+                else if (K <= 40) GOC(5); else if (K <= 48) GOC(6); else GOC(8);
+#undef GOC
+            } else
             if (mx <= 256) { if (K <= 48) GO(1, 3, true); else GO(1, 4, true); }
             else if (mx <= 512) { if (K <= 48) GO(2, 3, true); else GO(2, 4, true); }
             else GO(4, 4, false);

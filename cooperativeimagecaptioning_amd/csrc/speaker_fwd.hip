@@ -138,6 +138,94 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const float* __restri
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// K3 attention step, column-owner layout (A == H, H % 32 == 0, the shapes the model uses).
+// One workgroup per image, NW = H/32 waves (16 for H = 512).  Wave w owns the 32 columns
+// [32w, 32w+32) of every region row; lane = (rg = lane>>3 region sub-index, c = lane&7 float4 column),
+// so ONE wave load instruction reads 8 regions x 128 B (whole cache lines) and all loads of the
+// wave (<= 2*JMAX float4 per lane) are issued before the first use.
+//   phase 1: per-lane 4-column partial of w.tanh(p+ah), 3 xor-shuffles over c -> partial dot of
+//            (wave, region) -> LDS [NW][K];  ONE workgroup barrier
+//   phase 2: every wave redundantly sums the NW partials of region k in lane k and does the
+//            36-way softmax with wave shuffles (no second barrier, no LDS broadcast)
+//   phase 3: alpha-weighted sum of the att values still held in registers, 3 xor-shuffles over
+//            rg -> lanes 0..7 store the wave's 32 output columns (one 128-B line)
+// No cross-wave vector reduction at all.
+// ---------------------------------------------------------------------------------------------
+template <int JMAX>   // region groups of 8: K <= 8*JMAX
+__global__ __launch_bounds__(1024) void attn_fwd_cols_kernel(const float* __restrict__ att_h, const float* __restrict__ p_att,
+                                                             const float* __restrict__ att, const float* __restrict__ w_alpha,
+                                                             const float* __restrict__ b_alpha, const float* __restrict__ masks,
+                                                             float* __restrict__ att_res, float* __restrict__ alpha_out,
+                                                             float* __restrict__ dot_out, int K, int H) {
+    __shared__ float sp[16 * 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int NW = blockDim.x >> 6;
+    const int c = lane & 7, rg = lane >> 3;
+    const int H4 = H >> 2;
+    const int col4 = 8 * w + c;                         // this lane's float4 column
+    const f32x4* pa4 = reinterpret_cast<const f32x4*>(p_att + (size_t)b * K * H);
+    const f32x4* at4 = reinterpret_cast<const f32x4*>(att + (size_t)b * K * H);
+    const f32x4 ah = reinterpret_cast<const f32x4*>(att_h + (size_t)b * H)[col4];
+    const f32x4 wa = reinterpret_cast<const f32x4*>(w_alpha)[col4];
+    f32x4 pv[JMAX], av[JMAX];
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        const int k = 8 * j + rg;
+        pv[j] = k < K ? pa4[(size_t)k * H4 + col4] : z4;
+        av[j] = k < K ? at4[(size_t)k * H4 + col4] : z4;
+    }
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        float part = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part += wa[e] * fast_tanh(pv[j][e] + ah[e]);
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        part += __shfl_xor(part, 4, 64);
+        const int k = 8 * j + rg;
+        if (c == 0 && k < K) sp[w * 64 + k] = part;
+    }
+    __syncthreads();
+    // lane k: full dot of region k, then softmax across lanes (every wave does the same arithmetic)
+    float dot = -INFINITY;
+    if (lane < K) {
+        float s = 0.f;
+        for (int q = 0; q < NW; ++q) s += sp[q * 64 + lane];
+        dot = s + b_alpha[0];
+    }
+    const float mx = wave_max(dot);
+    float ex = lane < K ? __expf(dot - mx) : 0.f;
+    const float sum = wave_sum(ex);
+    float al = ex * (1.0f / sum);
+    if (masks) {   // weight = weight * mask; weight /= weight.sum()   (AttModel.py:481-483)
+        al = lane < K ? al * masks[(size_t)b * K + lane] : 0.f;
+        const float ms = wave_sum(al);
+        al = al * (1.0f / ms);
+    }
+    if (w == 0 && lane < K) {
+        alpha_out[(size_t)b * K + lane] = al;
+        if (dot_out) dot_out[(size_t)b * K + lane] = dot;
+    }
+    f32x4 acc = z4;
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        const float a = __shfl(al, 8 * j + rg, 64);      // lanes >= K hold 0
+        acc += a * av[j];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float v = acc[e];
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        acc[e] = v;
+    }
+    if (rg == 0) reinterpret_cast<f32x4*>(att_res + (size_t)b * H)[col4] = acc;
+}
+
 // ---------------------------------------------------------------------------------------
 // K4 cell pointwise  (Att2in2Core.forward, models/AttModel.py:515-529)
 //   pre[b, 0:5H] = i2h(x)+h2h(h) with a2c(att_res) already added to [3H:5H]
@@ -449,6 +537,16 @@ extern "C" int cic_attn_fwd(const float* att_h, const float* p_att, const float*
     CIC_REQUIRE(mx <= 1024);
     dim3 grid(B);
     hipStream_t st = cic_s(s);
+    if (A == H && (H & 31) == 0 && H <= 512 && K <= 64) {   // column-owner kernel (one barrier, no vector reduce)
+        dim3 blk((H / 32) * 64);
+#define GOC(J) hipLaunchKernelGGL((attn_fwd_cols_kernel<J>), grid, blk, 0, st, att_h, p_att, att, w_alpha, b_alpha, masks, \
+                                  att_res, alpha, dot, K, H)
+        if (K <= 8) GOC(1); else if (K <= 16) GOC(2); else if (K <= 24) GOC(3); else if (K <= 32) GOC(4);
+        else if (K <= 40) GOC(5); else if (K <= 48) GOC(6); else GOC(8);
+#undef GOC
+        CIC_LAUNCH_CHECK();
+        return 0;
+    }
     // 16 waves per image: each wave owns <= 4 regions, whose p_att and att rows are all in flight at once
 #define GO(NI, KPW, HOLD)                                                                                        \
     hipLaunchKernelGGL((attn_fwd_kernel<NI, KPW, 16, HOLD>), grid, dim3(1024), 0, st, att_h, p_att, att, w_alpha, \

@@ -43,6 +43,10 @@ int cic_prof_enable(int on);
 int cic_prof_reset(void);
 int cic_prof_collect(int id, double* total_ms, int* launches);
 
+/* diagnostics: shader clock in MHz (out2[0]) measured over `spin` dependent FMAs; an empty launch */
+int cic_debug_clock_mhz(float* out2, int spin, cic_stream_t s);
+int cic_debug_empty(int grid, int block, cic_stream_t s);
+
 /* ---- RNG (replaces torch.rand / nn.Dropout's bernoulli_ draws) ---------------------- */
 /* Philox4x32-10 counter RNG.  u[i] = (r >> 8) * 2^-24 in [0,1), as torch.rand does
  * (models/gumbel.py:6-11).  Element i uses counter (offset + i/4), lane i%4. */
