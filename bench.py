@@ -95,6 +95,30 @@ def cpu_baseline(opt, steps_budget_s=20.0):
                        f'workload on the CPU oracle, {steady * 1e3:.0f} ms/step')
 
 
+def attention_launch_time(model, batch, stream, iters=200):
+    """Average duration of one attention launch (cic_attn_fwd) on the tensors the step just used
+    (att / p_att of the sampled decode's workspace geometry), HIP events on the step's stream."""
+    from cooperativeimagecaptioning_amd import ops
+    cg = model.caption_generator
+    B, K, H = batch['att_feats'].shape[0], batch['att_feats'].shape[1], cg.rnn_size
+    dev = batch['att_feats'].device
+    att = cg._buf.get('att_pre', (B, K, H), torch.float32, dev)
+    p_att = torch.randn(B, K, H, device=dev)
+    att_h = torch.randn(B, H, device=dev)
+    w = cg.core.attention.alpha_net.weight.data.view(-1)
+    ba = cg.core.attention.alpha_net.bias.data
+    res, al, dot = torch.empty(B, H, device=dev), torch.empty(B, K, device=dev), torch.empty(B, K, device=dev)
+    for _ in range(10):
+        ops.attn_fwd(att_h, p_att, att, w, ba, None, res, al, dot)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(iters):
+        ops.attn_fwd(att_h, p_att, att, w, ba, None, res, al, dot)
+    e1.record(stream)
+    e1.synchronize()
+    return {'attn_fwd': dict(ms=e0.elapsed_time(e1), n=iters)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -103,6 +127,9 @@ def main():
     ap.add_argument('--batch', type=int, default=128)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    ap.add_argument('--graphs', action='store_true',
+                    help='run on a side stream and replay the sequence engines as HIP graphs (measured SLOWER on '
+                         'this stack: 9.5 vs 8.2 ms/step; the default is direct launches on the default stream)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -145,18 +172,22 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        loss = step()
-    engine.prof_reset()
-    engine.prof_enable(True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    engine.prof_enable(False)
-    prof = engine.prof_collect()
+    # --graphs: the whole step runs on one non-default HIP stream and the sequence engines are captured
+    # into HIP graphs on their first call and replayed afterwards (one launch per decode / listener pass)
+    stream = torch.cuda.Stream(device=dev) if args.graphs else torch.cuda.current_stream(dev)
+    engine.graph_enable(args.graphs)
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            loss = step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        barrier()
+        dt = time.perf_counter() - t0
+        # roofline leg: the attention kernel on the step's own tensors, timed with HIP events on this stream
+        prof = attention_launch_time(model, batch, stream)
+    gstats = engine.graph_stats()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -177,7 +208,7 @@ def main():
                                    'tau=1 + self-critical CIDEr-D, 36x2048 att_feats, vocab 9487, seq_len 16, '
                                    'dropout 0.5, clamp 0.1 + Adam both agents (BASELINE configs[2])',
                        'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': f'dp{world}',
-                       'final_loss': final_loss},
+                       'final_loss': final_loss, 'hip_graphs': gstats},
             'roofline': {'bound': 'hbm', 'kernel': 'attn_fwd_kernel (per-timestep top-down attention)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': None, 'avg_launch_us': attn_us, 'launches_timed': attn['n'],

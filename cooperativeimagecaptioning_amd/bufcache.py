@@ -1,0 +1,28 @@
+"""Persistent device buffers keyed by role and shape.
+
+The sequence engines are replayed as HIP graphs keyed on every pointer they receive, so the host keeps
+inputs, outputs and noise at stable addresses: a batch is copied into a staging buffer, outputs are
+written into the same tensors every step."""
+import torch
+
+
+class BufCache:
+    def __init__(self):
+        self._b = {}
+
+    def get(self, key, shape, dtype, device, fill=None):
+        k = (key, tuple(shape), dtype, str(device))
+        t = self._b.get(k)
+        if t is None:
+            t = torch.empty(shape, dtype=dtype, device=device)
+            if fill is not None:
+                t.fill_(fill)
+            self._b[k] = t
+        return t
+
+    def stage(self, key, src, dtype=None):
+        """Copy `src` into the persistent buffer of its role (same shape) and return that buffer."""
+        dtype = dtype or src.dtype
+        t = self.get(key, src.shape, dtype, src.device)
+        t.copy_(src)
+        return t

@@ -40,6 +40,17 @@ void cic_prof_end(void* h, hipStream_t st);
         cic_prof_end(ph_, (st));                 \
     } while (0)
 
+// ---- HIP graph capture/replay of an engine call (core.hip) ---------------------------------------
+uint64_t cic_hash_bytes(const void* p, size_t n, uint64_t h);
+struct CicGraphScope {
+    hipStream_t st;
+    uint64_t key;
+    bool capturing = false;
+    bool replayed = false;
+    CicGraphScope(hipStream_t s, uint64_t k);   // replays a cached graph if there is one, else begins capture
+    int finish(int rc);                         // ends capture, instantiates, caches and launches
+};
+
 static inline hipStream_t cic_s(cic_stream_t s) { return (hipStream_t)s; }
 static inline int cic_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -65,6 +65,82 @@ extern "C" int cic_prof_collect(int id, double* total_ms, int* launches) {
     return 0;
 }
 
+// ---- HIP graph cache ---------------------------------------------------------------------------------
+#include <unordered_map>
+namespace {
+bool g_graph_on = false;
+std::unordered_map<uint64_t, hipGraphExec_t> g_graphs;
+int64_t g_graph_stats[3] = {0, 0, 0};   // captures, replays, fallbacks
+}  // namespace
+
+uint64_t cic_hash_bytes(const void* p, size_t n, uint64_t h) {
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }   // FNV-1a
+    return h;
+}
+
+CicGraphScope::CicGraphScope(hipStream_t s, uint64_t k) : st(s), key(k) {
+    if (!g_graph_on || g_prof_on) return;
+    auto it = g_graphs.find(key);
+    if (it != g_graphs.end()) {
+        if (hipGraphLaunch(it->second, st) == hipSuccess) {
+            replayed = true;
+            ++g_graph_stats[1];
+            return;
+        }
+        (void)hipGetLastError();
+    }
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        capturing = true;
+    } else {
+        (void)hipGetLastError();   // e.g. the legacy default stream: run the launches directly
+        ++g_graph_stats[2];
+    }
+}
+
+int CicGraphScope::finish(int rc) {
+    if (!capturing) return rc;
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamEndCapture(st, &graph);
+    capturing = false;
+    if (e != hipSuccess || graph == nullptr) {
+        (void)hipGetLastError();
+        cic_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        return rc ? rc : 2;
+    }
+    if (rc != 0) {   // an engine error during capture: nothing was launched
+        (void)hipGraphDestroy(graph);
+        return rc;
+    }
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+        cic_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+        return 2;
+    }
+    if (g_graphs.size() >= 64) {   // bounded cache: drop everything rather than track recency
+        for (auto& kv : g_graphs) (void)hipGraphExecDestroy(kv.second);
+        g_graphs.clear();
+    }
+    g_graphs[key] = exec;
+    ++g_graph_stats[0];
+    CIC_HIP(hipGraphLaunch(exec, st));
+    return 0;
+}
+
+extern "C" int cic_graph_enable(int on) { g_graph_on = on != 0; return 0; }
+extern "C" int cic_graph_clear(void) {
+    for (auto& kv : g_graphs) (void)hipGraphExecDestroy(kv.second);
+    g_graphs.clear();
+    return 0;
+}
+extern "C" int cic_graph_stats(int64_t* out3) {
+    CIC_REQUIRE(out3);
+    for (int i = 0; i < 3; ++i) out3[i] = g_graph_stats[i];
+    return 0;
+}
+
 namespace {
 
 __global__ __launch_bounds__(256) void uniform_kernel(float* __restrict__ out, int64_t n, uint64_t seed,

@@ -334,8 +334,43 @@ extern "C" size_t cic_listener_ws_bytes(const cic_listener_dims* d) {
     return lst_carve(*d, nullptr).bytes;
 }
 
+static int listener_fwd_impl(const cic_listener_dims* dp, const cic_listener_params* p, const cic_listener_io* io,
+                             void* ws, size_t ws_bytes, cic_stream_t s);
+static int listener_bwd_impl(const cic_listener_dims* dp, const cic_listener_params* p, const cic_listener_io* io,
+                             const cic_listener_bwd_io* bio, void* ws, size_t ws_bytes, cic_stream_t s);
+
 extern "C" int cic_listener_fwd(const cic_listener_dims* dp, const cic_listener_params* p, const cic_listener_io* io,
                                 void* ws, size_t ws_bytes, cic_stream_t s) {
+    CIC_REQUIRE(dp && p && io && ws);
+    uint64_t key = cic_hash_bytes("listener_fwd", 12, 1469598103934665603ull);
+    key = cic_hash_bytes(dp, sizeof(*dp), key);
+    key = cic_hash_bytes(p, sizeof(*p), key);
+    key = cic_hash_bytes(io, sizeof(*io), key);
+    key = cic_hash_bytes(&ws, sizeof(ws), key);
+    CicGraphScope gs(cic_s(s), key);
+    if (gs.replayed) return 0;
+    return gs.finish(listener_fwd_impl(dp, p, io, ws, ws_bytes, s));
+}
+
+extern "C" int cic_listener_bwd(const cic_listener_dims* dp, const cic_listener_params* p, const cic_listener_io* io,
+                                const cic_listener_bwd_io* bio, void* ws, size_t ws_bytes, cic_stream_t s) {
+    CIC_REQUIRE(dp && p && io && bio && ws);
+    uint64_t key = cic_hash_bytes("listener_bwd", 12, 1469598103934665603ull);
+    key = cic_hash_bytes(dp, sizeof(*dp), key);
+    key = cic_hash_bytes(p, sizeof(*p), key);
+    key = cic_hash_bytes(io, sizeof(*io), key);
+    key = cic_hash_bytes(&bio->g_rows, sizeof(void*), key);
+    key = cic_hash_bytes(&bio->g_scalar, sizeof(void*), key);
+    if (bio->grads) key = cic_hash_bytes(bio->grads, sizeof(*bio->grads), key);
+    key = cic_hash_bytes(&bio->d_onehot, sizeof(void*), key);
+    key = cic_hash_bytes(&ws, sizeof(ws), key);
+    CicGraphScope gs(cic_s(s), key);
+    if (gs.replayed) return 0;
+    return gs.finish(listener_bwd_impl(dp, p, io, bio, ws, ws_bytes, s));
+}
+
+static int listener_fwd_impl(const cic_listener_dims* dp, const cic_listener_params* p, const cic_listener_io* io,
+                             void* ws, size_t ws_bytes, cic_stream_t s) {
     CIC_REQUIRE(dp && p && io && ws);
     const cic_listener_dims& d = *dp;
     if (int rc = check_ldims(d)) return rc;
@@ -394,8 +429,8 @@ extern "C" int cic_listener_fwd(const cic_listener_dims* dp, const cic_listener_
     return 0;
 }
 
-extern "C" int cic_listener_bwd(const cic_listener_dims* dp, const cic_listener_params* p, const cic_listener_io* io,
-                                const cic_listener_bwd_io* bio, void* ws, size_t ws_bytes, cic_stream_t s) {
+static int listener_bwd_impl(const cic_listener_dims* dp, const cic_listener_params* p, const cic_listener_io* io,
+                             const cic_listener_bwd_io* bio, void* ws, size_t ws_bytes, cic_stream_t s) {
     CIC_REQUIRE(dp && p && io && bio && ws);
     const cic_listener_dims& d = *dp;
     if (int rc = check_ldims(d)) return rc;

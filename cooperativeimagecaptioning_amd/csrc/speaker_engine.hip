@@ -80,8 +80,24 @@ extern "C" int cic_speaker_att_embed_fwd(const cic_speaker_dims* dp, const cic_s
                    true, cic_s(s));
 }
 
+static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params* p, const cic_decode_io* io, void* ws,
+                           size_t ws_bytes, cic_stream_t s);
+
 extern "C" int cic_speaker_decode_fwd(const cic_speaker_dims* dp, const cic_speaker_params* p,
                                       const cic_decode_io* io, void* ws, size_t ws_bytes, cic_stream_t s) {
+    CIC_REQUIRE(dp && p && io && ws);
+    uint64_t key = cic_hash_bytes("decode_fwd", 10, 1469598103934665603ull);
+    key = cic_hash_bytes(dp, sizeof(*dp), key);
+    key = cic_hash_bytes(p, sizeof(*p), key);
+    key = cic_hash_bytes(io, sizeof(*io), key);
+    key = cic_hash_bytes(&ws, sizeof(ws), key);
+    CicGraphScope gs(cic_s(s), key);
+    if (gs.replayed) return 0;
+    return gs.finish(decode_fwd_impl(dp, p, io, ws, ws_bytes, s));
+}
+
+static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params* p, const cic_decode_io* io, void* ws,
+                           size_t ws_bytes, cic_stream_t s) {
     CIC_REQUIRE(dp && p && io && ws);
     const cic_speaker_dims& d = *dp;
     if (int rc = check_dims(d)) return rc;

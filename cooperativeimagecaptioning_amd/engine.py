@@ -81,16 +81,18 @@ def speaker_att_embed_fwd(dims, params, att_raw, att_pre=None):
 
 def speaker_decode_fwd(dims, params, att_pre, mode, temp=1.0, att_masks=None, att_keep=None, x_keep=None,
                        out_keep=None, U=None, pick=None, decoding_constraint=0, want_stv=False, ws=None,
-                       first_token=None):
+                       first_token=None, out=None):
     """-> dict(seq i32[B,T], slp f32[B,T], stv f32[B,T]|None, L i32[1], ws)."""
     dev = att_pre.device
     B, T = dims.B, dims.T
     nbytes = lib.cic_speaker_decode_ws_bytes(C.byref(dims))
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    out = dict(seq=torch.zeros(B, T, dtype=torch.int32, device=dev), slp=torch.zeros(B, T, device=dev),
-               stv=torch.ones(B, T, device=dev) if want_stv else None,
-               L=torch.zeros(1, dtype=torch.int32, device=dev), ws=ws)
+    if out is None:   # callers that replay HIP graphs pass the same output buffers every step
+        out = dict(seq=torch.zeros(B, T, dtype=torch.int32, device=dev), slp=torch.zeros(B, T, device=dev),
+                   stv=torch.ones(B, T, device=dev) if want_stv else None,
+                   L=torch.zeros(1, dtype=torch.int32, device=dev))
+    out['ws'] = ws
     io = DecodeIO()
     io.mode, io.temp, io.decoding_constraint = mode, float(temp), int(decoding_constraint)
     io.att_pre, io.att_masks = _p(att_pre), _p(att_masks)
@@ -137,15 +139,17 @@ def listener_params(tensors):
 
 
 def listener_fwd(dims, params, fc_feats, labels=None, masks=None, seq=None, stv=None, L=None,
-                 only_one_retrieval='off', want_emb=False, ws=None):
+                 only_one_retrieval='off', want_emb=False, ws=None, out=None):
     """-> dict(loss_rows f32[B], loss_sum f32[1], img_emb, cap_emb, ws, io)."""
     dev = fc_feats.device
     nbytes = lib.cic_listener_ws_bytes(C.byref(dims))
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    out = dict(loss_rows=torch.empty(dims.B, device=dev), loss_sum=torch.empty(1, device=dev), ws=ws,
-               img_emb=torch.empty(dims.B, dims.J, device=dev) if want_emb else None,
-               cap_emb=torch.empty(dims.B, dims.J, device=dev) if want_emb else None)
+    if out is None:
+        out = dict(loss_rows=torch.empty(dims.B, device=dev), loss_sum=torch.empty(1, device=dev),
+                   img_emb=torch.empty(dims.B, dims.J, device=dev) if want_emb else None,
+                   cap_emb=torch.empty(dims.B, dims.J, device=dev) if want_emb else None)
+    out['ws'] = ws
     io = ListenerIO()
     io.fc_feats, io.labels, io.masks = _p(fc_feats), _p(labels), _p(masks)
     io.seq, io.stv, io.L = _p(seq), _p(stv), _p(L)
@@ -255,3 +259,22 @@ def prof_collect():
         check(lib.cic_prof_collect(i, C.byref(ms), C.byref(n)), 'cic_prof_collect')
         out[name] = dict(ms=ms.value, n=n.value)
     return out
+
+
+lib.cic_graph_enable.argtypes = [C.c_int]
+lib.cic_graph_stats.argtypes = [C.POINTER(C.c_int64)]
+
+
+def graph_enable(on):
+    """Capture/replay the sequence engines as HIP graphs (needs a non-default stream and stable buffers)."""
+    check(lib.cic_graph_enable(int(bool(on))), 'cic_graph_enable')
+
+
+def graph_clear():
+    check(lib.cic_graph_clear(), 'cic_graph_clear')
+
+
+def graph_stats():
+    a = (C.c_int64 * 3)()
+    check(lib.cic_graph_stats(a), 'cic_graph_stats')
+    return dict(captures=a[0], replays=a[1], fallbacks=a[2])

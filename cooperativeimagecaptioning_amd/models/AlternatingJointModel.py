@@ -129,7 +129,7 @@ class AlternatingJointModel(nn.Module):
             mle = cg.decode(att_feats, att_masks, 'multinomial', 1.0, att_pre=att_pre, grad=True, T=Tm,
                             pick=seq.t().contiguous().long(), first_token=seq[:, 0].contiguous().long(), tag='mle',
                             decoding_constraint=0, want_stv=False)
-            d_mle = torch.empty(B, Tm, device=dev)
+            d_mle = cg._buf.get('d_mle', (B, Tm), torch.float32, dev)
             l_mle = engine.masked_nll(mle.slp, masks.float()[:, 1:], cw, dslp=d_mle)
             cg._loss['xe'] = l_mle.detach()[0]
             self._loss['loss_cap'] = l_mle.detach()[0]
@@ -161,7 +161,7 @@ class AlternatingJointModel(nn.Module):
                 else:                                                  # :312-319
                     base = torch.zeros(B, device=dev)
                 coef = (gen.loss_rows - base).contiguous()
-                dslp = torch.zeros(B, T, device=dev)
+                dslp = cg._buf.get('dslp', (B, T), torch.float32, dev)
                 sc = engine.seq_loss(sample.slp, sample.seq, sample.L, coef, 1.0, dw, dslp=dslp)   # :321-325
                 terms.append((dw, sc))
                 self._loss['retrieval_sc_loss'] = sc.detach()[0]
@@ -174,7 +174,7 @@ class AlternatingJointModel(nn.Module):
                 gen = vse.run(fc_feats, decode=sample, only_one_retrieval=oor, slot=2)
                 vse._loss['contrastive'] = gen.loss_sum.detach()[0]
                 terms.append((dw, gen.loss_sum))
-                d_onehot = torch.empty(T, B, cg.vocab_size + 1, device=dev) if spk_grad else None
+                d_onehot = cg._buf.get('d_onehot', (T, B, cg.vocab_size + 1), torch.float32, dev) if spk_grad else None
 
                 def bwd_listener(go, gen=gen, d_onehot=d_onehot):
                     vse.run_backward(gen, g_scalar=(go * dw).reshape(1).contiguous(), param_grads=lst_grad,
@@ -193,9 +193,10 @@ class AlternatingJointModel(nn.Module):
             refs, ref_off = self._refs(data, dev)
             rw = rewards.get_self_critical_reward_device(refs, ref_off, sample, greedy)
             coef = rw['scores'][:B].float().contiguous() if self.use_gen_cider_scores else rw['reward']
-            if dslp is None:
-                dslp = torch.zeros(B, T, device=dev)
-            lc = engine.seq_loss(sample.slp, sample.seq, sample.L, coef, -1.0, ciw, dslp=dslp, accumulate=True)
+            fresh = dslp is None
+            if fresh:
+                dslp = cg._buf.get('dslp', (B, T), torch.float32, dev)
+            lc = engine.seq_loss(sample.slp, sample.seq, sample.L, coef, -1.0, ciw, dslp=dslp, accumulate=not fresh)
             terms.append((ciw, lc))
             self._loss['avg_reward'] = coef.mean().detach()
             self._loss['cider_greedy'] = rw['stats'][1].detach()

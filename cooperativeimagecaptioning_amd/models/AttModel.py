@@ -12,6 +12,7 @@ import torch.nn as nn
 from .. import _lib, engine
 from ..flat import FlatAgent
 from ..noise import NoiseSource
+from ..bufcache import BufCache
 from ..autograd_glue import EngineLoss
 
 
@@ -91,6 +92,7 @@ class AttModel(nn.Module):
         self._flat = None
         self.noise = NoiseSource()
         self._ws = {}
+        self._buf = BufCache()
 
     # ---- engine plumbing -----------------------------------------------------------------
     def flat(self):
@@ -117,7 +119,10 @@ class AttModel(nn.Module):
         B, K, _ = att_feats.shape
         dims = self._dims(B, K, self.seq_length)
         params = engine.speaker_params(fl.tensors())
-        return engine.speaker_att_embed_fwd(dims, params, att_feats.contiguous().float())
+        att_raw = self._buf.stage('att_raw', att_feats, torch.float32)
+        self._staged_att = att_feats          # the decodes of this step reuse the staged copy
+        att_pre = self._buf.get('att_pre', (B, K, self.rnn_size), torch.float32, att_raw.device)
+        return engine.speaker_att_embed_fwd(dims, params, att_raw, att_pre)
 
     def decode(self, att_feats, att_masks, mode, temp=1.0, att_pre=None, grad=False, T=None, pick=None,
                first_token=None, decoding_constraint=None, tag='sample', want_stv=None):
@@ -128,9 +133,14 @@ class AttModel(nn.Module):
         T = T or self.seq_length
         dims = self._dims(B, K, T)
         params = engine.speaker_params(fl.tensors())
-        att_raw = att_feats.contiguous().float()
+        if att_pre is not None and getattr(self, '_staged_att', None) is att_feats:
+            att_raw = self._buf.get('att_raw', att_feats.shape, torch.float32, att_feats.device)   # staged by att_embed_pre
+        else:
+            att_raw = self._buf.stage('att_raw', att_feats, torch.float32)
+            self._staged_att = None
         if att_pre is None:
-            att_pre = engine.speaker_att_embed_fwd(dims, params, att_raw)
+            att_pre = engine.speaker_att_embed_fwd(dims, params, att_raw,
+                                                   self._buf.get('att_pre', (B, K, self.rnn_size), torch.float32, att_raw.device))
         p = self.drop_prob_lm if self.training else 0.0
         dims.p_drop = p
         nz = self.noise.decode_noise(tag, B, K, self.rnn_size, self.input_encoding_size, self.vocab_size + 1, T, p,
@@ -142,16 +152,28 @@ class AttModel(nn.Module):
             want_stv = mode in ('gumbel', 'multinomial_st')
         # a decode whose activations must survive until backward() gets its own workspace
         ws_key = (tag, B, K, T, grad)
-        fwd = engine.speaker_decode_fwd(dims, params, att_pre, MODES[mode], temp,
-                                        att_masks.contiguous().float() if att_masks is not None else None,
+        dev = att_raw.device
+        out = dict(seq=self._buf.get((ws_key, 'seq'), (B, T), torch.int32, dev, fill=0),
+                   slp=self._buf.get((ws_key, 'slp'), (B, T), torch.float32, dev, fill=0),
+                   stv=self._buf.get((ws_key, 'stv'), (B, T), torch.float32, dev, fill=1) if want_stv else None,
+                   L=self._buf.get((ws_key, 'L'), (1,), torch.int32, dev, fill=0))
+        if att_masks is not None:
+            att_masks = self._buf.stage('att_masks', att_masks, torch.float32)
+        if pick is not None:
+            pick = self._buf.stage((tag, 'pick'), pick.contiguous(), torch.int64)
+        if first_token is not None:
+            first_token = self._buf.stage((tag, 'first'), first_token.contiguous(), torch.int64)
+        fwd = engine.speaker_decode_fwd(dims, params, att_pre, MODES[mode], temp, att_masks,
                                         nz.get('att_keep'), nz.get('x_keep'), nz.get('out_keep'), nz.get('gumbel_u'),
                                         pick, self.decoding_constraint if decoding_constraint is None else decoding_constraint,
-                                        want_stv=want_stv, ws=self._ws.get(ws_key), first_token=first_token)
+                                        want_stv=want_stv, ws=self._ws.get(ws_key), first_token=first_token, out=out)
         self._ws[ws_key] = fwd['ws']
         return DecodeResult(fwd, mode, dims, params, att_raw, grad)
 
     def decode_backward(self, res, d_onehot=None, dslp=None):
         fl = self.flat()
+        if dslp is not None:   # stable address for the HIP-graph key
+            dslp = self._buf.stage(('dslp_in', res.dims.T), dslp.contiguous(), torch.float32)
         key = ('bwd', res.dims.B, res.dims.K, res.dims.T)
         self._ws[key] = engine.speaker_decode_bwd(res.dims, res.params, res.fwd, fl.grad_tensors(), res.att_raw,
                                                   d_onehot=d_onehot, dslp=dslp, ws_bwd=self._ws.get(key))
@@ -205,10 +227,11 @@ class AttModel(nn.Module):
                              'torch.cat of an empty list, AttModel.py:446)')
         seq = res.seq[:, :L].long()
         slp = res.slp[:, :L].clone()
+        stv = res.stv[:, :L].clone() if res.stv is not None else None
         if sample_max or plain:
             return seq, slp
         one_hot = torch.zeros(seq.shape[0], L, self.vocab_size + 2, device=seq.device)
-        one_hot.scatter_(2, seq.unsqueeze(2), res.stv[:, :L].unsqueeze(2))
+        one_hot.scatter_(2, seq.unsqueeze(2), stv.unsqueeze(2))
         return seq, one_hot, slp
 
 

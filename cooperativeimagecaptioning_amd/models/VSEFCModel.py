@@ -7,6 +7,7 @@ import torch.nn as nn
 from .. import _lib, engine
 from ..flat import FlatAgent
 from ..autograd_glue import EngineLoss
+from ..bufcache import BufCache
 
 
 class EncoderImage(nn.Module):
@@ -81,6 +82,7 @@ class VSEFCModel(nn.Module):
         self._loss = {}
         self._flat = None
         self._ws = {}
+        self._buf = BufCache()
         self._n = 0
 
     def flat(self):
@@ -104,26 +106,39 @@ class VSEFCModel(nn.Module):
         fl = self.flat()
         B = fc_feats.shape[0]
         params = engine.listener_params(fl.tensors())
-        fc = fc_feats.contiguous().float()
+        fc = self._buf.stage('fc', fc_feats, torch.float32)
+        dev = fc.device
+
+        def outs(key, J):
+            return dict(loss_rows=self._buf.get((key, 'rows'), (B,), torch.float32, dev),
+                        loss_sum=self._buf.get((key, 'sum'), (1,), torch.float32, dev),
+                        img_emb=self._buf.get((key, 'img'), (B, J), torch.float32, dev) if want_emb else None,
+                        cap_emb=self._buf.get((key, 'cap'), (B, J), torch.float32, dev) if want_emb else None)
         if decode is not None:
             dims = self._dims(B, self.seq_length + 1)
             key = ('gen', B, slot)
             fwd = engine.listener_fwd(dims, params, fc, seq=decode.seq, stv=decode.stv, L=decode.L,
-                                      only_one_retrieval=only_one_retrieval, want_emb=want_emb, ws=self._ws.get(key))
+                                      only_one_retrieval=only_one_retrieval, want_emb=want_emb, ws=self._ws.get(key),
+                                      out=outs(key, dims.J))
         else:
             if labels.dim() > 2:
                 raise NotImplementedError('dense one-hot / soft caption input (VSEFCModel.py:102-104) is only '
                                           'supported through the joint model (straight-through token + value)')
             dims = self._dims(B, labels.shape[1])
             key = ('lab', B, labels.shape[1], slot)
-            fwd = engine.listener_fwd(dims, params, fc, labels=labels.contiguous().long(),
-                                      masks=masks.contiguous().float(), only_one_retrieval=only_one_retrieval,
-                                      want_emb=want_emb, ws=self._ws.get(key))
+            fwd = engine.listener_fwd(dims, params, fc, labels=self._buf.stage((key, 'labels'), labels, torch.int64),
+                                      masks=self._buf.stage((key, 'masks'), masks, torch.float32),
+                                      only_one_retrieval=only_one_retrieval, want_emb=want_emb, ws=self._ws.get(key),
+                                      out=outs(key, dims.J))
         self._ws[key] = fwd['ws']
         return ListenerResult(fwd, dims, params)
 
     def run_backward(self, res, g_scalar=None, g_rows=None, param_grads=True, d_onehot=None):
         fl = self.flat()
+        if g_scalar is not None:   # stable addresses for the HIP-graph key
+            g_scalar = self._buf.stage('g_scalar', g_scalar.reshape(1), torch.float32)
+        if g_rows is not None:
+            g_rows = self._buf.stage('g_rows', g_rows.contiguous(), torch.float32)
         engine.listener_bwd(res.dims, res.params, res.fwd, g_rows=g_rows, g_scalar=g_scalar,
                             grads=fl.grad_tensors() if param_grads else None, d_onehot=d_onehot)
 

@@ -16,6 +16,7 @@ class NoiseSource:
         self.seed = int(seed)
         self.counter = 0          # Philox offset in units of 2^32 calls: one fresh sub-stream per tensor
         self.override = None      # {tag: {att_keep,x_keep,out_keep,gumbel_u,pick}} numpy/torch arrays
+        self._buf = {}            # persistent device buffers (stable addresses for HIP-graph replay)
 
     def manual_seed(self, seed):
         self.seed, self.counter = int(seed), 0
@@ -23,6 +24,13 @@ class NoiseSource:
     def _next_offset(self):
         self.counter += 1
         return self.counter << 32
+
+    def _get(self, key, shape, dtype, device):
+        k = (key, tuple(shape), dtype, str(device))
+        t = self._buf.get(k)
+        if t is None:
+            t = self._buf[k] = torch.empty(shape, dtype=dtype, device=device)
+        return t
 
     def decode_noise(self, tag, B, K, H, E, V1, T, p, need_u, device):
         if self.override is not None:
@@ -47,11 +55,11 @@ class NoiseSource:
         out = {}
         if p > 0.0:
             for key, shape in (('att_keep', (B, K, H)), ('x_keep', (T + 1, B, E)), ('out_keep', (T + 1, B, H))):
-                t = torch.empty(shape, dtype=torch.uint8, device=device)
+                t = self._get((tag, key), shape, torch.uint8, device)
                 ops.dropout_keep_(t, p, self.seed, self._next_offset())
                 out[key] = t
         if need_u:
-            u = torch.empty(T + 1, B, V1, device=device)
+            u = self._get((tag, 'gumbel_u'), (T + 1, B, V1), torch.float32, device)
             ops.uniform_(u, self.seed, self._next_offset())
             out['gumbel_u'] = u
         return out

@@ -43,6 +43,16 @@ int cic_prof_enable(int on);
 int cic_prof_reset(void);
 int cic_prof_collect(int id, double* total_ms, int* launches);
 
+/* ---- HIP graphs -----------------------------------------------------------------------------
+ * When enabled, each sequence engine call (decode fwd/bwd, listener fwd/bwd) is stream-captured the first
+ * time it is seen with a given set of arguments (every pointer, size and scalar is part of the key) and
+ * replayed with hipGraphLaunch afterwards: ~150 launches become one.  Callers must therefore keep the
+ * buffers they pass at stable addresses and must not use the legacy default stream (capture is refused
+ * there; the engine then falls back to direct launches).  cic_graph_stats: [captures, replays, fallbacks]. */
+int cic_graph_enable(int on);
+int cic_graph_clear(void);
+int cic_graph_stats(int64_t* out3);
+
 /* diagnostics: shader clock in MHz (out2[0]) measured over `spin` dependent FMAs; an empty launch */
 int cic_debug_clock_mhz(float* out2, int spin, cic_stream_t s);
 int cic_debug_empty(int grid, int block, cic_stream_t s);
