@@ -336,8 +336,13 @@ int launch_skinny(const cic_gemm_args& g, bool vec, hipStream_t st) {
 //   i.e. one float4 per group when the operand is K-contiguous (weights W[N,K], activations x[M,K]);
 //   a K-strided B (dX = dY W) is read as 4 row-coalesced dwords per group.
 // ---------------------------------------------------------------------------------------------
+__device__ unsigned long long* g_stamp_buf = nullptr;   // diagnostics: per-workgroup phase stamps (cic_debug_set_stamps)
+
 template <int KS, bool KCB>   // waves = KS (one 32-row strip per workgroup)
 __global__ __launch_bounds__(KS * 64) void gemm_rega_kernel(cic_gemm_args g, int gps) {
+    unsigned long long* stamps = g_stamp_buf;
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
+    if (stamps) st0 = __builtin_amdgcn_s_memrealtime();
     // gps = groups (of 8 k) per K slice, a multiple of CH; processed in chunks of CH groups with a
     // register double buffer (next chunk's loads in flight under the current chunk's MFMAs)
     constexpr int CH = 4;
@@ -394,12 +399,15 @@ __global__ __launch_bounds__(KS * 64) void gemm_rega_kernel(cic_gemm_args g, int
     for (int c = 0; c < nch; c += 2) {
         if (c + 1 < nch) load_chunk(a1, b1, c + 1);
         mma_chunk(a0, b0);
+        if (stamps && c == 0) { asm volatile("" :: "v"(acc[0])); st1 = __builtin_amdgcn_s_memrealtime(); }
         if (c + 2 < nch) load_chunk(a0, b0, c + 2);
         if (c + 1 < nch) mma_chunk(a1, b1);
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) red[(ks * 16 + e) * 64 + lane] = acc[e];
+    if (stamps) st2 = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
+    if (stamps) st3 = __builtin_amdgcn_s_memrealtime();
     // wave ks sums accumulator register e = ks, ks + KS, ... over the KS partial tiles (fixed order)
     for (int e = ks; e < 16; e += KS) {
         float v = 0.f;
@@ -413,6 +421,13 @@ __global__ __launch_bounds__(KS * 64) void gemm_rega_kernel(cic_gemm_args g, int
             if (g.relu) v = fmaxf(v, 0.f);
             *c = v;
         }
+    }
+    if (stamps && lane == 0) {   // [block][wave][5]: start, first chunk done, MFMAs done, barrier passed, end (100 MHz ticks)
+        unsigned long long* o = stamps + ((size_t)blockIdx.x * KS + ks) * 6;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = __builtin_amdgcn_s_memrealtime();
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        o[5] = xcc;
     }
 }
 
@@ -597,6 +612,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
 }
 
 }  // namespace
+
+extern "C" int cic_debug_set_stamps(unsigned long long* buf) {
+    CIC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)));
+    return 0;
+}
 
 extern "C" int cic_gemm_f32(const cic_gemm_args* a, cic_stream_t s) {
     CIC_REQUIRE(a != nullptr);

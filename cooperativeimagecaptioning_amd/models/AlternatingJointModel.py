@@ -53,6 +53,11 @@ class AlternatingJointModel(nn.Module):
         self.cider_optimization = getattr(opt, 'cider_optimization', 0)
         self.use_gen_cider_scores = getattr(opt, 'use_gen_cider_scores', 0)
         self._loss = {}
+        # MI355X: the greedy (baseline) decode of the CIDEr term is independent of the sampled decode and the
+        # listener pass until the reward: it runs on a second HIP stream so that two latency-bound launch
+        # chains share the chip.  Off by default: see the measurement below.
+        self.overlap_greedy = False   # measured: 8.9 ms/step overlapped vs 8.2 ms serial (side-stream launches are slower on this stack)
+        self._side_stream = None
         # Load model (:131-177)
         if opt.is_alternating:
             if getattr(opt, 'continue_from_existing_models', False):
@@ -148,6 +153,18 @@ class AlternatingJointModel(nn.Module):
         sample = None
         greedy = None
         dslp = None
+        greedy_event = None
+        wants_async_greedy = bool(ciw) and self.overlap_greedy and not (
+            dw > 0 and rr == 'reinforce' and self.reinforce_baseline_type == 'greedy')
+        if wants_async_greedy:
+            main = torch.cuda.current_stream(dev)
+            if self._side_stream is None or self._side_stream.device != dev:
+                self._side_stream = torch.cuda.Stream(device=dev)
+            side = self._side_stream
+            side.wait_stream(main)                                     # att_pre, staged inputs, parameters
+            with torch.cuda.stream(side):
+                greedy = cg.decode(att_feats, att_masks, 'greedy', att_pre=att_pre, tag='greedy')   # :391-403
+                greedy_event = side.record_event()
         if dw > 0:                                                     # DISC loss :455-488
             if rr == 'reinforce':
                 sample = cg.decode(att_feats, att_masks, 'multinomial', 1.0, att_pre=att_pre, grad=spk_grad)  # :226-247
@@ -190,6 +207,8 @@ class AlternatingJointModel(nn.Module):
                                    tag='cider_gen')                    # gen_result_for_cider :378-389
             if greedy is None:
                 greedy = cg.decode(att_feats, att_masks, 'greedy', att_pre=att_pre, tag='greedy')   # :391-403
+            if greedy_event is not None:
+                torch.cuda.current_stream(dev).wait_event(greedy_event)
             refs, ref_off = self._refs(data, dev)
             rw = rewards.get_self_critical_reward_device(refs, ref_off, sample, greedy)
             coef = rw['scores'][:B].float().contiguous() if self.use_gen_cider_scores else rw['reward']

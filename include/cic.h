@@ -56,6 +56,8 @@ int cic_graph_stats(int64_t* out3);
 /* diagnostics: shader clock in MHz (out2[0]) measured over `spin` dependent FMAs; an empty launch */
 int cic_debug_clock_mhz(float* out2, int spin, cic_stream_t s);
 int cic_debug_empty(int grid, int block, cic_stream_t s);
+/* diagnostics: per-workgroup phase stamps of the register-streaming GEMM (NULL = off) */
+int cic_debug_set_stamps(unsigned long long* buf);
 
 /* ---- RNG (replaces torch.rand / nn.Dropout's bernoulli_ draws) ---------------------- */
 /* Philox4x32-10 counter RNG.  u[i] = (r >> 8) * 2^-24 in [0,1), as torch.rand does
