@@ -47,7 +47,8 @@ class SamplerArgs(C.Structure):
     _fields_ = [('logits', c_ptr), ('B', C.c_int), ('V1', C.c_int), ('ld', C.c_int),
                 ('mode', C.c_int), ('temp', C.c_float),
                 ('U', c_ptr), ('ldu', C.c_int),
-                ('pick', c_ptr), ('decoding_constraint', C.c_int), ('step', C.c_int),
+                ('pick', c_ptr), ('ss_u', c_ptr), ('ss_prob', C.c_float), ('ss_pick', c_ptr),
+                ('decoding_constraint', C.c_int), ('step', C.c_int),
                 ('unfinished', c_ptr), ('it_next', c_ptr), ('seq', c_ptr), ('slp', c_ptr),
                 ('stv', c_ptr), ('seq_ld', C.c_int), ('any_unfinished', c_ptr)]
 
@@ -77,7 +78,8 @@ class SpeakerParams(C.Structure):
 class DecodeIO(C.Structure):
     _fields_ = [('mode', C.c_int), ('temp', C.c_float), ('decoding_constraint', C.c_int),
                 ('att_pre', c_ptr), ('att_masks', c_ptr), ('att_keep', c_ptr), ('x_keep', c_ptr),
-                ('out_keep', c_ptr), ('U', c_ptr), ('pick', c_ptr), ('first_token', c_ptr),
+                ('out_keep', c_ptr), ('U', c_ptr), ('pick', c_ptr), ('ss_u', c_ptr), ('ss_prob', C.c_float),
+                ('ss_pick', c_ptr), ('first_token', c_ptr),
                 ('seq', c_ptr), ('slp', c_ptr), ('stv', c_ptr), ('L', c_ptr)]
 
 
@@ -120,7 +122,7 @@ class ListenerBwdIO(C.Structure):
                 ('d_onehot', c_ptr)]
 
 
-SAMPLE_NONE, SAMPLE_GREEDY, SAMPLE_MULTINOMIAL, SAMPLE_GUMBEL_ST, SAMPLE_MULTINOMIAL_ST = range(5)
+SAMPLE_NONE, SAMPLE_GREEDY, SAMPLE_MULTINOMIAL, SAMPLE_GUMBEL_ST, SAMPLE_MULTINOMIAL_ST, SAMPLE_TEACHER = range(6)
 
 
 def declared_symbols():

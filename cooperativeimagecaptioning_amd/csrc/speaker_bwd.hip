@@ -45,6 +45,7 @@ __global__ __launch_bounds__(SNW * 64) void sampler_bwd_kernel(const float* __re
                                                           const float* __restrict__ U,          // [T+1,B,V1] or null
                                                           const float* __restrict__ G,          // [T,B,V1] or null
                                                           const int32_t* __restrict__ it_all,   // [T+1,B]
+                                                          const int64_t* __restrict__ target,   // [T+1,B] teacher targets or null
                                                           const int32_t* __restrict__ seq,      // [B,T] or null
                                                           const float* __restrict__ dslp,       // [B,T] or null
                                                           const int32_t* __restrict__ Lp, int mode, float tau,
@@ -57,7 +58,9 @@ __global__ __launch_bounds__(SNW * 64) void sampler_bwd_kernel(const float* __re
     const float* lp = logp_all + (size_t)row * V1;
     float* out = dlogits + (size_t)row * V1;
     const float* g = G ? G + (size_t)row * V1 : nullptr;
-    const int it = it_all[(size_t)(t + 1) * B + b];
+    // the log-prob that was gathered: the fed token, or the label under teacher forcing (scheduled sampling
+    // may feed a different token than the target)
+    const int it = target ? (int)target[(size_t)(t + 1) * B + b] : it_all[(size_t)(t + 1) * B + b];
     const float ds = (dslp && t < L) ? dslp[(size_t)b * T + t] : 0.f;
     const bool st_mode = (mode == CIC_SAMPLE_GUMBEL_ST || mode == CIC_SAMPLE_MULTINOMIAL_ST);
     const bool unf = st_mode && g && seq && t < L && seq[(size_t)b * T + t] > 0;
@@ -543,8 +546,9 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     // 1. d logits for every step at once (rows are independent of the recurrence)
     {
         dim3 grid(T * B), blk(1024);
+        const int64_t* tgt = io->mode == CIC_SAMPLE_TEACHER ? io->pick : nullptr;
 #define GO(RV) hipLaunchKernelGGL((sampler_bwd_kernel<RV>), grid, blk, 0, st, w.logp_all, io->U, bio->d_onehot, w.it_all, \
-                                  io->seq, bio->dslp, io->L, io->mode, io->temp, g.dlogits, T, B, V1)
+                                  tgt, io->seq, bio->dslp, io->L, io->mode, io->temp, g.dlogits, T, B, V1)
         if (V1 <= 4096) GO(1); else if (V1 <= 12288) GO(3); else if (V1 <= 32768) GO(8);
         else { cic_set_error("vocabulary too large"); return 1; }
 #undef GO

@@ -101,7 +101,7 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     CIC_REQUIRE(dp && p && io && ws);
     const cic_speaker_dims& d = *dp;
     if (int rc = check_dims(d)) return rc;
-    CIC_REQUIRE(io->mode >= CIC_SAMPLE_GREEDY && io->mode <= CIC_SAMPLE_MULTINOMIAL_ST);
+    CIC_REQUIRE(io->mode >= CIC_SAMPLE_GREEDY && io->mode <= CIC_SAMPLE_TEACHER);
     CIC_REQUIRE(io->att_pre && io->seq && io->slp && io->L);
     SpkWs w = spk_carve(d, ws);
     CIC_REQUIRE(ws_bytes >= w.bytes);
@@ -158,6 +158,9 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         a.mode = io->mode; a.temp = io->temp;
         a.U = io->U ? io->U + (size_t)(t + 1) * B * V1 : nullptr; a.ldu = V1;
         a.pick = io->pick ? io->pick + (size_t)(t + 1) * B : nullptr;
+        a.ss_u = io->ss_u ? io->ss_u + (size_t)(t + 1) * B : nullptr;
+        a.ss_prob = io->ss_prob;
+        a.ss_pick = io->ss_pick ? io->ss_pick + (size_t)(t + 1) * B : nullptr;
         a.decoding_constraint = io->decoding_constraint;
         a.step = t + 1;
         a.unfinished = w.unfinished;

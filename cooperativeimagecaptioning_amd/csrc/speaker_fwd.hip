@@ -430,7 +430,10 @@ __global__ __launch_bounds__(SNW * 64) void logsoftmax_sample_kernel(cic_sampler
 
     // ---- choose the token -------------------------------------------------------------
     const float* urow = a.U ? a.U + (size_t)b * a.ldu : nullptr;
-    const bool use_noise = (a.mode != CIC_SAMPLE_GREEDY) && !(a.pick && a.mode != CIC_SAMPLE_GUMBEL_ST);
+    const bool ss_on = a.mode == CIC_SAMPLE_TEACHER && a.ss_u && a.ss_prob > 0.f;
+    const bool use_noise = a.mode == CIC_SAMPLE_TEACHER
+                               ? (ss_on && !a.ss_pick)
+                               : ((a.mode != CIC_SAMPLE_GREEDY) && !(a.pick && a.mode != CIC_SAMPLE_GUMBEL_ST));
     const float inv_t = 1.0f / a.temp;
     ArgMax best = {-INFINITY, 0x7fffffff};
     float z[RV][4];
@@ -457,7 +460,15 @@ __global__ __launch_bounds__(SNW * 64) void logsoftmax_sample_kernel(cic_sampler
     }
     best = block_argmax(best, shf, shi);
     int it = best.i;
-    if (a.pick && a.mode != CIC_SAMPLE_GREEDY && a.mode != CIC_SAMPLE_GUMBEL_ST) it = (int)a.pick[b];
+    int it_feed = -1;                                   // teacher mode: token fed to the next step
+    if (a.mode == CIC_SAMPLE_TEACHER) {
+        const int target = (int)a.pick[b];
+        const int drawn = a.ss_pick ? (int)a.ss_pick[b] : best.i;
+        it_feed = (ss_on && a.ss_u[b] < a.ss_prob) ? drawn : target;   // AttModel.py:119-128
+        it = target;                                     // the loss gathers log p(target)
+    } else if (a.pick && a.mode != CIC_SAMPLE_GREEDY && a.mode != CIC_SAMPLE_GUMBEL_ST) {
+        it = (int)a.pick[b];
+    }
 
     // sampled log-prob (gather) and the straight-through value v = (1 - y_it) + y_it
     float slp_part = 0.f;
@@ -509,7 +520,7 @@ __global__ __launch_bounds__(SNW * 64) void logsoftmax_sample_kernel(cic_sampler
         int unf = (it > 0) ? 1 : 0;
         if (t > 1) unf = unf & a.unfinished[b];
         a.unfinished[b] = unf;
-        a.it_next[b] = it;                                  // un-masked: embed(it) precedes the masking (:399)
+        a.it_next[b] = it_feed >= 0 ? it_feed : it;         // un-masked: embed(it) precedes the masking (:399)
         a.seq[(size_t)b * a.seq_ld + (t - 1)] = unf ? it : 0;   // it * unfinished (:409)
         a.slp[(size_t)b * a.seq_ld + (t - 1)] = slp;
         if (a.stv) a.stv[(size_t)b * a.seq_ld + (t - 1)] = unf ? v : 1.0f;   // finished rows -> exact EOS one-hot (:419-420)
@@ -610,7 +621,9 @@ extern "C" int cic_logsoftmax_sample(const cic_sampler_args* a, cic_stream_t s) 
         CIC_REQUIRE(a->unfinished && a->it_next && a->seq && a->slp && a->any_unfinished && a->step >= 1);
         CIC_REQUIRE(a->temp > 0.f);
         const bool needs_u = a->mode == CIC_SAMPLE_GUMBEL_ST ||
-                             ((a->mode == CIC_SAMPLE_MULTINOMIAL || a->mode == CIC_SAMPLE_MULTINOMIAL_ST) && !a->pick);
+                             ((a->mode == CIC_SAMPLE_MULTINOMIAL || a->mode == CIC_SAMPLE_MULTINOMIAL_ST) && !a->pick) ||
+                             (a->mode == CIC_SAMPLE_TEACHER && a->ss_u && a->ss_prob > 0.f && !a->ss_pick);
+        CIC_REQUIRE(a->mode != CIC_SAMPLE_TEACHER || a->pick);
         CIC_REQUIRE(!needs_u || (a->U && a->ldu >= a->V1));
     }
     dim3 grid(a->B), blk(1024);

@@ -81,7 +81,7 @@ def speaker_att_embed_fwd(dims, params, att_raw, att_pre=None):
 
 def speaker_decode_fwd(dims, params, att_pre, mode, temp=1.0, att_masks=None, att_keep=None, x_keep=None,
                        out_keep=None, U=None, pick=None, decoding_constraint=0, want_stv=False, ws=None,
-                       first_token=None, out=None):
+                       first_token=None, out=None, ss_u=None, ss_prob=0.0, ss_pick=None):
     """-> dict(seq i32[B,T], slp f32[B,T], stv f32[B,T]|None, L i32[1], ws)."""
     dev = att_pre.device
     B, T = dims.B, dims.T
@@ -98,11 +98,12 @@ def speaker_decode_fwd(dims, params, att_pre, mode, temp=1.0, att_masks=None, at
     io.att_pre, io.att_masks = _p(att_pre), _p(att_masks)
     io.att_keep, io.x_keep, io.out_keep = _p(att_keep), _p(x_keep), _p(out_keep)
     io.U, io.pick, io.first_token = _p(U), _p(pick), _p(first_token)
+    io.ss_u, io.ss_prob, io.ss_pick = _p(ss_u), float(ss_prob), _p(ss_pick)
     io.seq, io.slp, io.stv, io.L = _p(out['seq']), _p(out['slp']), _p(out['stv']), _p(out['L'])
     check(lib.cic_speaker_decode_fwd(C.byref(dims), C.byref(params), C.byref(io), ws.data_ptr(), ws.numel(),
                                      stream()), 'cic_speaker_decode_fwd')
     out['io'] = io
-    out['_keep'] = (att_pre, att_masks, att_keep, x_keep, out_keep, U, pick, first_token)   # alive until the backward call
+    out['_keep'] = (att_pre, att_masks, att_keep, x_keep, out_keep, U, pick, first_token, ss_u, ss_pick)   # alive until the backward call
     return out
 
 

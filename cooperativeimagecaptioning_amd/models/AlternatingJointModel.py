@@ -128,12 +128,10 @@ class AlternatingJointModel(nn.Module):
 
         # MLE (ce_loss :196-207)
         if cw > 0:
-            if cg.training and cg.ss_prob > 0.0:
-                raise NotImplementedError('scheduled sampling (ss_prob > 0) is not on the MI355X path yet')
             Tm = seq.shape[1] - 1
-            mle = cg.decode(att_feats, att_masks, 'multinomial', 1.0, att_pre=att_pre, grad=True, T=Tm,
+            mle = cg.decode(att_feats, att_masks, 'teacher', 1.0, att_pre=att_pre, grad=True, T=Tm,
                             pick=seq.t().contiguous().long(), first_token=seq[:, 0].contiguous().long(), tag='mle',
-                            decoding_constraint=0, want_stv=False)
+                            decoding_constraint=0, want_stv=False, ss_prob=cg.ss_prob if cg.training else 0.0)
             d_mle = cg._buf.get('d_mle', (B, Tm), torch.float32, dev)
             l_mle = engine.masked_nll(mle.slp, masks.float()[:, 1:], cw, dslp=d_mle)
             cg._loss['xe'] = l_mle.detach()[0]

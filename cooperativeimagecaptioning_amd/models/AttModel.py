@@ -43,7 +43,8 @@ class Att2in2Core(nn.Module):
 
 
 MODES = {'greedy': _lib.SAMPLE_GREEDY, 'multinomial': _lib.SAMPLE_MULTINOMIAL,
-         'gumbel': _lib.SAMPLE_GUMBEL_ST, 'multinomial_st': _lib.SAMPLE_MULTINOMIAL_ST}
+         'gumbel': _lib.SAMPLE_GUMBEL_ST, 'multinomial_st': _lib.SAMPLE_MULTINOMIAL_ST,
+         'teacher': _lib.SAMPLE_TEACHER}
 
 
 class DecodeResult:
@@ -125,7 +126,7 @@ class AttModel(nn.Module):
         return engine.speaker_att_embed_fwd(dims, params, att_raw, att_pre)
 
     def decode(self, att_feats, att_masks, mode, temp=1.0, att_pre=None, grad=False, T=None, pick=None,
-               first_token=None, decoding_constraint=None, tag='sample', want_stv=None):
+               first_token=None, decoding_constraint=None, tag='sample', want_stv=None, ss_prob=0.0):
         """One AttModel.sample / AttModel.forward pass on the device -> DecodeResult."""
         self._check_inputs(att_feats)
         fl = self.flat()
@@ -143,10 +144,14 @@ class AttModel(nn.Module):
                                                    self._buf.get('att_pre', (B, K, self.rnn_size), torch.float32, att_raw.device))
         p = self.drop_prob_lm if self.training else 0.0
         dims.p_drop = p
+        ss = mode == 'teacher' and ss_prob > 0.0
         nz = self.noise.decode_noise(tag, B, K, self.rnn_size, self.input_encoding_size, self.vocab_size + 1, T, p,
-                                     need_u=(mode == 'gumbel') or (mode in ('multinomial', 'multinomial_st') and pick is None),
-                                     device=att_raw.device)
-        if pick is None:
+                                     need_u=(mode == 'gumbel') or (mode in ('multinomial', 'multinomial_st') and pick is None) or ss,
+                                     device=att_raw.device, need_ss=ss)
+        ss_pick = None
+        if mode == 'teacher':
+            ss_pick = nz.get('pick') if ss else None     # recorded scheduled-sampling draws (tests)
+        elif pick is None:
             pick = nz.get('pick')
         if want_stv is None:
             want_stv = mode in ('gumbel', 'multinomial_st')
@@ -166,7 +171,9 @@ class AttModel(nn.Module):
         fwd = engine.speaker_decode_fwd(dims, params, att_pre, MODES[mode], temp, att_masks,
                                         nz.get('att_keep'), nz.get('x_keep'), nz.get('out_keep'), nz.get('gumbel_u'),
                                         pick, self.decoding_constraint if decoding_constraint is None else decoding_constraint,
-                                        want_stv=want_stv, ws=self._ws.get(ws_key), first_token=first_token, out=out)
+                                        want_stv=want_stv, ws=self._ws.get(ws_key), first_token=first_token, out=out,
+                                        ss_u=nz.get('ss_u') if ss else None, ss_prob=ss_prob if ss else 0.0,
+                                        ss_pick=ss_pick)
         self._ws[ws_key] = fwd['ws']
         return DecodeResult(fwd, mode, dims, params, att_raw, grad)
 
@@ -181,13 +188,11 @@ class AttModel(nn.Module):
     # ---- reference API ---------------------------------------------------------------------
     def forward(self, fc_feats, att_feats, att_masks, seq, masks):
         """Teacher-forced MLE loss, models/AttModel.py:103-148."""
-        if self.training and self.ss_prob > 0.0:
-            raise NotImplementedError('scheduled sampling (ss_prob > 0) is not on the MI355X path yet')
         B, Lp = seq.shape
         T = Lp - 1
-        res = self.decode(att_feats, att_masks, 'multinomial', 1.0, grad=True, T=T,
+        res = self.decode(att_feats, att_masks, 'teacher', 1.0, grad=True, T=T,
                           pick=seq.t().contiguous().long(), first_token=seq[:, 0].contiguous().long(), tag='mle',
-                          decoding_constraint=0, want_stv=False)
+                          decoding_constraint=0, want_stv=False, ss_prob=self.ss_prob if self.training else 0.0)
         dslp = torch.empty(B, T, device=att_feats.device)
         loss = engine.masked_nll(res.slp, masks.float()[:, 1:], 1.0, dslp=dslp)
         self._loss['xe'] = loss.detach()[0]

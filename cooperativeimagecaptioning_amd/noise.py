@@ -32,7 +32,7 @@ class NoiseSource:
             t = self._buf[k] = torch.empty(shape, dtype=dtype, device=device)
         return t
 
-    def decode_noise(self, tag, B, K, H, E, V1, T, p, need_u, device):
+    def decode_noise(self, tag, B, K, H, E, V1, T, p, need_u, device, need_ss=False):
         if self.override is not None:
             ov = self.override.get(tag)
             if ov is None:
@@ -42,6 +42,9 @@ class NoiseSource:
                 if v is None:
                     continue
                 t = torch.as_tensor(v)
+                if k != 'att_keep' and t.shape[0] < T + 1:      # per-step arrays: pad to T+1 rows
+                    pad = torch.ones((T + 1 - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype)
+                    t = torch.cat([t, pad], 0)
                 if k.endswith('_keep'):
                     if p == 0.0:
                         continue
@@ -62,4 +65,8 @@ class NoiseSource:
             u = self._get((tag, 'gumbel_u'), (T + 1, B, V1), torch.float32, device)
             ops.uniform_(u, self.seed, self._next_offset())
             out['gumbel_u'] = u
+        if need_ss:
+            su = self._get((tag, 'ss_u'), (T + 1, B), torch.float32, device)
+            ops.uniform_(su, self.seed, self._next_offset())
+            out['ss_u'] = su
         return out

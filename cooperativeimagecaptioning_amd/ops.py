@@ -116,6 +116,7 @@ def logsoftmax_sample(logits, mode, temp=1.0, U=None, pick=None, decoding_constr
     a.mode, a.temp = mode, float(temp)
     a.U, a.ldu = (U.data_ptr(), U.stride(0)) if U is not None else (None, 0)
     a.pick = ptr_any(pick)
+    a.ss_u, a.ss_prob, a.ss_pick = None, 0.0, None
     a.decoding_constraint = int(decoding_constraint)
     a.step = step
     a.unfinished, a.it_next = ptr_any(unfinished), ptr_any(it_next)

@@ -118,7 +118,10 @@ enum {
     CIC_SAMPLE_GREEDY = 1,         /* torch.max, ties -> lowest index (AttModel.py:328-329) */
     CIC_SAMPLE_MULTINOMIAL = 2,    /* it ~ softmax(logp/temp) (AttModel.py:332-343); Gumbel-max draw or pick[] */
     CIC_SAMPLE_GUMBEL_ST = 3,      /* models/gumbel.py:17-30 */
-    CIC_SAMPLE_MULTINOMIAL_ST = 4  /* models/multinomial.py:4-27 */
+    CIC_SAMPLE_MULTINOMIAL_ST = 4, /* models/multinomial.py:4-27 */
+    CIC_SAMPLE_TEACHER = 5         /* teacher forcing (AttModel.forward :116-141): slp = logp[pick] (the target);
+                                      next input = pick, or with scheduled sampling (:118-129) a draw from
+                                      softmax(logp) for the rows whose ss_u < ss_prob */
 };
 typedef struct {
     float* logits;        /* [B, ld] in: logits, out: log-probs (in place) */
@@ -127,7 +130,10 @@ typedef struct {
     float temp;           /* temperature / gumbel_temp / multinomial_temp */
     const float* U;       /* [B, ldu] uniforms for the Gumbel noise, or NULL */
     int ldu;
-    const int64_t* pick;  /* [B] externally chosen tokens (multinomial modes), or NULL */
+    const int64_t* pick;  /* [B] externally chosen tokens (multinomial modes) / targets (teacher), or NULL */
+    const float* ss_u;    /* [B] scheduled-sampling uniforms (teacher mode) or NULL */
+    float ss_prob;        /* scheduled-sampling probability */
+    const int64_t* ss_pick; /* [B] externally drawn scheduled-sampling tokens, or NULL (Gumbel-max draw from U) */
     int decoding_constraint; /* != 0: suppress the previously appended token seq[b, step-2] (step >= 2) */
     int step;             /* reference loop iteration t >= 1 whose input token is chosen */
     int32_t* unfinished;  /* [B] in/out */
@@ -182,8 +188,11 @@ typedef struct {
     const uint8_t* out_keep;  /* [T+1,B,H] row t: core-output dropout of step t */
     const float* U;           /* [T+1,B,V+1] row t (t>=1): Gumbel uniforms used to pick the input of step t */
     const int64_t* pick;      /* [T+1,B] row t: externally chosen tokens (multinomial modes) or NULL.
-                                 Teacher forcing (AttModel.forward, :103-148) = CIC_SAMPLE_MULTINOMIAL with
+                                 Teacher forcing (AttModel.forward, :103-148) = CIC_SAMPLE_TEACHER with
                                  pick[t] = labels[:, t]: slp then holds log p(target) of every step. */
+    const float* ss_u;        /* [T+1,B] scheduled-sampling uniforms, row t decides the input of step t (teacher mode) */
+    float ss_prob;            /* model.ss_prob (train.py:80-85); 0 = plain teacher forcing */
+    const int64_t* ss_pick;   /* [T+1,B] externally drawn scheduled-sampling tokens or NULL */
     const int64_t* first_token; /* [B] input token of step 0; NULL = <bos> = vocab_size+1 (:324-326).
                                  AttModel.forward starts from labels[:, 0] = 0 instead (:131).  When set
                                  (teacher forcing) all T steps count: L is written as T. */

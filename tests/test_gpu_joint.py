@@ -103,7 +103,7 @@ def test_cpu_input_fails_loudly():
               is_alternating=True, alternating_turn='speaker')
 
 
-@pytest.mark.parametrize('name', ['mle_plain', 'mle_dropout'])
+@pytest.mark.parametrize('name', ['mle_plain', 'mle_dropout', 'mle_ss'])
 def test_mle_forward_backward_matches_reference(name):
     """Att2in2Model.forward (teacher-forced MLE, models/AttModel.py:103-148) vs the reference."""
     from cooperativeimagecaptioning_amd import models
@@ -115,6 +115,7 @@ def test_mle_forward_backward_matches_reference(name):
     cg.load_state_dict({k: T_(v) for k, v in z['weights'].items()})
     cg.cuda().train()
     cg.noise.override = {'mle': GU.noise_dict(z, 'noise')}
+    cg.ss_prob = float(z['ss_prob'])       # scheduled sampling (AttModel.py:118-129): recorded uniforms and draws
     cg.zero_grad()
     loss = cg(T_(z['fc']).cuda(), T_(z['att_raw']).cuda(), None, T_(z['labels']).cuda(), T_(z['masks']).cuda())
     loss.backward()
