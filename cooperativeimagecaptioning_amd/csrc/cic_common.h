@@ -66,6 +66,53 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- DPP cross-lane moves: VALU-rate lane exchange inside a 16-lane row (no LDS crossbar) -----------
+// __shfl_xor lowers to ds_bpermute (an LDS-pipe instruction, ~60 cycles of latency per DEPENDENT step);
+// a 64-lane reduction is 6 such steps.  The first four steps (xor 1, 2, then mirror within 8 and 16 lanes)
+// exist as DPP modifiers on gfx950, leaving two cross-row steps.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1;       // quad_perm [1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;       // quad_perm [2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;   // lane i <-> 7-i within 8
+constexpr int DPP_ROW_MIRROR = 0x140;        // lane i <-> 15-i within 16
+constexpr int DPP_ROW_ROR8 = 0x128;          // lane i <- lane (i+8)%16: xor 8 within a row
+
+// sum over the 8 lanes that share lane>>3 (all 8 end with the total)
+__device__ __forceinline__ float sum8_dpp(float v) {
+    v += dpp_f32<DPP_QUAD_XOR1>(v);
+    v += dpp_f32<DPP_QUAD_XOR2>(v);
+    v += dpp_f32<DPP_ROW_HALF_MIRROR>(v);
+    return v;
+}
+__device__ __forceinline__ float readlane_f32(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+// whole-wave reductions without a single LDS-pipe instruction: 4 DPP steps inside each 16-lane row, then
+// the four row totals through v_readlane (scalar broadcast).  (v_permlane32_swap via the compiler builtin
+// returned wrong lanes on ROCm 7.2 / gfx950 in a direct test, so it is not used.)
+__device__ __forceinline__ float wave_sum_fast(float v) {
+    v = sum8_dpp(v);
+    v += dpp_f32<DPP_ROW_MIRROR>(v);
+    return (readlane_f32(v, 0) + readlane_f32(v, 16)) + (readlane_f32(v, 32) + readlane_f32(v, 48));
+}
+__device__ __forceinline__ float wave_max_fast(float v) {
+    v = fmaxf(v, dpp_f32<DPP_QUAD_XOR1>(v));
+    v = fmaxf(v, dpp_f32<DPP_QUAD_XOR2>(v));
+    v = fmaxf(v, dpp_f32<DPP_ROW_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f32<DPP_ROW_MIRROR>(v));
+    return fmaxf(fmaxf(readlane_f32(v, 0), readlane_f32(v, 16)), fmaxf(readlane_f32(v, 32), readlane_f32(v, 48)));
+}
+// sum over the 8 lanes that share lane&7 (xor 8, 16, 32)
+__device__ __forceinline__ float sum_over_rg(float v) {
+    v += dpp_f32<DPP_ROW_ROR8>(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
 // ---- fast, accurate-enough transcendental helpers (f32, abs err ~1e-7) ----------------
 __device__ __forceinline__ float fast_tanh(float x) {
     // tanh(x) = sign(x) * (1 - e) / (1 + e),  e = exp(-2|x|)

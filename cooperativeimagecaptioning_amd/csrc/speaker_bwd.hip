@@ -300,9 +300,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_cols_kernel(const float* __rest
         float part = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) part += dr[e] * av[j][e];
-        part += __shfl_xor(part, 1, 64);
-        part += __shfl_xor(part, 2, 64);
-        part += __shfl_xor(part, 4, 64);
+        part = sum8_dpp(part);
         const int k = 8 * j + rg;
         if (c == 0 && k < K) sp[w * 64 + k] = part;
     }
@@ -312,7 +310,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_cols_kernel(const float* __rest
         for (int q = 0; q < NW; ++q) dal += sp[q * 64 + lane];
         al = alpha[(size_t)b * K + lane];
     }
-    const float cs = wave_sum(al * dal);
+    const float cs = wave_sum_fast(al * dal);
     const float dd = al * (dal - cs);                  // 0 for lanes >= K
     if (w == 0 && half == 0 && lane < K) ddot_out[(size_t)b * K + lane] = dd;
     if (!owner) return;
@@ -328,11 +326,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_cols_kernel(const float* __rest
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        float v = acc[e];
-        v += __shfl_xor(v, 8, 64);
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        acc[e] = v * wa[e];
+        acc[e] = sum_over_rg(acc[e]) * wa[e];
     }
     if (rg == 0) reinterpret_cast<f32x4*>(d_att_h + (size_t)b * H)[col4] = acc;
 }

@@ -58,6 +58,7 @@ int cic_debug_clock_mhz(float* out2, int spin, cic_stream_t s);
 int cic_debug_empty(int grid, int block, cic_stream_t s);
 /* diagnostics: per-workgroup phase stamps of the register-streaming GEMM (NULL = off) */
 int cic_debug_set_stamps(unsigned long long* buf);
+int cic_debug_set_attn_stamps(unsigned long long* buf);
 
 /* ---- RNG (replaces torch.rand / nn.Dropout's bernoulli_ draws) ---------------------- */
 /* Philox4x32-10 counter RNG.  u[i] = (r >> 8) * 2^-24 in [0,1), as torch.rand does
@@ -101,6 +102,13 @@ int cic_colsum_f32(const float* X, int M, int N, int ldx, float* out, int accumu
 int cic_attn_fwd(const float* att_h, const float* p_att, const float* att, const float* w_alpha,
                  const float* b_alpha, const float* masks, float* att_res, float* alpha, float* dot,
                  int B, int K, int A, int H, cic_stream_t s);
+/* Average duration of one cic_attn_fwd launch, HIP events on the stream, measured from C++ (helper of
+ * bench.py: roofline.achieved = algorithmic bytes / this duration).  With a `pollute` buffer the launches
+ * are interleaved with a kernel that streams it, and that kernel's own time is subtracted: the attention
+ * kernel then runs in the cache state it sees inside a decode step. */
+int cic_attn_fwd_timed(const float* att_h, const float* p_att, const float* att, const float* w_alpha,
+                       const float* b_alpha, float* att_res, float* alpha, int B, int K, int A, int H,
+                       int iters, const float* pollute, int64_t pollute_floats, double* avg_us, cic_stream_t s);
 /* Att2in2Core.forward pointwise part, models/AttModel.py:515-529.  pre[B,5H] = i2h(x)+h2h(h)
  * with a2c(att_res) added to columns [3H,5H).  keep: u8[B,H] dropout keep mask or NULL. */
 int cic_cell_fwd(const float* pre, const float* c_prev, const uint8_t* keep, float p_drop,
