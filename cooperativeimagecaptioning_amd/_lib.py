@@ -48,6 +48,7 @@ class SamplerArgs(C.Structure):
                 ('mode', C.c_int), ('temp', C.c_float),
                 ('U', c_ptr), ('ldu', C.c_int),
                 ('pick', c_ptr), ('ss_u', c_ptr), ('ss_prob', C.c_float), ('ss_pick', c_ptr),
+                ('soft', c_ptr), ('ld_soft', C.c_int), ('ps_u', c_ptr), ('ps_prob', C.c_float),
                 ('decoding_constraint', C.c_int), ('step', C.c_int),
                 ('unfinished', c_ptr), ('it_next', c_ptr), ('seq', c_ptr), ('slp', c_ptr),
                 ('stv', c_ptr), ('seq_ld', C.c_int), ('any_unfinished', c_ptr)]
@@ -78,7 +79,9 @@ class SpeakerParams(C.Structure):
 class DecodeIO(C.Structure):
     _fields_ = [('mode', C.c_int), ('temp', C.c_float), ('decoding_constraint', C.c_int),
                 ('att_pre', c_ptr), ('att_masks', c_ptr), ('att_keep', c_ptr), ('x_keep', c_ptr),
-                ('out_keep', c_ptr), ('U', c_ptr), ('pick', c_ptr), ('ss_u', c_ptr), ('ss_prob', C.c_float),
+                ('out_keep', c_ptr), ('U', c_ptr), ('pick', c_ptr),
+                ('ps_u', c_ptr), ('ps_prob', C.c_float), ('soft_raw', c_ptr), ('xpre', c_ptr), ('soft_out', c_ptr),
+                ('ss_u', c_ptr), ('ss_prob', C.c_float),
                 ('ss_pick', c_ptr), ('first_token', c_ptr),
                 ('seq', c_ptr), ('slp', c_ptr), ('stv', c_ptr), ('L', c_ptr)]
 
@@ -113,7 +116,8 @@ class ListenerParams(C.Structure):
 
 class ListenerIO(C.Structure):
     _fields_ = [('fc_feats', c_ptr), ('labels', c_ptr), ('masks', c_ptr), ('seq', c_ptr), ('stv', c_ptr),
-                ('L', c_ptr), ('only_one_retrieval', C.c_int), ('loss_rows', c_ptr), ('loss_sum', c_ptr),
+                ('L', c_ptr), ('soft', c_ptr), ('only_one_retrieval', C.c_int), ('loss_rows', c_ptr),
+                ('loss_sum', c_ptr),
                 ('img_emb_out', c_ptr), ('cap_emb_out', c_ptr)]
 
 
@@ -123,6 +127,7 @@ class ListenerBwdIO(C.Structure):
 
 
 SAMPLE_NONE, SAMPLE_GREEDY, SAMPLE_MULTINOMIAL, SAMPLE_GUMBEL_ST, SAMPLE_MULTINOMIAL_ST, SAMPLE_TEACHER = range(6)
+SAMPLE_GUMBEL_PS, SAMPLE_MULTINOMIAL_PS = 6, 7
 
 
 def declared_symbols():

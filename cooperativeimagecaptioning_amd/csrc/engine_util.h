@@ -34,6 +34,9 @@ SpkWs spk_carve(const cic_speaker_dims& d, void* base);
 
 int cic_fill_i32(int32_t* p, int n, int32_t v, hipStream_t st);
 int cic_add_vec(const float* a, const float* b, float* o, int n, hipStream_t st);
+int cic_relu_keep_fwd(const float* xpre, const uint8_t* keep, float p_drop, float* x, int64_t n, hipStream_t st);
+int cic_soft_mask(const float* soft_raw, const int32_t* seq, const int32_t* L, float* soft_out, int T, int B, int V1,
+                  hipStream_t st);
 
 // C[M,N] = A[M,K] W[N,K]^T (+bias) (+C)           — nn.Linear forward
 static inline int gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,

@@ -19,9 +19,11 @@ namespace {
 // generated captions: tokens = [<bos>, seq[:, 0:L]], lens from masks [1,1,(seq>0)[:, :L-1]]
 // (models/AlternatingJointModel.py:353-370)
 __global__ void prep_generated_kernel(const int32_t* __restrict__ seq, const float* __restrict__ stv,
-                                      const int32_t* __restrict__ Lp, int B, int T, int bos,
+                                      const int32_t* __restrict__ Lp, int B, int T, int bos, int dense,
                                       int32_t* __restrict__ idx, float* __restrict__ val,
                                       int32_t* __restrict__ len) {
+    // dense != 0 (soft caption rows): positions 1..T are embedded by a dense product added afterwards, so
+    // their gather contributes nothing (val = 0)
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const int L = *Lp;
@@ -30,8 +32,8 @@ __global__ void prep_generated_kernel(const int32_t* __restrict__ seq, const flo
     val[(size_t)b * (T + 1)] = 1.0f;
     for (int j = 0; j < T; ++j) {
         const int tok = seq[(size_t)b * T + j];
-        idx[(size_t)b * (T + 1) + 1 + j] = j < L ? tok : 0;
-        val[(size_t)b * (T + 1) + 1 + j] = (j < L && stv) ? stv[(size_t)b * T + j] : 1.0f;
+        idx[(size_t)b * (T + 1) + 1 + j] = (j < L && !dense) ? tok : 0;
+        val[(size_t)b * (T + 1) + 1 + j] = dense ? 0.0f : ((j < L && stv) ? stv[(size_t)b * T + j] : 1.0f);
         if (j < L - 1 && tok > 0) ++n;
     }
     if (n > L + 1) n = L + 1;
@@ -389,7 +391,7 @@ static int listener_fwd_impl(const cic_listener_dims* dp, const cic_listener_par
     } else {
         CIC_REQUIRE(io->seq && io->L && Lp == d.T + 1);
         hipLaunchKernelGGL(prep_generated_kernel, dim3(cic_cdiv(B, 256)), dim3(256), 0, st, io->seq, io->stv, io->L, B,
-                           d.T, d.V + 1, w.idx, w.val, w.len);
+                           d.T, d.V + 1, io->soft ? 1 : 0, w.idx, w.val, w.len);
     }
     CIC_LAUNCH_CHECK();
     // image encoder: l2norm(fc W^T + b)                                  (VSEFCModel.py:40-54)
@@ -403,6 +405,10 @@ static int listener_fwd_impl(const cic_listener_dims* dp, const cic_listener_par
         hipLaunchKernelGGL(embed_st_fwd_kernel, dim3(cic_cdiv(n, 256)), dim3(256), 0, st, p->embed_w, w.idx, w.val,
                            w.x_emb, B, Lp, E);
         CIC_LAUNCH_CHECK();
+    }
+    if (io->soft && !io->labels) {
+        // soft caption rows: x_emb[1..T] += soft @ embed[0:V+1]          (VSEFCModel.py:102-104)
+        RUN(gemm_nn(io->soft, d.V + 1, p->embed_w, E, w.x_emb + (size_t)B * E, E, (Lp - 1) * B, E, d.V + 1, true, st));
     }
     RUN(gemm_nt(w.x_emb, E, p->w_ih, E, w.gi_all, 3 * J, Lp * B, 3 * J, E, p->b_ih, false, false, st));
     CIC_HIP(hipMemsetAsync(w.h_all, 0, sizeof(float) * B * J, st));
@@ -488,6 +494,8 @@ static int listener_bwd_impl(const cic_listener_dims* dp, const cic_listener_par
             hipLaunchKernelGGL(embed_st_bwd_kernel, dim3(cic_cdiv(n, 256)), dim3(256), 0, st, w.dx_emb, w.idx, w.val,
                                w.len, g->embed_w, B, Lp, E);
             CIC_LAUNCH_CHECK();
+            if (io->soft && !io->labels)   // dense rows: d embed[0:V+1] += soft^T dx_emb[1..T]
+                RUN(gemm_tn(io->soft, d.V + 1, w.dx_emb + (size_t)B * E, E, g->embed_w, E, d.V + 1, E, (Lp - 1) * B, true, st));
         }
         if (bio->d_onehot) {
             // straight-through path back to the speaker: d one_hot[t,b,0:V+1] = dx_emb[t,b,:] E[0:V+1,:]^T for the

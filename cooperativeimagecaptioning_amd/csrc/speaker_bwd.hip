@@ -125,6 +125,106 @@ __global__ __launch_bounds__(SNW * 64) void sampler_bwd_kernel(const float* __re
         }
 }
 
+
+// Partial-sampling modes, one core step per launch (one workgroup per image row b of step t).
+//   soft row  o = (m y_hard - m y).detach() + y  =>  d y = G    (gumbel_softmax.py:30-41, multinomial_soft.py:23-33)
+//   G = [unfinished] * d soft_out[t,b,:]  (finished rows were replaced by the constant EOS one-hot, AttModel.py:428-432)
+//       + d soft_raw[t,b,:] from the next step's input xt = relu_dropout(soft_raw @ embed)   (:395-397; already in dl)
+//   gumbel_ps      y = softmax((logp+g)/tau):  d logp_j = y_j (G_j - sum_i y_i G_i) / tau      (zero-sum)
+//   multinomial_ps y = exp(logp/tau):          d logp_j = y_j G_j / tau                        (not zero-sum)
+//   d logits_j = d logp_j - exp(logp_j) sum_i d logp_i  +  dslp ([j == it] - exp(logp_j))
+template <int RV>
+__global__ __launch_bounds__(SNW * 64) void sampler_ps_bwd_kernel(const float* __restrict__ logp,     // [B,V1] step t
+                                                             const float* __restrict__ U,        // [B,V1] row t+1 or null
+                                                             const float* __restrict__ G,        // [B,V1] d soft_out[t] or null
+                                                             float* __restrict__ dl,             // [B,V1] in: recurrent part (rec), out: d logits
+                                                             int rec, const int32_t* __restrict__ it_next,   // [B] it_all[t+1]
+                                                             const int32_t* __restrict__ seq,    // [B,T]
+                                                             const float* __restrict__ dslp,     // [B,T] or null
+                                                             const int32_t* __restrict__ Lp, int t, int mode, float tau,
+                                                             int T, int V1) {
+    constexpr int NT = SNW * 64;
+    __shared__ float sh[SNW];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int L = *Lp;
+    const float* lp = logp + (size_t)b * V1;
+    float* out = dl + (size_t)b * V1;
+    if (t >= L) {   // block-uniform: the reference never ran this step's sampler with gradient (break, AttModel.py:407)
+        for (int c = tid; c < V1; c += NT) out[c] = 0.f;
+        return;
+    }
+    const float* g = G ? G + (size_t)b * V1 : nullptr;
+    const float* urow = U ? U + (size_t)b * V1 : nullptr;
+    const int it = it_next[b];
+    const float ds = dslp ? dslp[(size_t)b * T + t] : 0.f;
+    const bool unf = g && seq[(size_t)b * T + t] > 0;
+    const bool gum = mode == CIC_SAMPLE_GUMBEL_PS;
+    const int nq = (V1 + 3) >> 2;
+    const float inv_t = 1.0f / tau;
+    float x[RV][4], y[RV][4], gg[RV][4];
+    float zm = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < RV; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * (tid + NT * r) + e;
+            const bool ok = (tid + NT * r) < nq && c < V1;
+            x[r][e] = ok ? lp[c] : -INFINITY;
+            float gv = 0.f;
+            if (ok && unf) gv = g[c];
+            if (ok && rec) gv += out[c];
+            gg[r][e] = gv;
+            float z = -INFINITY;
+            if (ok) z = gum ? (x[r][e] + gumbel_from_u(urow[c])) * inv_t : x[r][e] * inv_t;
+            y[r][e] = z;
+            zm = fmaxf(zm, z);
+        }
+    float corr = 0.f;   // sum_i d logp_i (multinomial_ps) or sum_i y_i G_i (gumbel_ps)
+    if (gum) {
+        zm = block_max4(zm, sh);
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < RV; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[r][e] = __expf(y[r][e] - zm);
+                s += y[r][e];
+            }
+        const float inv = 1.0f / block_sum4(s, sh);
+        float c = 0.f;
+#pragma unroll
+        for (int r = 0; r < RV; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[r][e] *= inv;
+                c += y[r][e] * gg[r][e];
+            }
+        corr = block_sum4(c, sh);
+    } else {
+        float c = 0.f;
+#pragma unroll
+        for (int r = 0; r < RV; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[r][e] = __expf(y[r][e]);          // exp(-inf) = 0 for the padding lanes
+                c += y[r][e] * gg[r][e] * inv_t;
+            }
+        corr = block_sum4(c, sh);
+    }
+#pragma unroll
+    for (int r = 0; r < RV; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * (tid + NT * r) + e;
+            if ((tid + NT * r) < nq && c < V1) {
+                const float pj = __expf(x[r][e]);
+                float v = gum ? y[r][e] * (gg[r][e] - corr) * inv_t : y[r][e] * gg[r][e] * inv_t - pj * corr;
+                if (ds != 0.f) v += ds * ((c == it ? 1.f : 0.f) - pj);
+                out[c] = v;
+            }
+        }
+}
+
 // ---- cell backward -----------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cell_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ c_prev,
                                                        const float* __restrict__ c_new, const float* __restrict__ d_out,
@@ -528,8 +628,10 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     CIC_REQUIRE(ws_fwd_bytes >= w.bytes);
     SpkBws g = spk_bcarve(d, ws_bwd, true);
     CIC_REQUIRE(ws_bwd_bytes >= g.bytes);
+    const bool ps = io->mode == CIC_SAMPLE_GUMBEL_PS || io->mode == CIC_SAMPLE_MULTINOMIAL_PS;
     CIC_REQUIRE(!(bio->d_onehot && io->mode == CIC_SAMPLE_GUMBEL_ST) || io->U);
     CIC_REQUIRE(!bio->d_onehot || io->seq);
+    CIC_REQUIRE(!ps || (io->soft_raw && io->xpre && io->seq && (io->mode != CIC_SAMPLE_GUMBEL_PS || io->U)));
     hipStream_t st = cic_s(s);
     const int B = d.B, K = d.K, H = d.H, E = d.E, A = d.A, T = d.T, V1 = d.V + 1, D = d.D;
     const float scale = 1.0f / (1.0f - d.p_drop);
@@ -537,8 +639,9 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     int rc;
 #define RUN(x) if ((rc = (x)) != 0) return rc
 
-    // 1. d logits for every step at once (rows are independent of the recurrence)
-    {
+    // 1. d logits for every step at once (rows are independent of the recurrence; not so for partial sampling,
+    //    whose soft row is the next step's input: there steps 1-2 run inside the time loop)
+    if (!ps) {
         dim3 grid(T * B), blk(1024);
         const int64_t* tgt = io->mode == CIC_SAMPLE_TEACHER ? io->pick : nullptr;
 #define GO(RV) hipLaunchKernelGGL((sampler_bwd_kernel<RV>), grid, blk, 0, st, w.logp_all, io->U, bio->d_onehot, w.it_all, \
@@ -549,9 +652,7 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         CIC_LAUNCH_CHECK();
     }
     // 2. logit layer, batched over time: d_out = dlogits W,  dW += dlogits^T out,  db += colsum
-    RUN(gemm_nn(g.dlogits, V1, p->logit_w, H, g.d_out_all, H, T * B, H, V1, false, st));
-    RUN(gemm_tn(g.dlogits, V1, w.out_all, H, gr->logit_w, H, V1, H, T * B, true, st));
-    RUN(cic_colsum_f32(g.dlogits, T * B, V1, V1, gr->logit_b, 1, s));
+    if (!ps) RUN(gemm_nn(g.dlogits, V1, p->logit_w, H, g.d_out_all, H, T * B, H, V1, false, st));
 
     // 3. BPTT over the cell + attention (only dh, dc are carried)
     float* dh_in = g.dh_a;
@@ -559,6 +660,22 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     for (int t = T - 1; t >= 0; --t) {
         const uint8_t* ok = io->out_keep ? io->out_keep + (size_t)t * B * H : nullptr;
         float* dpre = g.dpre_all + (size_t)t * B * 5 * H;
+        if (ps) {
+            float* dl = g.dlogits + (size_t)t * B * V1;
+            const int rec = t + 1 < T ? 1 : 0;
+            // d soft_raw[t] from the next step's input: d xpre[t+1] embed[0:V+1]^T         (AttModel.py:395-397)
+            if (rec) RUN(gemm_nt(g.dx_all + (size_t)(t + 1) * B * E, E, p->embed_w, E, dl, V1, B, V1, E, nullptr, false, false, st));
+            dim3 grid(B), blk(1024);
+#define GO(RV) hipLaunchKernelGGL((sampler_ps_bwd_kernel<RV>), grid, blk, 0, st, w.logp_all + (size_t)t * B * V1,          \
+                                  io->U ? io->U + (size_t)(t + 1) * B * V1 : nullptr,                                      \
+                                  bio->d_onehot ? bio->d_onehot + (size_t)t * B * V1 : nullptr, dl, rec,                   \
+                                  w.it_all + (size_t)(t + 1) * B, io->seq, bio->dslp, io->L, t, io->mode, io->temp, T, V1)
+            if (V1 <= 4096) GO(1); else if (V1 <= 12288) GO(3); else if (V1 <= 32768) GO(8);
+            else { cic_set_error("vocabulary too large"); return 1; }
+#undef GO
+            CIC_LAUNCH_CHECK();
+            RUN(gemm_nn(dl, V1, p->logit_w, H, g.d_out_all + (size_t)t * B * H, H, B, H, V1, false, st));
+        }
         hipLaunchKernelGGL(cell_bwd_kernel, dim3(cic_cdiv(B * (H / 4), 256)), dim3(256), 0, st,
                            w.pre_all + (size_t)t * B * 5 * H, w.c_all + (size_t)t * B * H,
                            w.c_all + (size_t)(t + 1) * B * H, g.d_out_all + (size_t)t * B * H, dh_in, g.dc, ok, scale,
@@ -604,7 +721,21 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
                          dh_out, H, B, H, false, st));
             float* tmp = dh_in; dh_in = dh_out; dh_out = tmp;
         }
+        if (ps) {
+            // d xt = dpre i2h.W, then back through relu_dropout to d xpre (in place)          (AttModel.py:396-397)
+            float* dx = g.dx_all + (size_t)t * B * E;
+            RUN(gemm_nn(dpre, 5 * H, p->i2h_w, E, dx, E, B, E, 5 * H, false, st));
+            if (t >= 1) {
+                const int64_t n4 = (int64_t)B * E / 4;
+                hipLaunchKernelGGL(relu_keep_bwd_kernel, dim3(cic_cdiv(n4, 256)), dim3(256), 0, st, dx,
+                                   io->xpre + (size_t)t * B * E, io->x_keep ? io->x_keep + (size_t)t * B * E : nullptr,
+                                   scale, dx, n4);
+                CIC_LAUNCH_CHECK();
+            }
+        }
     }
+    RUN(gemm_tn(g.dlogits, V1, w.out_all, H, gr->logit_w, H, V1, H, T * B, true, st));
+    RUN(cic_colsum_f32(g.dlogits, T * B, V1, V1, gr->logit_b, 1, s));
     // 4. weight gradients of the recurrent part, batched over time
     RUN(gemm_tn(g.dpre_all, 5 * H, w.x_all, E, gr->i2h_w, E, 5 * H, E, T * B, true, st));
     RUN(gemm_tn(g.dpre_all, 5 * H, w.h_all, H, gr->h2h_w, H, 5 * H, H, T * B, true, st));
@@ -615,12 +746,16 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     RUN(gemm_tn(g.d_att_h_all, A, w.h_all, H, gr->h2att_w, H, A, H, T * B, true, st));
     RUN(cic_colsum_f32(g.d_att_h_all, T * B, A, A, gr->h2att_b, 1, s));
     // token embedding: dx = dpre i2h.W, scattered into the embedding rows
-    RUN(gemm_nn(g.dpre_all, 5 * H, p->i2h_w, E, g.dx_all, E, T * B, E, 5 * H, false, st));
+    if (!ps) RUN(gemm_nn(g.dpre_all, 5 * H, p->i2h_w, E, g.dx_all, E, T * B, E, 5 * H, false, st));
     {
-        const int64_t n = (int64_t)T * B * E;
+        // partial sampling: only step 0 reads an embedding row (<bos>); steps >= 1 used soft_raw[t-1] @ embed
+        const int rows = ps ? B : T * B;
+        const int64_t n = (int64_t)rows * E;
         hipLaunchKernelGGL(embed_bwd_kernel, dim3(cic_cdiv(n, 256)), dim3(256), 0, st, p->embed_w, w.it_all, io->x_keep,
-                           scale, g.dx_all, gr->embed_w, T * B, E);
+                           scale, g.dx_all, gr->embed_w, rows, E);
         CIC_LAUNCH_CHECK();
+        if (ps && T > 1)
+            RUN(gemm_tn(io->soft_raw, V1, g.dx_all + (size_t)B * E, E, gr->embed_w, E, V1, E, (T - 1) * B, true, st));
     }
     // 5. attention features: d att, d p_att, d alpha_net in one pass over p_att
     {

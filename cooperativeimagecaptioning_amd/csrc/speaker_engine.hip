@@ -101,7 +101,9 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     CIC_REQUIRE(dp && p && io && ws);
     const cic_speaker_dims& d = *dp;
     if (int rc = check_dims(d)) return rc;
-    CIC_REQUIRE(io->mode >= CIC_SAMPLE_GREEDY && io->mode <= CIC_SAMPLE_TEACHER);
+    CIC_REQUIRE(io->mode >= CIC_SAMPLE_GREEDY && io->mode <= CIC_SAMPLE_MULTINOMIAL_PS);
+    const bool ps = io->mode == CIC_SAMPLE_GUMBEL_PS || io->mode == CIC_SAMPLE_MULTINOMIAL_PS;
+    CIC_REQUIRE(!ps || (io->soft_raw && io->xpre && io->soft_out));
     CIC_REQUIRE(io->att_pre && io->seq && io->slp && io->L);
     SpkWs w = spk_carve(d, ws);
     CIC_REQUIRE(ws_bytes >= w.bytes);
@@ -137,8 +139,15 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         float* logp = w.logp_all + (size_t)t * B * V1;
         const uint8_t* xk = io->x_keep ? io->x_keep + (size_t)t * B * E : nullptr;
         const uint8_t* ok = io->out_keep ? io->out_keep + (size_t)t * B * H : nullptr;
-        // xt = embed(it)                                                   (:399)
-        RUN(cic_embed_fwd(p->embed_w, w.it_all + (size_t)t * B, xk, xk ? p_drop : 0.f, x, B, E, s));
+        if (ps && t >= 1) {
+            // xt = relu_dropout(soft_vec @ embed.weight)                   (:395-397), soft_vec un-masked
+            float* xp = io->xpre + (size_t)t * B * E;
+            RUN(gemm_nn(io->soft_raw + (size_t)(t - 1) * B * V1, V1, p->embed_w, E, xp, E, B, E, V1, false, st));
+            RUN(cic_relu_keep_fwd(xp, xk, xk ? p_drop : 0.f, x, (int64_t)B * E, st));
+        } else {
+            // xt = embed(it)                                               (:399)
+            RUN(cic_embed_fwd(p->embed_w, w.it_all + (size_t)t * B, xk, xk ? p_drop : 0.f, x, B, E, s));
+        }
         // attention                                                        (:465-489)
         RUN(gemm_nt(h, H, p->h2att_w, H, att_h, A, B, A, H, p->h2att_b, false, false, st));
         CIC_PROF(CIC_PROF_ATTN_FWD, st,
@@ -158,6 +167,10 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         a.mode = io->mode; a.temp = io->temp;
         a.U = io->U ? io->U + (size_t)(t + 1) * B * V1 : nullptr; a.ldu = V1;
         a.pick = io->pick ? io->pick + (size_t)(t + 1) * B : nullptr;
+        a.soft = ps ? io->soft_raw + (size_t)t * B * V1 : nullptr;
+        a.ld_soft = V1;
+        a.ps_u = (ps && io->ps_u) ? io->ps_u + (size_t)(t + 1) * B : nullptr;
+        a.ps_prob = io->ps_prob;
         a.ss_u = io->ss_u ? io->ss_u + (size_t)(t + 1) * B : nullptr;
         a.ss_prob = io->ss_prob;
         a.ss_pick = io->ss_pick ? io->ss_pick + (size_t)(t + 1) * B : nullptr;
@@ -175,6 +188,7 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     } else {
         RUN(cic_finalize_len(w.any_unf, T, io->L, s));
     }
+    if (ps) RUN(cic_soft_mask(io->soft_raw, io->seq, io->L, io->soft_out, T, B, V1, st));
 #undef RUN
     return 0;
 }

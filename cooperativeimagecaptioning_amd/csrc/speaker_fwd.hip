@@ -317,6 +317,33 @@ __global__ __launch_bounds__(256) void apply_keep_kernel(const float* __restrict
     reinterpret_cast<f32x4*>(y)[idx] = v;
 }
 
+// x = dropout(relu(xpre))  — self.relu_dropout on soft_vec @ embed (models/AttModel.py:77-78,396-397)
+__global__ __launch_bounds__(256) void relu_keep_fwd_kernel(const float* __restrict__ xpre, const uint8_t* __restrict__ keep,
+                                                            float scale, float* __restrict__ x, int64_t n4) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n4) return;
+    f32x4 v = reinterpret_cast<const f32x4*>(xpre)[idx];
+    uint32_t kp = 0x01010101u;
+    if (keep) kp = *reinterpret_cast<const uint32_t*>(keep + idx * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float r = fmaxf(v[e], 0.f);
+        v[e] = keep ? r * ((float)((kp >> (8 * e)) & 0xffu) * scale) : r;
+    }
+    reinterpret_cast<f32x4*>(x)[idx] = v;
+}
+
+// soft_out[t,b,:] = unfinished ? soft_raw[t,b,:] : one-hot(EOS = 0)    (models/AttModel.py:428-432)
+__global__ __launch_bounds__(256) void soft_mask_kernel(const float* __restrict__ soft_raw, const int32_t* __restrict__ seq,
+                                                        const int32_t* __restrict__ Lp, float* __restrict__ soft_out, int T,
+                                                        int B, int V1) {
+    const int row = blockIdx.x, t = row / B, b = row % B;
+    const bool unf = t < *Lp && seq[(size_t)b * T + t] > 0;
+    const float* src = soft_raw + (size_t)row * V1;
+    float* dst = soft_out + (size_t)row * V1;
+    for (int c = threadIdx.x; c < V1; c += 256) dst[c] = unf ? src[c] : (c == 0 ? 1.0f : 0.0f);
+}
+
 // ---------------------------------------------------------------------------------------
 // K5b/K6 row kernel: log-softmax over the vocabulary + sampler + EOS bookkeeping
 //   (models/AttModel.py:328-365,401-434,438-444; models/gumbel.py:6-30; models/multinomial.py:4-27)
@@ -446,9 +473,10 @@ __global__ __launch_bounds__(SNW * 64) void logsoftmax_sample_kernel(cic_sampler
     // ---- choose the token -------------------------------------------------------------
     const float* urow = a.U ? a.U + (size_t)b * a.ldu : nullptr;
     const bool ss_on = a.mode == CIC_SAMPLE_TEACHER && a.ss_u && a.ss_prob > 0.f;
+    const bool gumbel_mode = a.mode == CIC_SAMPLE_GUMBEL_ST || a.mode == CIC_SAMPLE_GUMBEL_PS;
     const bool use_noise = a.mode == CIC_SAMPLE_TEACHER
                                ? (ss_on && !a.ss_pick)
-                               : ((a.mode != CIC_SAMPLE_GREEDY) && !(a.pick && a.mode != CIC_SAMPLE_GUMBEL_ST));
+                               : ((a.mode != CIC_SAMPLE_GREEDY) && !(a.pick && !gumbel_mode));
     const float inv_t = 1.0f / a.temp;
     ArgMax best = {-INFINITY, 0x7fffffff};
     float z[RV][4];
@@ -462,7 +490,7 @@ __global__ __launch_bounds__(SNW * 64) void logsoftmax_sample_kernel(cic_sampler
             if (q < nq && col < V1) {
                 if (a.mode == CIC_SAMPLE_GREEDY) {
                     zz = x[r][e];
-                } else if (a.mode == CIC_SAMPLE_GUMBEL_ST) {
+                } else if (gumbel_mode) {
                     zz = (x[r][e] + gumbel_from_u(urow[col])) * inv_t;           // gumbel.py:13-15
                 } else {   // multinomial flavours: Gumbel-max draw from softmax(logp / temp)
                     zz = x[r][e] * inv_t;
@@ -481,7 +509,7 @@ __global__ __launch_bounds__(SNW * 64) void logsoftmax_sample_kernel(cic_sampler
         const int drawn = a.ss_pick ? (int)a.ss_pick[b] : best.i;
         it_feed = (ss_on && a.ss_u[b] < a.ss_prob) ? drawn : target;   // AttModel.py:119-128
         it = target;                                     // the loss gathers log p(target)
-    } else if (a.pick && a.mode != CIC_SAMPLE_GREEDY && a.mode != CIC_SAMPLE_GUMBEL_ST) {
+    } else if (a.pick && a.mode != CIC_SAMPLE_GREEDY && !gumbel_mode) {
         it = (int)a.pick[b];
     }
 
@@ -494,11 +522,12 @@ __global__ __launch_bounds__(SNW * 64) void logsoftmax_sample_kernel(cic_sampler
             if (4 * (tid + NT * r) + e == it) slp_part = x[r][e];
     const float slp = block_sum(slp_part, shf);
     float v = 1.0f;
-    if (a.mode == CIC_SAMPLE_GUMBEL_ST || a.mode == CIC_SAMPLE_MULTINOMIAL_ST) {
+    float zm = 0.f, s2 = 1.f;
+    if (gumbel_mode || a.mode == CIC_SAMPLE_MULTINOMIAL_ST) {
         // y = softmax(z) with z = (logp+g)/tau  (gumbel)  or  logp/tau  (multinomial.py:10-15)
-        float zm, zi = -INFINITY;
-        float s2 = 0.f;
-        if (a.mode == CIC_SAMPLE_GUMBEL_ST) {
+        float zi = -INFINITY;
+        s2 = 0.f;
+        if (gumbel_mode) {
             zm = best.v;
 #pragma unroll
             for (int r = 0; r < RV; ++r)
@@ -527,6 +556,27 @@ __global__ __launch_bounds__(SNW * 64) void logsoftmax_sample_kernel(cic_sampler
         zi = block_max(zi, shf);
         const float y = __expf(zi - zm) / s2;
         v = (1.0f - y) + y;    // (y_hard - y).detach() + y at the arg-max entry, gumbel.py:28
+    }
+    if (a.soft) {
+        // partial sampling (gumbel_softmax.py:30-41, multinomial_soft.py:23-33): rows drawn with u < prob get the
+        // straight-through row (exactly 0 off the token), the others the distribution itself
+        const bool hard = a.ps_u && a.ps_prob > 0.f && a.ps_u[b] < a.ps_prob;
+        float* srow = a.soft + (size_t)b * a.ld_soft;
+        const float inv_s = 1.0f / s2;
+        float v_it = 0.f;
+#pragma unroll
+        for (int r = 0; r < RV; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int col = 4 * (tid + NT * r) + e;
+                if ((tid + NT * r) < nq && col < V1) {
+                    const float yj = gumbel_mode ? __expf(z[r][e] - zm) * inv_s : __expf(x[r][e] * inv_t);
+                    const float o = hard ? (col == it ? (1.0f - yj) + yj : 0.f) : yj;
+                    srow[col] = o;
+                    if (col == it) v_it = o;
+                }
+            }
+        v = block_sum(v_it, shf);
     }
 
     // ---- EOS bookkeeping (AttModel.py:401-434) -----------------------------------------
@@ -690,15 +740,32 @@ extern "C" int cic_apply_keep(const float* x, const uint8_t* keep, float p_drop,
     return 0;
 }
 
+int cic_relu_keep_fwd(const float* xpre, const uint8_t* keep, float p_drop, float* x, int64_t n, hipStream_t st) {
+    CIC_REQUIRE(xpre && x && n > 0 && (n & 3) == 0);
+    hipLaunchKernelGGL(relu_keep_fwd_kernel, dim3(cic_cdiv(n / 4, 256)), dim3(256), 0, st, xpre, keep, 1.0f / (1.0f - p_drop),
+                       x, n / 4);
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+int cic_soft_mask(const float* soft_raw, const int32_t* seq, const int32_t* L, float* soft_out, int T, int B, int V1,
+                  hipStream_t st) {
+    hipLaunchKernelGGL(soft_mask_kernel, dim3(T * B), dim3(256), 0, st, soft_raw, seq, L, soft_out, T, B, V1);
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int cic_logsoftmax_sample(const cic_sampler_args* a, cic_stream_t s) {
     CIC_REQUIRE(a && a->logits && a->B > 0 && a->V1 > 0 && a->ld >= a->V1);
     if (a->mode != CIC_SAMPLE_NONE) {
         CIC_REQUIRE(a->unfinished && a->it_next && a->seq && a->slp && a->any_unfinished && a->step >= 1);
         CIC_REQUIRE(a->temp > 0.f);
-        const bool needs_u = a->mode == CIC_SAMPLE_GUMBEL_ST ||
-                             ((a->mode == CIC_SAMPLE_MULTINOMIAL || a->mode == CIC_SAMPLE_MULTINOMIAL_ST) && !a->pick) ||
+        const bool needs_u = a->mode == CIC_SAMPLE_GUMBEL_ST || a->mode == CIC_SAMPLE_GUMBEL_PS ||
+                             ((a->mode == CIC_SAMPLE_MULTINOMIAL || a->mode == CIC_SAMPLE_MULTINOMIAL_ST ||
+                               a->mode == CIC_SAMPLE_MULTINOMIAL_PS) && !a->pick) ||
                              (a->mode == CIC_SAMPLE_TEACHER && a->ss_u && a->ss_prob > 0.f && !a->ss_pick);
         CIC_REQUIRE(a->mode != CIC_SAMPLE_TEACHER || a->pick);
+        const bool ps = a->mode == CIC_SAMPLE_GUMBEL_PS || a->mode == CIC_SAMPLE_MULTINOMIAL_PS;
+        CIC_REQUIRE(!ps || (a->soft && a->ld_soft >= a->V1));
         CIC_REQUIRE(!needs_u || (a->U && a->ldu >= a->V1));
     }
     dim3 grid(a->B), blk(1024);

@@ -81,8 +81,9 @@ def speaker_att_embed_fwd(dims, params, att_raw, att_pre=None):
 
 def speaker_decode_fwd(dims, params, att_pre, mode, temp=1.0, att_masks=None, att_keep=None, x_keep=None,
                        out_keep=None, U=None, pick=None, decoding_constraint=0, want_stv=False, ws=None,
-                       first_token=None, out=None, ss_u=None, ss_prob=0.0, ss_pick=None):
-    """-> dict(seq i32[B,T], slp f32[B,T], stv f32[B,T]|None, L i32[1], ws)."""
+                       first_token=None, out=None, ss_u=None, ss_prob=0.0, ss_pick=None, ps_u=None, ps_prob=0.0):
+    """-> dict(seq i32[B,T], slp f32[B,T], stv f32[B,T]|None, L i32[1], ws); partial-sampling modes add
+    soft f32[T,B,V+1] (the caption rows handed to the listener) and the saved soft_raw / xpre."""
     dev = att_pre.device
     B, T = dims.B, dims.T
     nbytes = lib.cic_speaker_decode_ws_bytes(C.byref(dims))
@@ -94,6 +95,13 @@ def speaker_decode_fwd(dims, params, att_pre, mode, temp=1.0, att_masks=None, at
                    L=torch.zeros(1, dtype=torch.int32, device=dev))
     out['ws'] = ws
     io = DecodeIO()
+    if mode in (_lib.SAMPLE_GUMBEL_PS, _lib.SAMPLE_MULTINOMIAL_PS):
+        V1 = dims.V + 1
+        for k, shape in (('soft', (T, B, V1)), ('soft_raw', (T, B, V1)), ('xpre', (T, B, dims.E))):
+            if out.get(k) is None:
+                out[k] = torch.empty(shape, device=dev)
+        io.soft_out, io.soft_raw, io.xpre = _p(out['soft']), _p(out['soft_raw']), _p(out['xpre'])
+        io.ps_u, io.ps_prob = _p(ps_u), float(ps_prob)
     io.mode, io.temp, io.decoding_constraint = mode, float(temp), int(decoding_constraint)
     io.att_pre, io.att_masks = _p(att_pre), _p(att_masks)
     io.att_keep, io.x_keep, io.out_keep = _p(att_keep), _p(x_keep), _p(out_keep)
@@ -103,7 +111,7 @@ def speaker_decode_fwd(dims, params, att_pre, mode, temp=1.0, att_masks=None, at
     check(lib.cic_speaker_decode_fwd(C.byref(dims), C.byref(params), C.byref(io), ws.data_ptr(), ws.numel(),
                                      stream()), 'cic_speaker_decode_fwd')
     out['io'] = io
-    out['_keep'] = (att_pre, att_masks, att_keep, x_keep, out_keep, U, pick, first_token, ss_u, ss_pick)   # alive until the backward call
+    out['_keep'] = (att_pre, att_masks, att_keep, x_keep, out_keep, U, pick, first_token, ss_u, ss_pick, ps_u)   # alive until the backward call
     return out
 
 
@@ -140,7 +148,7 @@ def listener_params(tensors):
 
 
 def listener_fwd(dims, params, fc_feats, labels=None, masks=None, seq=None, stv=None, L=None,
-                 only_one_retrieval='off', want_emb=False, ws=None, out=None):
+                 only_one_retrieval='off', want_emb=False, ws=None, out=None, soft=None):
     """-> dict(loss_rows f32[B], loss_sum f32[1], img_emb, cap_emb, ws, io)."""
     dev = fc_feats.device
     nbytes = lib.cic_listener_ws_bytes(C.byref(dims))
@@ -153,14 +161,14 @@ def listener_fwd(dims, params, fc_feats, labels=None, masks=None, seq=None, stv=
     out['ws'] = ws
     io = ListenerIO()
     io.fc_feats, io.labels, io.masks = _p(fc_feats), _p(labels), _p(masks)
-    io.seq, io.stv, io.L = _p(seq), _p(stv), _p(L)
+    io.seq, io.stv, io.L, io.soft = _p(seq), _p(stv), _p(L), _p(soft)
     io.only_one_retrieval = ONLY_ONE[only_one_retrieval]
     io.loss_rows, io.loss_sum = _p(out['loss_rows']), _p(out['loss_sum'])
     io.img_emb_out, io.cap_emb_out = _p(out['img_emb']), _p(out['cap_emb'])
     check(lib.cic_listener_fwd(C.byref(dims), C.byref(params), C.byref(io), ws.data_ptr(), ws.numel(), stream()),
           'cic_listener_fwd')
     out['io'] = io
-    out['_keep'] = (fc_feats, labels, masks, seq, stv, L)     # keep inputs alive for the backward call
+    out['_keep'] = (fc_feats, labels, masks, seq, stv, L, soft)     # keep inputs alive for the backward call
     return out
 
 

@@ -182,10 +182,12 @@ class AlternatingJointModel(nn.Module):
                 self._loss['retrieval_sc_loss'] = sc.detach()[0]
                 self._loss['retrieval_loss'] = gen.loss_rows.sum().detach()
                 self._loss['retrieval_loss_greedy'] = base.sum().detach()
-            elif rr in ('gumbel', 'multinomial'):                      # st_and_ps_methods :343-376
-                mode = 'gumbel' if rr == 'gumbel' else 'multinomial_st'
-                temp = cg.gumbel_temp if rr == 'gumbel' else cg.multinomial_temp
-                sample = cg.decode(att_feats, att_masks, mode, temp, att_pre=att_pre, grad=spk_grad)
+            elif rr in ('gumbel', 'multinomial', 'gumbel_softmax', 'multinomial_soft'):   # st_and_ps_methods :343-376
+                mode = {'gumbel': 'gumbel', 'multinomial': 'multinomial_st', 'gumbel_softmax': 'gumbel_ps',
+                        'multinomial_soft': 'multinomial_ps'}[rr]
+                temp = cg.gumbel_temp if rr in ('gumbel', 'gumbel_softmax') else cg.multinomial_temp
+                ps_prob = {'gumbel_softmax': cg.prob_gumbel_softmax, 'multinomial_soft': cg.prob_multinomial_soft}.get(rr, 0.0)
+                sample = cg.decode(att_feats, att_masks, mode, temp, att_pre=att_pre, grad=spk_grad, ps_prob=ps_prob)
                 gen = vse.run(fc_feats, decode=sample, only_one_retrieval=oor, slot=2)
                 vse._loss['contrastive'] = gen.loss_sum.detach()[0]
                 terms.append((dw, gen.loss_sum))
@@ -197,8 +199,12 @@ class AlternatingJointModel(nn.Module):
                 if spk_grad or lst_grad:
                     bwd_steps.append(bwd_listener)
                 sample.d_onehot = d_onehot
+                if sample.soft is not None and spk_grad:
+                    # partial sampling: the CIDEr term below draws its own captions (:378-389), so this decode's
+                    # backward (listener gradient only) is queued here
+                    bwd_steps.append(lambda go, ps=sample, d=d_onehot: cg.decode_backward(ps, d_onehot=d))
             else:
-                raise NotImplementedError(f"retrieval_reward='{rr}' (partial sampling) is not on the MI355X path yet")
+                raise ValueError(f'unknown retrieval_reward {rr!r}')
         if ciw:                                                        # CIDEr loss :490-503
             if sample is None or rr in ('multinomial_soft', 'gumbel_softmax'):
                 sample = cg.decode(att_feats, att_masks, 'multinomial', 1.0, att_pre=att_pre, grad=spk_grad,
@@ -218,6 +224,8 @@ class AlternatingJointModel(nn.Module):
             self._loss['avg_reward'] = coef.mean().detach()
             self._loss['cider_greedy'] = rw['stats'][1].detach()
             self._loss['loss_cider'] = lc.detach()[0]
+        if sample is not None and sample.soft is not None:
+            sample = None            # a partial-sampling decode without a CIDEr term: already queued above
         if sample is not None and spk_grad and (dslp is not None or getattr(sample, 'd_onehot', None) is not None):
             def bwd_speaker(go, sample=sample, dslp=dslp):
                 cg.decode_backward(sample, d_onehot=getattr(sample, 'd_onehot', None),

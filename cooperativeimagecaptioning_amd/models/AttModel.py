@@ -44,7 +44,8 @@ class Att2in2Core(nn.Module):
 
 MODES = {'greedy': _lib.SAMPLE_GREEDY, 'multinomial': _lib.SAMPLE_MULTINOMIAL,
          'gumbel': _lib.SAMPLE_GUMBEL_ST, 'multinomial_st': _lib.SAMPLE_MULTINOMIAL_ST,
-         'teacher': _lib.SAMPLE_TEACHER}
+         'teacher': _lib.SAMPLE_TEACHER, 'gumbel_ps': _lib.SAMPLE_GUMBEL_PS,
+         'multinomial_ps': _lib.SAMPLE_MULTINOMIAL_PS}
 
 
 class DecodeResult:
@@ -54,6 +55,7 @@ class DecodeResult:
     def __init__(self, fwd, mode, dims, params, att_raw, grad):
         self.fwd, self.mode, self.dims, self.params, self.att_raw, self.grad = fwd, mode, dims, params, att_raw, grad
         self.seq, self.slp, self.stv, self.L = fwd['seq'], fwd['slp'], fwd['stv'], fwd['L']
+        self.soft = fwd.get('soft')       # [T,B,V+1] partial-sampling caption rows (time-major) or None
 
 
 class AttModel(nn.Module):
@@ -126,7 +128,7 @@ class AttModel(nn.Module):
         return engine.speaker_att_embed_fwd(dims, params, att_raw, att_pre)
 
     def decode(self, att_feats, att_masks, mode, temp=1.0, att_pre=None, grad=False, T=None, pick=None,
-               first_token=None, decoding_constraint=None, tag='sample', want_stv=None, ss_prob=0.0):
+               first_token=None, decoding_constraint=None, tag='sample', want_stv=None, ss_prob=0.0, ps_prob=0.0):
         """One AttModel.sample / AttModel.forward pass on the device -> DecodeResult."""
         self._check_inputs(att_feats)
         fl = self.flat()
@@ -145,9 +147,11 @@ class AttModel(nn.Module):
         p = self.drop_prob_lm if self.training else 0.0
         dims.p_drop = p
         ss = mode == 'teacher' and ss_prob > 0.0
+        ps = mode in ('gumbel_ps', 'multinomial_ps')
         nz = self.noise.decode_noise(tag, B, K, self.rnn_size, self.input_encoding_size, self.vocab_size + 1, T, p,
-                                     need_u=(mode == 'gumbel') or (mode in ('multinomial', 'multinomial_st') and pick is None) or ss,
-                                     device=att_raw.device, need_ss=ss)
+                                     need_u=(mode in ('gumbel', 'gumbel_ps')) or
+                                     (mode in ('multinomial', 'multinomial_st', 'multinomial_ps') and pick is None) or ss,
+                                     device=att_raw.device, need_ss=ss, need_ps=ps and ps_prob > 0.0)
         ss_pick = None
         if mode == 'teacher':
             ss_pick = nz.get('pick') if ss else None     # recorded scheduled-sampling draws (tests)
@@ -162,6 +166,11 @@ class AttModel(nn.Module):
                    slp=self._buf.get((ws_key, 'slp'), (B, T), torch.float32, dev, fill=0),
                    stv=self._buf.get((ws_key, 'stv'), (B, T), torch.float32, dev, fill=1) if want_stv else None,
                    L=self._buf.get((ws_key, 'L'), (1,), torch.int32, dev, fill=0))
+        if ps:
+            V1 = self.vocab_size + 1
+            out.update(soft=self._buf.get((ws_key, 'soft'), (T, B, V1), torch.float32, dev),
+                       soft_raw=self._buf.get((ws_key, 'soft_raw'), (T, B, V1), torch.float32, dev),
+                       xpre=self._buf.get((ws_key, 'xpre'), (T, B, self.input_encoding_size), torch.float32, dev))
         if att_masks is not None:
             att_masks = self._buf.stage('att_masks', att_masks, torch.float32)
         if pick is not None:
@@ -173,7 +182,8 @@ class AttModel(nn.Module):
                                         pick, self.decoding_constraint if decoding_constraint is None else decoding_constraint,
                                         want_stv=want_stv, ws=self._ws.get(ws_key), first_token=first_token, out=out,
                                         ss_u=nz.get('ss_u') if ss else None, ss_prob=ss_prob if ss else 0.0,
-                                        ss_pick=ss_pick)
+                                        ss_pick=ss_pick, ps_u=nz.get('ps_u') if ps else None,
+                                        ps_prob=ps_prob if ps else 0.0)
         self._ws[ws_key] = fwd['ws']
         return DecodeResult(fwd, mode, dims, params, att_raw, grad)
 
@@ -223,9 +233,14 @@ class AttModel(nn.Module):
             res = self.decode(att_feats, att_masks, 'gumbel', self.gumbel_temp, decoding_constraint=dc)
         elif self.retrieval_reward == 'multinomial':
             res = self.decode(att_feats, att_masks, 'multinomial_st', self.multinomial_temp, decoding_constraint=dc)
+        elif self.retrieval_reward == 'gumbel_softmax':
+            res = self.decode(att_feats, att_masks, 'gumbel_ps', self.gumbel_temp, decoding_constraint=dc,
+                              ps_prob=self.prob_gumbel_softmax)
+        elif self.retrieval_reward == 'multinomial_soft':
+            res = self.decode(att_feats, att_masks, 'multinomial_ps', self.multinomial_temp, decoding_constraint=dc,
+                              ps_prob=self.prob_multinomial_soft)
         else:
-            raise NotImplementedError(f"retrieval_reward='{self.retrieval_reward}' (partial sampling) is not on the "
-                                      f"MI355X path yet")
+            raise ValueError(f'unknown retrieval_reward {self.retrieval_reward!r}')
         L = int(res.L.item())                      # the one host sync of a decode (the reference syncs every step)
         if L == 0:
             raise ValueError('every caption ended at the first step (the reference raises here too: '
@@ -235,6 +250,10 @@ class AttModel(nn.Module):
         stv = res.stv[:, :L].clone() if res.stv is not None else None
         if sample_max or plain:
             return seq, slp
+        if res.soft is not None:          # soft rows, with the reference's trailing zero <bos> column (:372-378)
+            soft = torch.zeros(seq.shape[0], L, self.vocab_size + 2, device=seq.device)
+            soft[:, :, :self.vocab_size + 1] = res.soft[:L].transpose(0, 1)
+            return seq, soft, slp
         one_hot = torch.zeros(seq.shape[0], L, self.vocab_size + 2, device=seq.device)
         one_hot.scatter_(2, seq.unsqueeze(2), stv.unsqueeze(2))
         return seq, one_hot, slp

@@ -119,7 +119,7 @@ class VSEFCModel(nn.Module):
             key = ('gen', B, slot)
             fwd = engine.listener_fwd(dims, params, fc, seq=decode.seq, stv=decode.stv, L=decode.L,
                                       only_one_retrieval=only_one_retrieval, want_emb=want_emb, ws=self._ws.get(key),
-                                      out=outs(key, dims.J))
+                                      out=outs(key, dims.J), soft=getattr(decode, 'soft', None))
         else:
             if labels.dim() > 2:
                 raise NotImplementedError('dense one-hot / soft caption input (VSEFCModel.py:102-104) is only '

@@ -32,7 +32,7 @@ class NoiseSource:
             t = self._buf[k] = torch.empty(shape, dtype=dtype, device=device)
         return t
 
-    def decode_noise(self, tag, B, K, H, E, V1, T, p, need_u, device, need_ss=False):
+    def decode_noise(self, tag, B, K, H, E, V1, T, p, need_u, device, need_ss=False, need_ps=False):
         if self.override is not None:
             ov = self.override.get(tag)
             if ov is None:
@@ -69,4 +69,8 @@ class NoiseSource:
             su = self._get((tag, 'ss_u'), (T + 1, B), torch.float32, device)
             ops.uniform_(su, self.seed, self._next_offset())
             out['ss_u'] = su
+        if need_ps:
+            pu = self._get((tag, 'ps_u'), (T + 1, B), torch.float32, device)
+            ops.uniform_(pu, self.seed, self._next_offset())
+            out['ps_u'] = pu
         return out

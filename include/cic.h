@@ -127,6 +127,8 @@ enum {
     CIC_SAMPLE_MULTINOMIAL = 2,    /* it ~ softmax(logp/temp) (AttModel.py:332-343); Gumbel-max draw or pick[] */
     CIC_SAMPLE_GUMBEL_ST = 3,      /* models/gumbel.py:17-30 */
     CIC_SAMPLE_MULTINOMIAL_ST = 4, /* models/multinomial.py:4-27 */
+    CIC_SAMPLE_GUMBEL_PS = 6,      /* partial sampling, models/gumbel_softmax.py:17-42 */
+    CIC_SAMPLE_MULTINOMIAL_PS = 7, /* partial sampling, models/multinomial_soft.py:5-35 (exp(logp/tau), unnormalised) */
     CIC_SAMPLE_TEACHER = 5         /* teacher forcing (AttModel.forward :116-141): slp = logp[pick] (the target);
                                       next input = pick, or with scheduled sampling (:118-129) a draw from
                                       softmax(logp) for the rows whose ss_u < ss_prob */
@@ -142,6 +144,10 @@ typedef struct {
     const float* ss_u;    /* [B] scheduled-sampling uniforms (teacher mode) or NULL */
     float ss_prob;        /* scheduled-sampling probability */
     const int64_t* ss_pick; /* [B] externally drawn scheduled-sampling tokens, or NULL (Gumbel-max draw from U) */
+    float* soft;          /* PS modes: out [B, ld_soft] the soft / straight-through row (first V1 columns), else NULL */
+    int ld_soft;
+    const float* ps_u;    /* PS modes: [B] row uniforms; rows with ps_u < ps_prob get the hard (straight-through) row */
+    float ps_prob;        /* prob_gumbel_softmax / prob_multinomial_soft */
     int decoding_constraint; /* != 0: suppress the previously appended token seq[b, step-2] (step >= 2) */
     int step;             /* reference loop iteration t >= 1 whose input token is chosen */
     int32_t* unfinished;  /* [B] in/out */
@@ -198,6 +204,13 @@ typedef struct {
     const int64_t* pick;      /* [T+1,B] row t: externally chosen tokens (multinomial modes) or NULL.
                                  Teacher forcing (AttModel.forward, :103-148) = CIC_SAMPLE_TEACHER with
                                  pick[t] = labels[:, t]: slp then holds log p(target) of every step. */
+    /* partial-sampling modes (CIC_SAMPLE_*_PS): the recurrent input of step t>=1 is relu_dropout(soft @ embed)
+     * (AttModel.py:395-397) and the caption handed to the listener is the soft row */
+    const float* ps_u;        /* [T+1,B] row uniforms (row t: the draw made when choosing the input of step t) */
+    float ps_prob;
+    float* soft_raw;          /* scratch/out [T,B,V+1]: un-masked soft rows (saved for the backward pass) */
+    float* xpre;              /* scratch/out [T,B,E]: soft @ embed before ReLU/dropout (saved for the backward pass) */
+    float* soft_out;          /* out [T,B,V+1]: soft rows with finished rows replaced by the EOS one-hot (:428-432) */
     const float* ss_u;        /* [T+1,B] scheduled-sampling uniforms, row t decides the input of step t (teacher mode) */
     float ss_prob;            /* model.ss_prob (train.py:80-85); 0 = plain teacher forcing */
     const int64_t* ss_pick;   /* [T+1,B] externally drawn scheduled-sampling tokens or NULL */
@@ -219,7 +232,8 @@ int cic_speaker_decode_fwd(const cic_speaker_dims* d, const cic_speaker_params* 
                            void* ws, size_t ws_bytes, cic_stream_t s);
 
 typedef struct {
-    const float* d_onehot;   /* [T,B,V+1] gradient w.r.t. the ST one-hot rows (from cic_listener_bwd) or NULL */
+    const float* d_onehot;   /* [T,B,V+1] gradient w.r.t. the ST one-hot rows / the soft rows io->soft_out (from
+                                cic_listener_bwd) or NULL */
     const float* dslp;       /* [B,T] gradient w.r.t. the sampled log-probs (io->slp) or NULL */
     const cic_speaker_params* grads; /* accumulated into (+=) */
     const float* att_raw;    /* [B,K,D] the raw region features (for the att_embed weight gradient) */
@@ -227,7 +241,10 @@ typedef struct {
 size_t cic_speaker_decode_bwd_ws_bytes(const cic_speaker_dims* d);
 /* autograd of cic_speaker_decode_fwd: straight-through sampler, logit layer, BPTT through
  * Att2in2Core/Attention, embeddings, ctx2att, att_embed.  io must be the struct of the
- * forward call (same noise pointers), ws_fwd its untouched workspace. */
+ * forward call (same noise pointers), ws_fwd its untouched workspace.
+ * Partial-sampling decodes (CIC_SAMPLE_*_PS): d_onehot is the gradient w.r.t. io->soft_out; the soft row
+ * also feeds the next step's input (AttModel.py:395-397), so the sampler and logit-layer backward run
+ * inside the time loop instead of batched over time. */
 int cic_speaker_decode_bwd(const cic_speaker_dims* d, const cic_speaker_params* p, const cic_decode_io* io,
                            const cic_decode_bwd_io* bio, void* ws_fwd, size_t ws_fwd_bytes, void* ws_bwd,
                            size_t ws_bwd_bytes, cic_stream_t s);
@@ -259,6 +276,8 @@ typedef struct {
     const int32_t* seq;       /* [B, T] */
     const float* stv;         /* [B, T] straight-through values or NULL (plain indices) */
     const int32_t* L;         /* [1] */
+    const float* soft;        /* [T,B,V+1] soft caption rows (partial sampling) or NULL: positions 1..T are then embedded
+                                 by the dense product soft @ embed (VSEFCModel.py:102-104) instead of the gather */
     int only_one_retrieval;   /* 0 off, 1 'image', 2 'caption' (VSEFCModel.py:202-207) */
     float* loss_rows;         /* out [B]: per-row loss (whole_batch=True) */
     float* loss_sum;          /* out [1]: scalar loss (whole_batch=False) */

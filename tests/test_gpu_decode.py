@@ -37,12 +37,17 @@ def run_decode(z, mode_name):
     U = T_(nz['gumbel_u']).cuda().contiguous() if 'gumbel_u' in nz else None
     pick = T_(nz['pick']).cuda().contiguous() if 'pick' in nz else None
     mode = dict(greedy=_lib.SAMPLE_GREEDY, multinomial=_lib.SAMPLE_MULTINOMIAL, gumbel_st=_lib.SAMPLE_GUMBEL_ST,
-                multinomial_st=_lib.SAMPLE_MULTINOMIAL_ST)[mode_name]
+                multinomial_st=_lib.SAMPLE_MULTINOMIAL_ST, gumbel_ps=_lib.SAMPLE_GUMBEL_PS,
+                multinomial_ps=_lib.SAMPLE_MULTINOMIAL_PS)[mode_name]
     temp = dict(greedy=1.0, multinomial=float(z.get('opt.temperature', 1.0)), gumbel_st=cfg['gumbel_temp'],
-                multinomial_st=cfg['multinomial_temp'])[mode_name]
+                multinomial_st=cfg['multinomial_temp'], gumbel_ps=cfg['gumbel_temp'],
+                multinomial_ps=cfg['multinomial_temp'])[mode_name]
+    ps = mode_name.endswith('_ps')
+    ps_u = T_(nz['ps_u']).cuda().contiguous() if ps and 'ps_u' in nz else None
+    ps_prob = cfg['prob_gumbel_softmax'] if mode_name == 'gumbel_ps' else cfg['prob_multinomial_soft']
     out = engine.speaker_decode_fwd(dims, params, att_pre, mode, temp, None, keep('att_keep'), keep('x_keep'),
                                     keep('out_keep'), U, pick, cfg['decoding_constraint'],
-                                    want_stv=mode_name.endswith('_st'))
+                                    want_stv=mode_name.endswith('_st'), ps_u=ps_u, ps_prob=ps_prob if ps else 0.0)
     torch.cuda.synchronize()
     return out, cfg
 
@@ -50,7 +55,9 @@ def run_decode(z, mode_name):
 CASES = [('sample_greedy_full', 'greedy'), ('sample_greedy_early', 'greedy'), ('sample_greedy_dropout', 'greedy'),
          ('sample_constraint', 'greedy'), ('sample_multinomial_plain', 'multinomial'),
          ('sample_multinomial_temp', 'multinomial'), ('sample_gumbel_st', 'gumbel_st'),
-         ('sample_gumbel_st_tau', 'gumbel_st'), ('sample_multinomial_st', 'multinomial_st')]
+         ('sample_gumbel_st_tau', 'gumbel_st'), ('sample_multinomial_st', 'multinomial_st'),
+         ('sample_gumbel_ps', 'gumbel_ps'), ('sample_multinomial_ps', 'multinomial_ps'),
+         ('sample_multinomial_ps_tau', 'multinomial_ps')]
 
 
 @pytest.mark.parametrize('name,mode', CASES)
@@ -71,3 +78,12 @@ def test_decode_matches_reference(name, mode):
         np.testing.assert_allclose(out['stv'][:, :L].cpu().numpy(), val.numpy(), atol=1.5e-7)
         nnz = (torch.from_numpy(oh) != 0).sum(2)
         assert int(nnz.max()) == 1
+    if mode.endswith('_ps'):
+        # the reference's soft rows [B, L, V+2]: distributions for the rows drawn soft, straight-through rows
+        # (exact zeros off the token) for the rows drawn hard, the EOS one-hot for finished rows
+        soft = out['soft'][:L].transpose(0, 1).cpu().numpy()
+        ref = z['res1']
+        V1 = soft.shape[2]
+        np.testing.assert_allclose(soft, ref[:, :, :V1], rtol=2e-4, atol=2e-7)
+        np.testing.assert_array_equal(soft == 0, ref[:, :, :V1] == 0)          # same rows are hard / finished
+        assert not ref[:, :, V1:].any()

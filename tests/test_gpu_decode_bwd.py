@@ -34,7 +34,9 @@ def _run(W, cfg, att_raw, noise, mode_name, seed):
     A = W['ctx2att.weight'].shape[0]
     V, T = cfg['vocab_size'], cfg['seq_length']
     p = cfg['drop_prob_lm']
-    rr = {'gumbel_st': 'gumbel', 'multinomial_st': 'multinomial', 'multinomial': 'reinforce'}[mode_name]
+    rr = {'gumbel_st': 'gumbel', 'multinomial_st': 'multinomial', 'multinomial': 'reinforce',
+          'gumbel_ps': 'gumbel_softmax', 'multinomial_ps': 'multinomial_soft'}[mode_name]
+    ps = mode_name.endswith('_ps')
     # ---- oracle with autograd
     P = {k: v.clone().requires_grad_(True) for k, v in W.items()}
     opt = {'sample_max': 0, 'temperature': 1, 'use_one_hot': 0 if rr == 'reinforce' else 1}
@@ -65,12 +67,19 @@ def _run(W, cfg, att_raw, noise, mode_name, seed):
         t = noise[key]
         return (t.to(dt) if dt is not None else t).cuda().contiguous()
     mode = dict(multinomial=_lib.SAMPLE_MULTINOMIAL, gumbel_st=_lib.SAMPLE_GUMBEL_ST,
-                multinomial_st=_lib.SAMPLE_MULTINOMIAL_ST)[mode_name]
-    temp = cfg['gumbel_temp'] if mode_name == 'gumbel_st' else cfg['multinomial_temp'] if mode_name == 'multinomial_st' else 1.0
+                multinomial_st=_lib.SAMPLE_MULTINOMIAL_ST, gumbel_ps=_lib.SAMPLE_GUMBEL_PS,
+                multinomial_ps=_lib.SAMPLE_MULTINOMIAL_PS)[mode_name]
+    temp = (cfg['gumbel_temp'] if mode_name.startswith('gumbel') else
+            cfg['multinomial_temp'] if mode_name in ('multinomial_st', 'multinomial_ps') else 1.0)
+    ps_prob = cfg['prob_gumbel_softmax'] if mode_name == 'gumbel_ps' else cfg['prob_multinomial_soft']
     f = engine.speaker_decode_fwd(dims, params, att_pre, mode, temp, None, nz('att_keep', torch.uint8),
                                   nz('x_keep', torch.uint8), nz('out_keep', torch.uint8), nz('gumbel_u'), nz('pick'),
-                                  0, want_stv=(oh is not None))
+                                  0, want_stv=(oh is not None), ps_u=nz('ps_u') if ps else None,
+                                  ps_prob=ps_prob if ps else 0.0)
     assert int(f['L']) == L
+    if ps:   # the soft rows themselves (time-major here, [B,L,V+2] in the oracle)
+        np.testing.assert_allclose(f['soft'][:L].transpose(0, 1).cpu().numpy(), oh[:, :, :V + 1].detach().numpy(),
+                                   rtol=2e-4, atol=2e-7)
     np.testing.assert_array_equal(f['seq'][:, :L].cpu().numpy(), seq.numpy())
     grads = {k: torch.zeros_like(v) for k, v in Wd.items()}
     engine.speaker_decode_bwd(dims, params, f, grads, raw_d, d_onehot=G.cuda().contiguous() if oh is not None else None,
@@ -81,7 +90,9 @@ def _run(W, cfg, att_raw, noise, mode_name, seed):
 
 @pytest.mark.parametrize('name,mode', [('sample_gumbel_st', 'gumbel_st'), ('sample_gumbel_st_tau', 'gumbel_st'),
                                        ('sample_multinomial_st', 'multinomial_st'),
-                                       ('sample_multinomial_plain', 'multinomial')])
+                                       ('sample_multinomial_plain', 'multinomial'),
+                                       ('sample_gumbel_ps', 'gumbel_ps'), ('sample_multinomial_ps', 'multinomial_ps'),
+                                       ('sample_multinomial_ps_tau', 'multinomial_ps')])
 def test_decode_bwd_golden_inputs(name, mode):
     z = GU.load_case(name)
     cfg = GU.cfg_dict(z)
@@ -112,3 +123,28 @@ def test_decode_bwd_flagship_dims():
                  out_keep=(torch.rand(T + 1, B, H, generator=g) >= 0.5).float(),
                  gumbel_u=torch.rand(T + 1, B, V + 1, generator=g))
     _run(W, cfg, att_raw, noise, 'gumbel_st', 4)
+
+
+def test_decode_bwd_partial_sampling_flagship_dims():
+    """Partial-sampling Gumbel (gumbel_softmax.py) at the flagship widths: the logit-layer backward runs inside
+    the time loop and the embedding gradient is a dense [V+1, T*B] x [T*B, E] product."""
+    g = torch.Generator().manual_seed(22)
+    B, K, D, H, V, T = 4, 36, 128, 512, 9487, 16
+
+    def lin(o, i, s=1.0):
+        r = s / np.sqrt(i)
+        return (torch.rand(o, i, generator=g) * 2 - 1) * r, (torch.rand(o, generator=g) * 2 - 1) * r
+    W = {'embed.0.weight': torch.randn(V + 2, H, generator=g)}
+    for nm, (o, i, s) in {'att_embed.0': (H, D, 1), 'logit': (V + 1, H, 6), 'ctx2att': (H, H, 1), 'core.a2c': (2 * H, H, 1),
+                          'core.i2h': (5 * H, H, 1), 'core.h2h': (5 * H, H, 1), 'core.attention.h2att': (H, H, 1),
+                          'core.attention.alpha_net': (1, H, 3)}.items():
+        W[nm + '.weight'], W[nm + '.bias'] = lin(o, i, s)
+    W['logit.bias'][0] = 3.0
+    cfg = dict(vocab_size=V, seq_length=T, drop_prob_lm=0.5, gumbel_temp=0.7, multinomial_temp=1.0,
+               prob_gumbel_softmax=0.5, prob_multinomial_soft=0.5, decoding_constraint=0)
+    att_raw = torch.randn(B, K, D, generator=g).abs() * 0.5
+    noise = dict(att_keep=(torch.rand(B, K, H, generator=g) >= 0.5).float(),
+                 x_keep=(torch.rand(T + 1, B, H, generator=g) >= 0.5).float(),
+                 out_keep=(torch.rand(T + 1, B, H, generator=g) >= 0.5).float(),
+                 gumbel_u=torch.rand(T + 1, B, V + 1, generator=g), ps_u=torch.rand(T + 1, B, generator=g))
+    _run(W, cfg, att_raw, noise, 'gumbel_ps', 5)

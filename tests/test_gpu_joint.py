@@ -28,6 +28,8 @@ def decode_tags(cfg, turn, n):
             if rr == 'reinforce' and cfg['reinforce_baseline_type'] == 'greedy':
                 names.append('greedy')
         if cfg['cider_optimization']:
+            if rr in ('gumbel_softmax', 'multinomial_soft') or 'sample' not in names:
+                names.append('cider_gen')        # gen_result_for_cider, AlternatingJointModel.py:378-389
             if 'greedy' not in names:
                 names.append('greedy')
     assert len(names) == n, (names, n)
@@ -36,7 +38,7 @@ def decode_tags(cfg, turn, n):
 
 CASES = ['joint_gumbel', 'joint_gumbel_dropout', 'joint_gumbel_tau', 'joint_multinomial', 'joint_reinforce_gt',
          'joint_reinforce_greedy', 'joint_reinforce_no', 'joint_reinforce_listener', 'joint_gumbel_mle',
-         'joint_plain_all']
+         'joint_plain_all', 'joint_gumbel_ps', 'joint_multinomial_ps']
 
 
 @pytest.mark.parametrize('name', CASES)
@@ -65,7 +67,7 @@ def test_joint_step_matches_reference(name):
         loss = model(fc, labels, masks, data, att, None, is_alternating=True, alternating_turn=turn)
     loss.backward()
     torch.cuda.synchronize()
-    np.testing.assert_allclose(float(loss), float(z['loss']), rtol=5e-5, atol=1e-6)
+    np.testing.assert_allclose(float(loss.detach()), float(np.asarray(z['loss']).reshape(-1)[0]), rtol=5e-5, atol=1e-6)
     n = 0
     grads = {k: p.grad for k, p in model.named_parameters()}
     glob = max(float(np.abs(z[k][1]) / max(grads[k[5:]].numel(), 1)) for k in z if k.startswith('gdig.'))
