@@ -52,6 +52,17 @@ struct CicGraphScope {
 };
 
 static inline hipStream_t cic_s(cic_stream_t s) { return (hipStream_t)s; }
+
+// A pointer per decode of a PAIR of decodes that advance in lock step through the same launches
+// (rows [0,B) belong to decode a, rows [B,2B) to decode b; b is unused for a single decode).
+template <typename T>
+struct Dual {
+    T* a;
+    T* b;
+    __host__ __device__ T* sel(bool second) const { return second ? b : a; }
+};
+template <typename T>
+static inline Dual<T> dual1(T* p) { return Dual<T>{p, nullptr}; }
 static inline int cic_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ---- wave / block reductions (wave = 64 lanes) ---------------------------------------

@@ -34,6 +34,16 @@ SpkWs spk_carve(const cic_speaker_dims& d, void* base);
 
 int cic_fill_i32(int32_t* p, int n, int32_t v, hipStream_t st);
 int cic_add_vec(const float* a, const float* b, float* o, int n, hipStream_t st);
+// pair-capable launchers (nb = 1: one decode, the .b pointers are unused; nb = 2: a pair in lock step)
+bool cic_attn_pair_ok(int K, int A, int H);
+int cic_attn_fwd2(Dual<const float> att_h, Dual<const float> p_att, Dual<const float> att, const float* w_alpha,
+                  const float* b_alpha, const float* masks, Dual<float> att_res, Dual<float> alpha, Dual<float> dot, int B,
+                  int nb, int K, int A, int H, hipStream_t st);
+int cic_cell_fwd2(Dual<const float> pre, Dual<const float> c_prev, Dual<const uint8_t> keep, float p_drop, Dual<float> h_new,
+                  Dual<float> c_new, Dual<float> out, int B, int nb, int H, hipStream_t st);
+int cic_embed_fwd2(const float* E, Dual<const int32_t> it, Dual<const uint8_t> keep, float p_drop, Dual<float> x, int B,
+                   int nb, int Ed, hipStream_t st);
+int cic_logsoftmax_sample2(const cic_sampler_args* a, const cic_sampler_args* b, hipStream_t st);
 int cic_relu_keep_fwd(const float* xpre, const uint8_t* keep, float p_drop, float* x, int64_t n, hipStream_t st);
 int cic_soft_mask(const float* soft_raw, const int32_t* seq, const int32_t* L, float* soft_out, int T, int B, int V1,
                   hipStream_t st);
@@ -60,15 +70,21 @@ static inline int gemm_nt2(const float* A1, int lda1, const float* W1, int ldw1,
     g.C = C; g.ldc = ldc; g.bias = bias;
     return cic_gemm_f32(&g, st);
 }
-// C[M,N] = A[M,K] Bm[K,N] (+C)                    — dX = dY W   (W stored [K=out, N=in])
+// C[M,N] = A[M,K] Bm[K,N] (+C)                    — dX = dY W   (W stored [K=out, N=in]); a gradient product:
+// the summation order is free
 static inline int gemm_nn(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K,
-                          bool accumulate, hipStream_t st) {
+                          bool accumulate, hipStream_t st, bool order_free = true) {
     cic_gemm_args g = {};
     g.M = M; g.N = N; g.K = K;
     g.A = A; g.lda = lda; g.a_kc = 1;
     g.B = Bm; g.ldb = ldb; g.b_kc = 0;
-    g.C = C; g.ldc = ldc; g.accumulate = accumulate;
+    g.C = C; g.ldc = ldc; g.accumulate = accumulate; g.sum_order_free = order_free;
     return cic_gemm_f32(&g, st);
+}
+// the same product in a FORWARD pass (soft caption rows @ embedding): fixed summation order
+static inline int gemm_nn_fwd(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K,
+                              bool accumulate, hipStream_t st) {
+    return gemm_nn(A, lda, Bm, ldb, C, ldc, M, N, K, accumulate, st, false);
 }
 // C = A1 B1 + A2 B2 (+C), all B stored [K,N]
 static inline int gemm_nn2(const float* A1, int lda1, const float* B1, int ldb1, int K1, const float* A2, int lda2,
@@ -79,7 +95,7 @@ static inline int gemm_nn2(const float* A1, int lda1, const float* B1, int ldb1,
     g.A = A1; g.lda = lda1; g.a_kc = 1;
     g.B = B1; g.ldb = ldb1; g.b_kc = 0;
     g.K2 = K2; g.A2 = A2; g.lda2 = lda2; g.B2 = B2; g.ldb2 = ldb2;
-    g.C = C; g.ldc = ldc; g.accumulate = accumulate;
+    g.C = C; g.ldc = ldc; g.accumulate = accumulate; g.sum_order_free = 1;
     return cic_gemm_f32(&g, st);
 }
 // C[M,N] = At[K,M]^T Bm[K,N] (+C)                 — dW = dY^T X
@@ -89,6 +105,6 @@ static inline int gemm_tn(const float* At, int lda, const float* Bm, int ldb, fl
     g.M = M; g.N = N; g.K = K;
     g.A = At; g.lda = lda; g.a_kc = 0;
     g.B = Bm; g.ldb = ldb; g.b_kc = 0;
-    g.C = C; g.ldc = ldc; g.accumulate = accumulate;
+    g.C = C; g.ldc = ldc; g.accumulate = accumulate; g.sum_order_free = 1;   // weight gradients
     return cic_gemm_f32(&g, st);
 }

@@ -97,8 +97,13 @@ struct Tile {
     }
 };
 
+// Tail balancing (`full`, `ks`): with T output tiles on 256 CUs the last partial round of tiles would leave most
+// of the chip idle (300 tiles = 1 full round + 44 tiles), so only the first `full` tiles (a multiple of the CU
+// count) run their whole K range; each remaining tile is cut into `ks` K-slices handled by `ks` workgroups that
+// add their partial tile into C with float atomics (C pre-zeroed by the launcher unless it accumulates).
+// full == all tiles: plain data-parallel GEMM with a deterministic, fixed summation order.
 template <int BM, int BN, int WM, int WN, bool KCA, bool KCB, bool VEC>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(cic_gemm_args g) {
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(cic_gemm_args g, int full, int ks) {
     constexpr int THREADS = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     using TA = Tile<BM, KCA, VEC, THREADS>;
@@ -116,6 +121,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(cic_gemm_args g) {
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
     if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    int slice = 0, nslice = 1;
+    if (bid >= full) {               // K-sliced tail tile
+        const int rem = bid - full;
+        slice = rem % ks;
+        nslice = ks;
+        bid = full + rem / ks;
+    }
     const int tiles_n = (g.N + BN - 1) / BN;
     const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
 
@@ -135,11 +147,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(cic_gemm_args g) {
         const int lda = pair ? g.lda2 : g.lda, ldb = pair ? g.ldb2 : g.ldb;
         const int K = pair ? g.K2 : g.K;
         if (K <= 0) continue;
-        const int nk = (K + BK - 1) / BK;
-        TA::load(ra, A, lda, m0, g.M, 0, K, tid);
-        TB::load(rb, B, ldb, n0, g.N, 0, K, tid);
+        const int nk_all = (K + BK - 1) / BK;
+        const int per = (nk_all + nslice - 1) / nslice;     // K-tiles per slice (a tail slice may be empty)
+        const int kt0 = slice * per;
+        const int nk = min(nk_all, kt0 + per);
+        if (kt0 >= nk) continue;
+        TA::load(ra, A, lda, m0, g.M, kt0 * BK, K, tid);
+        TB::load(rb, B, ldb, n0, g.N, kt0 * BK, K, tid);
 #pragma unroll 1
-        for (int kt = 0; kt < nk; ++kt) {
+        for (int kt = kt0; kt < nk; ++kt) {
             __syncthreads();   // everyone is done reading the previous tile
             TA::store(ra, LA, tid);
             TB::store(rb, LB, tid);
@@ -173,16 +189,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(cic_gemm_args g) {
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * (BN / WN) + j * 32 + r;
             if (n >= g.N) continue;
-            const float bv = g.bias ? g.bias[n] : 0.f;
+            const float bv = (g.bias && slice == 0) ? g.bias[n] : 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m < g.M) {
                     float* c = g.C + (size_t)m * g.ldc + n;
                     float v = acc[i][j][e] + bv;
-                    if (g.accumulate) v += *c;
-                    if (g.relu) v = fmaxf(v, 0.f);
-                    *c = v;
+                    if (nslice > 1) {
+                        atomicAdd(c, v);         // no-return global_atomic_add_f32, executed at the memory side
+                    } else {
+                        if (g.accumulate) v += *c;
+                        if (g.relu) v = fmaxf(v, 0.f);
+                        *c = v;
+                    }
                 }
             }
         }
@@ -350,21 +370,29 @@ __global__ __launch_bounds__(KS * 64) void gemm_rega_kernel(cic_gemm_args g, int
     const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
     const int h = lane >> 5, r = lane & 31;
     const int tiles_n = (g.N + 31) / 32;
-    const int m0 = (blockIdx.x / tiles_n) * 32, n0 = (blockIdx.x % tiles_n) * 32;
+    int m0 = (blockIdx.x / tiles_n) * 32;
+    const int n0 = (blockIdx.x % tiles_n) * 32;
+    // row blocks: strips at or beyond rows_blk read/write the second decode's buffers (strips never straddle)
+    const bool blk2 = g.rows_blk > 0 && m0 >= g.rows_blk;
+    const float* __restrict__ gA = blk2 ? g.A_b : g.A;
+    const float* __restrict__ gA2 = blk2 ? g.A2_b : g.A2;
+    float* __restrict__ gC = blk2 ? g.C_b : g.C;
+    const int Mloc = g.rows_blk > 0 ? (blk2 ? g.M - g.rows_blk : min(g.M, g.rows_blk)) : g.M;
+    if (blk2) m0 -= g.rows_blk;
     const int m = m0 + r, n = n0 + r;
     const int K1 = g.K, Kt = g.K + g.K2;
-    const bool mok = m < g.M, nok = n < g.N;
+    const bool mok = m < Mloc, nok = n < g.N;
 
     // Loads are UNCONDITIONAL (addresses clamped into the operand, results zeroed by a select): a branch
     // around a load makes hipcc wait vmcnt(0) before the next MFMA chain, which serialises the prefetch.
-    const int mc = mok ? m : g.M - 1, nc = nok ? n : g.N - 1;
+    const int mc = mok ? m : Mloc - 1, nc = nok ? n : g.N - 1;
     auto load_chunk = [&](f32x4 (&af)[CH], f32x4 (&bf)[CH], int c) {
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int k = 8 * (ks * gps + c * CH + i) + 4 * h;   // first of this lane's 4 k's (K1 % 8 == 0)
             const bool kok = k < Kt;
             const bool second = kok && k >= K1;
-            const float* A = second ? g.A2 : g.A;
+            const float* A = second ? gA2 : gA;
             const float* B = second ? g.B2 : g.B;
             const int lda = second ? g.lda2 : g.lda, ldb = second ? g.ldb2 : g.ldb;
             const int kp = second ? g.K2 : K1;
@@ -414,8 +442,8 @@ __global__ __launch_bounds__(KS * 64) void gemm_rega_kernel(cic_gemm_args g, int
 #pragma unroll
         for (int q = 0; q < KS; ++q) v += red[(q * 16 + e) * 64 + lane];
         const int mm = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (mm < g.M && nok) {
-            float* c = g.C + (size_t)mm * g.ldc + n;
+        if (mm < Mloc && nok) {
+            float* c = gC + (size_t)mm * g.ldc + n;
             if (g.bias) v += g.bias[n];
             if (g.accumulate) v += *c;
             if (g.relu) v = fmaxf(v, 0.f);
@@ -447,11 +475,18 @@ __global__ __launch_bounds__(KS * 64) void gemm_rega_loop_kernel(cic_gemm_args g
     const int h = lane >> 5, r = lane & 31;
     const int tiles_n = (g.N + 31) / 32;
     const int strip = blockIdx.x % strips, first = blockIdx.x / strips, step = gridDim.x / strips;
-    const int m0 = strip * 32, m = m0 + r;
+    int m0 = strip * 32;
+    const bool blk2 = g.rows_blk > 0 && m0 >= g.rows_blk;   // row blocks: see gemm_rega_kernel
+    const float* __restrict__ gA = blk2 ? g.A_b : g.A;
+    const float* __restrict__ gA2 = blk2 ? g.A2_b : g.A2;
+    float* __restrict__ gC = blk2 ? g.C_b : g.C;
+    const int Mloc = g.rows_blk > 0 ? (blk2 ? g.M - g.rows_blk : min(g.M, g.rows_blk)) : g.M;
+    if (blk2) m0 -= g.rows_blk;
+    const int m = m0 + r;
     const int K1 = g.K, Kt = g.K + g.K2;
-    const bool mok = m < g.M;
+    const bool mok = m < Mloc;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    const int mc = mok ? m : g.M - 1;
+    const int mc = mok ? m : Mloc - 1;
     f32x4 af[GPS];
 #pragma unroll
     for (int i = 0; i < GPS; ++i) {
@@ -461,7 +496,7 @@ __global__ __launch_bounds__(KS * 64) void gemm_rega_loop_kernel(cic_gemm_args g
         const int kp = second ? g.K2 : K1;
         int kk = second ? k - K1 : k;
         kk = kk < kp - 4 ? kk : kp - 4;
-        const f32x4 a = *reinterpret_cast<const f32x4*>((second ? g.A2 : g.A) + (size_t)mc * (second ? g.lda2 : g.lda) + kk);
+        const f32x4 a = *reinterpret_cast<const f32x4*>((second ? gA2 : gA) + (size_t)mc * (second ? g.lda2 : g.lda) + kk);
         af[i] = (kok && mok) ? a : z4;
     }
     auto load_b = [&](f32x4 (&bf)[GPS], int t) {
@@ -494,7 +529,7 @@ __global__ __launch_bounds__(KS * 64) void gemm_rega_loop_kernel(cic_gemm_args g
     int buf = 0;
     const int e_own = ks;                              // wave ks finishes accumulator register ks
     const int mm = m0 + (e_own & 3) + 8 * (e_own >> 2) + 4 * h;
-    const int mcl = mm < g.M ? mm : g.M - 1;
+    const int mcl = mm < Mloc ? mm : Mloc - 1;
 #pragma unroll 1
     for (int t = first; t < tiles_n; t += step) {
         load_b(bnext, t + step);                       // next tile's fragments in flight
@@ -502,7 +537,7 @@ __global__ __launch_bounds__(KS * 64) void gemm_rega_loop_kernel(cic_gemm_args g
         const int ncl = n < g.N ? n : g.N - 1;
         float bias_v = 0.f, cold = 0.f;                // epilogue operands fetched before the barrier
         if (g.bias) bias_v = g.bias[ncl];
-        if (g.accumulate) cold = g.C[(size_t)mcl * g.ldc + ncl];
+        if (g.accumulate) cold = gC[(size_t)mcl * g.ldc + ncl];
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -519,7 +554,7 @@ __global__ __launch_bounds__(KS * 64) void gemm_rega_loop_kernel(cic_gemm_args g
         for (int q = 0; q < KS; ++q) v += rb[(q * 16 + e_own) * 64 + lane];
         v += bias_v + cold;
         if (g.relu) v = fmaxf(v, 0.f);
-        if (mm < g.M && n < g.N) g.C[(size_t)mm * g.ldc + n] = v;
+        if (mm < Mloc && n < g.N) gC[(size_t)mm * g.ldc + n] = v;
         buf ^= 1;
 #pragma unroll
         for (int i = 0; i < GPS; ++i) bcur[i] = bnext[i];
@@ -527,7 +562,8 @@ __global__ __launch_bounds__(KS * 64) void gemm_rega_loop_kernel(cic_gemm_args g
 }
 
 bool rega_ok(const cic_gemm_args& g) {
-    if (!g.a_kc || g.M > 128) return false;
+    if (!g.a_kc || g.M > (g.rows_blk > 0 ? 256 : 128)) return false;
+    if (g.rows_blk > 0 && (!aligned16(g.A_b) || (g.K2 > 0 && !aligned16(g.A2_b)))) return false;
     if ((g.K & 7) || (g.K2 & 7)) return false;
     if (!aligned16(g.A) || (g.lda & 3) || !aligned16(g.B) || (g.ldb & 3)) return false;
     if (g.K2 > 0 && (!aligned16(g.A2) || (g.lda2 & 3) || !aligned16(g.B2) || (g.ldb2 & 3))) return false;
@@ -557,12 +593,40 @@ int launch_rega(const cic_gemm_args& g, hipStream_t st) {
     return 0;
 }
 
+int g_tail_split = 1;   // cic_debug_gemm_tail_split: 0 disables the K-sliced tail (A/B measurements, determinism)
+int g_force_tile = 0;   // cic_debug_gemm_tail_split bits 8..: 1 = 128x128, 2 = 64x64 (A/B measurements)
+
 template <int BM, int BN, int WM, int WN>
-int launch_shape(const cic_gemm_args& g, bool vec, hipStream_t st) {
-    const int grid = cic_cdiv(g.M, BM) * cic_cdiv(g.N, BN);
+int launch_shape(const cic_gemm_args& g, bool vec, bool want_tail, hipStream_t st) {
+    const int tiles = cic_cdiv(g.M, BM) * cic_cdiv(g.N, BN);
+    constexpr int CUS = 256;
+    int full = tiles, ks = 1;
+    const int nk = cic_cdiv(g.K, BK);
+    const int tail = tiles % CUS;
+    // a tail of fewer than ~3/4 of the CUs is K-sliced (needs a plain sum epilogue: no second operand pair, no ReLU,
+    // and a caller that accepts an unordered sum)
+    if (want_tail && g_tail_split && g.sum_order_free && tail > 0 && tail <= (CUS * 3) / 4 && g.K2 == 0 && !g.relu && nk >= 8) {
+        ks = CUS / tail;
+        if (tiles < CUS) ks = (2 * CUS) / tail;     // nothing but a tail: two co-resident workgroups per CU
+        if (ks > nk / 4) ks = nk / 4;               // at least 4 K-tiles (128 k) per slice
+        if (ks > 32) ks = 32;
+        if (ks >= 2) full = tiles - tail; else ks = 1;
+    }
+    const int grid = full + (tiles - full) * ks;
+    if (ks > 1 && !g.accumulate) {
+        // the sliced tiles sum into C: zero the rows x columns they cover (whole C when everything is tail)
+        if (full == 0) {
+            CIC_HIP(hipMemset2DAsync(g.C, sizeof(float) * g.ldc, 0, sizeof(float) * g.N, g.M, st));
+        } else {
+            const int tiles_n = cic_cdiv(g.N, BN);
+            const int first_row = (full / tiles_n) * BM;      // tail tiles start somewhere in this tile row
+            CIC_HIP(hipMemset2DAsync(g.C + (size_t)first_row * g.ldc, sizeof(float) * g.ldc, 0, sizeof(float) * g.N,
+                                     g.M - first_row, st));
+        }
+    }
     dim3 blk(WM * WN * 64);
 #define CIC_GEMM_GO(KA, KB, V) \
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, KA, KB, V>), dim3(grid), blk, 0, st, g)
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, KA, KB, V>), dim3(grid), blk, 0, st, g, full, ks)
     const int code = (g.a_kc ? 4 : 0) | (g.b_kc ? 2 : 0) | (vec ? 1 : 0);
     switch (code) {
         case 7: CIC_GEMM_GO(true, true, true); break;
@@ -613,6 +677,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
 
 }  // namespace
 
+extern "C" int cic_debug_gemm_tail_split(int on) {
+    g_tail_split = on & 0xff;
+    g_force_tile = (on >> 8) & 0xff;
+    return 0;
+}
+
 extern "C" int cic_debug_set_stamps(unsigned long long* buf) {
     CIC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)));
     return 0;
@@ -628,6 +698,11 @@ extern "C" int cic_gemm_f32(const cic_gemm_args* a, cic_stream_t s) {
     if (g.K2 > 0)
         vec = vec && operand_vec_ok(g.A2, g.lda2, g.a_kc, g.M, g.K2) && operand_vec_ok(g.B2, g.ldb2, g.b_kc, g.N, g.K2);
     const int64_t big_tiles = (int64_t)cic_cdiv(g.M, 128) * cic_cdiv(g.N, 128);
+    if (g.rows_blk > 0) {
+        CIC_REQUIRE(g.a_kc && (g.rows_blk & 31) == 0 && g.M > g.rows_blk && g.M <= 2 * g.rows_blk && g.A_b && g.C_b);
+        CIC_REQUIRE(g.K2 == 0 || g.A2_b);
+        CIC_REQUIRE(rega_ok(g));     // only the register-streaming kernels address row blocks
+    }
     if (rega_ok(g)) return launch_rega(g, cic_s(s));
     if (g.M <= 128) {
         // per-timestep products: in-workgroup split-K (see gemm_skinny_kernel)
@@ -635,8 +710,20 @@ extern "C" int cic_gemm_f32(const cic_gemm_args* a, cic_stream_t s) {
         if (g.M > 64 && (cic_cdiv(g.N, 32) >= 128 || ktot < 2048)) return launch_skinny<4, 4>(g, vec, cic_s(s));
         return launch_skinny<2, 8>(g, vec, cic_s(s));
     }
-    if (big_tiles >= 192) return launch_shape<128, 128, 2, 2>(g, vec, cic_s(s));
-    return launch_shape<64, 64, 2, 2>(g, vec, cic_s(s));
+    if (g_force_tile == 1) return launch_shape<128, 128, 2, 2>(g, vec, true, cic_s(s));
+    if (g_force_tile == 2) return launch_shape<64, 64, 2, 2>(g, vec, true, cic_s(s));
+    // Tile choice (measured on the shapes of the B = 128 joint step, tools/gemm_sweep.py): a lone 128x128 workgroup
+    // runs its CU at ~90 % of the f32 MFMA rate, a 64x64 one at about half of that but four of them share a CU.
+    //   >= 400 big tiles: 128x128, several rounds of full tiles;
+    //   48..192 big tiles and a free summation order: 128x128 tiles, every tile K-sliced so that ~512 workgroups
+    //     cover the chip (unless the 64x64 grid is an exact multiple of the CU count);
+    //   otherwise 64x64 tiles, K-sliced only when there are fewer than one per CU.
+    const int64_t small_tiles = (int64_t)cic_cdiv(g.M, 64) * cic_cdiv(g.N, 64);
+    const bool free_sum = g.sum_order_free && g_tail_split && g.K2 == 0 && !g.relu;
+    if (big_tiles >= 400) return launch_shape<128, 128, 2, 2>(g, vec, true, cic_s(s));
+    if (free_sum && big_tiles >= 48 && big_tiles <= 192 && g.K >= 1024 && (small_tiles % 256) != 0)
+        return launch_shape<128, 128, 2, 2>(g, vec, true, cic_s(s));
+    return launch_shape<64, 64, 2, 2>(g, vec, small_tiles < 256, cic_s(s));
 }
 
 extern "C" int cic_colsum_f32(const float* X, int M, int N, int ldx, float* out, int accumulate,

@@ -408,7 +408,7 @@ static int listener_fwd_impl(const cic_listener_dims* dp, const cic_listener_par
     }
     if (io->soft && !io->labels) {
         // soft caption rows: x_emb[1..T] += soft @ embed[0:V+1]          (VSEFCModel.py:102-104)
-        RUN(gemm_nn(io->soft, d.V + 1, p->embed_w, E, w.x_emb + (size_t)B * E, E, (Lp - 1) * B, E, d.V + 1, true, st));
+        RUN(gemm_nn_fwd(io->soft, d.V + 1, p->embed_w, E, w.x_emb + (size_t)B * E, E, (Lp - 1) * B, E, d.V + 1, true, st));
     }
     RUN(gemm_nt(w.x_emb, E, p->w_ih, E, w.gi_all, 3 * J, Lp * B, 3 * J, E, p->b_ih, false, false, st));
     CIC_HIP(hipMemsetAsync(w.h_all, 0, sizeof(float) * B * J, st));

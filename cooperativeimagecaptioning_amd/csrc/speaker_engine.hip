@@ -80,8 +80,8 @@ extern "C" int cic_speaker_att_embed_fwd(const cic_speaker_dims* dp, const cic_s
                    true, cic_s(s));
 }
 
-static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params* p, const cic_decode_io* io, void* ws,
-                           size_t ws_bytes, cic_stream_t s);
+static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params* p, const cic_decode_io* const* ios,
+                           void* const* wss, const size_t* ws_bytes, int nb, cic_stream_t s);
 
 extern "C" int cic_speaker_decode_fwd(const cic_speaker_dims* dp, const cic_speaker_params* p,
                                       const cic_decode_io* io, void* ws, size_t ws_bytes, cic_stream_t s) {
@@ -93,102 +93,189 @@ extern "C" int cic_speaker_decode_fwd(const cic_speaker_dims* dp, const cic_spea
     key = cic_hash_bytes(&ws, sizeof(ws), key);
     CicGraphScope gs(cic_s(s), key);
     if (gs.replayed) return 0;
-    return gs.finish(decode_fwd_impl(dp, p, io, ws, ws_bytes, s));
+    return gs.finish(decode_fwd_impl(dp, p, &io, &ws, &ws_bytes, 1, s));
 }
 
-static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params* p, const cic_decode_io* io, void* ws,
-                           size_t ws_bytes, cic_stream_t s) {
-    CIC_REQUIRE(dp && p && io && ws);
+static bool pair_ok(const cic_speaker_dims& d, const cic_decode_io* a, const cic_decode_io* b) {
+    auto ps = [](int m) { return m == CIC_SAMPLE_GUMBEL_PS || m == CIC_SAMPLE_MULTINOMIAL_PS; };
+    if (ps(a->mode) || ps(b->mode)) return false;                 // soft-input steps are not row-wise launches
+    if ((a->first_token != nullptr) != (b->first_token != nullptr)) return false;
+    if ((d.B & 31) || 2 * d.B > 256) return false;                // row blocks of the per-step products
+    if ((d.H & 7) || (d.E & 7) || (d.A & 7)) return false;        // register-streaming GEMM operands
+    return cic_attn_pair_ok(d.K, d.A, d.H);
+}
+
+extern "C" int cic_speaker_decode_fwd_pair(const cic_speaker_dims* dp, const cic_speaker_params* p,
+                                           const cic_decode_io* io_a, void* ws_a, size_t ws_a_bytes,
+                                           const cic_decode_io* io_b, void* ws_b, size_t ws_b_bytes, cic_stream_t s) {
+    CIC_REQUIRE(dp && p && io_a && ws_a && io_b && ws_b && ws_a != ws_b);
+    uint64_t key = cic_hash_bytes("decode_fwd_pair", 15, 1469598103934665603ull);
+    key = cic_hash_bytes(dp, sizeof(*dp), key);
+    key = cic_hash_bytes(p, sizeof(*p), key);
+    key = cic_hash_bytes(io_a, sizeof(*io_a), key);
+    key = cic_hash_bytes(io_b, sizeof(*io_b), key);
+    key = cic_hash_bytes(&ws_a, sizeof(ws_a), key);
+    key = cic_hash_bytes(&ws_b, sizeof(ws_b), key);
+    CicGraphScope gs(cic_s(s), key);
+    if (gs.replayed) return 0;
+    const cic_decode_io* ios[2] = {io_a, io_b};
+    void* wss[2] = {ws_a, ws_b};
+    const size_t wsb[2] = {ws_a_bytes, ws_b_bytes};
+    if (pair_ok(*dp, io_a, io_b)) return gs.finish(decode_fwd_impl(dp, p, ios, wss, wsb, 2, s));
+    int rc = decode_fwd_impl(dp, p, ios, wss, wsb, 1, s);          // shapes outside the paired kernels: one after the other
+    if (!rc) rc = decode_fwd_impl(dp, p, ios + 1, wss + 1, wsb + 1, 1, s);
+    return gs.finish(rc);
+}
+
+// nb = 1: one decode.  nb = 2: two decodes of the same images (e.g. the sampled and the greedy decode of a joint
+// step) advance in lock step: every per-timestep kernel is launched ONCE over 2B rows, rows [0,B) reading and
+// writing decode a's workspace / noise / outputs and rows [B,2B) decode b's.  Each row's arithmetic is exactly
+// that of the single-decode launch (same kernels, same K order), so the results are bit-identical to two
+// sequential cic_speaker_decode_fwd calls; what changes is 2x fewer launches and twice the rows per launch
+// (B = 128 alone fills only half of the 256 CUs in the one-workgroup-per-image kernels).
+static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params* p, const cic_decode_io* const* ios,
+                           void* const* wss, const size_t* ws_bytes, int nb, cic_stream_t s) {
+    CIC_REQUIRE(dp && p && ios && wss && (nb == 1 || nb == 2));
     const cic_speaker_dims& d = *dp;
     if (int rc = check_dims(d)) return rc;
-    CIC_REQUIRE(io->mode >= CIC_SAMPLE_GREEDY && io->mode <= CIC_SAMPLE_MULTINOMIAL_PS);
-    const bool ps = io->mode == CIC_SAMPLE_GUMBEL_PS || io->mode == CIC_SAMPLE_MULTINOMIAL_PS;
-    CIC_REQUIRE(!ps || (io->soft_raw && io->xpre && io->soft_out));
-    CIC_REQUIRE(io->att_pre && io->seq && io->slp && io->L);
-    SpkWs w = spk_carve(d, ws);
-    CIC_REQUIRE(ws_bytes >= w.bytes);
     hipStream_t st = cic_s(s);
     const int B = d.B, K = d.K, H = d.H, E = d.E, A = d.A, T = d.T, V1 = d.V + 1;
     const float p_drop = d.p_drop;
     int rc;
 #define RUN(x) if ((rc = (x)) != 0) return rc
-
-    // att = dropout(relu(att_embed(att_raw)));  p_att = ctx2att(att)      (AttModel.py:315,319)
-    RUN(cic_apply_keep(io->att_pre, io->att_keep, io->att_keep ? p_drop : 0.f, w.att, (int64_t)B * K * H, s));
-    RUN(gemm_nt(w.att, H, p->ctx2att_w, H, w.p_att, A, B * K, A, H, p->ctx2att_b, false, false, st));
-    RUN(cic_add_vec(p->i2h_b, p->h2h_b, w.bias_ih, 5 * H, st));
-    CIC_HIP(hipMemsetAsync(w.h_all, 0, sizeof(float) * B * H, st));          // init_hidden (:311)
-    CIC_HIP(hipMemsetAsync(w.c_all, 0, sizeof(float) * B * H, st));
-    CIC_HIP(hipMemsetAsync(w.any_unf, 0, sizeof(int32_t) * (T + 1), st));
-    RUN(cic_fill_i32(w.unfinished, B, 1, st));
-    if (io->first_token) {                                                    // AttModel.forward: seq[:, 0]  (:131)
-        hipLaunchKernelGGL(i64_to_i32_kernel, dim3(cic_cdiv(B, 256)), dim3(256), 0, st, io->first_token, w.it_all, B);
-        CIC_LAUNCH_CHECK();
-    } else {
-        RUN(cic_fill_i32(w.it_all, B, d.V + 1, st));                          // <bos> = vocab_size + 1 (:324-326)
+    SpkWs w[2];
+    const cic_decode_io* io[2] = {ios[0], nb == 2 ? ios[1] : nullptr};
+    bool ps = false;
+    for (int q = 0; q < nb; ++q) {
+        CIC_REQUIRE(io[q] && wss[q]);
+        CIC_REQUIRE(io[q]->mode >= CIC_SAMPLE_GREEDY && io[q]->mode <= CIC_SAMPLE_MULTINOMIAL_PS);
+        const bool psq = io[q]->mode == CIC_SAMPLE_GUMBEL_PS || io[q]->mode == CIC_SAMPLE_MULTINOMIAL_PS;
+        CIC_REQUIRE(!psq || (nb == 1 && io[q]->soft_raw && io[q]->xpre && io[q]->soft_out));
+        ps = ps || psq;
+        CIC_REQUIRE(io[q]->att_pre && io[q]->seq && io[q]->slp && io[q]->L);
+        w[q] = spk_carve(d, wss[q]);
+        CIC_REQUIRE(ws_bytes[q] >= w[q].bytes);
+        // att = dropout(relu(att_embed(att_raw)));  p_att = ctx2att(att)      (AttModel.py:315,319)
+        RUN(cic_apply_keep(io[q]->att_pre, io[q]->att_keep, io[q]->att_keep ? p_drop : 0.f, w[q].att, (int64_t)B * K * H, s));
+        RUN(gemm_nt(w[q].att, H, p->ctx2att_w, H, w[q].p_att, A, B * K, A, H, p->ctx2att_b, false, false, st));
+        RUN(cic_add_vec(p->i2h_b, p->h2h_b, w[q].bias_ih, 5 * H, st));
+        CIC_HIP(hipMemsetAsync(w[q].h_all, 0, sizeof(float) * B * H, st));          // init_hidden (:311)
+        CIC_HIP(hipMemsetAsync(w[q].c_all, 0, sizeof(float) * B * H, st));
+        CIC_HIP(hipMemsetAsync(w[q].any_unf, 0, sizeof(int32_t) * (T + 1), st));
+        RUN(cic_fill_i32(w[q].unfinished, B, 1, st));
+        if (io[q]->first_token) {                                                    // AttModel.forward: seq[:, 0]  (:131)
+            hipLaunchKernelGGL(i64_to_i32_kernel, dim3(cic_cdiv(B, 256)), dim3(256), 0, st, io[q]->first_token, w[q].it_all, B);
+            CIC_LAUNCH_CHECK();
+        } else {
+            RUN(cic_fill_i32(w[q].it_all, B, d.V + 1, st));                          // <bos> = vocab_size + 1 (:324-326)
+        }
     }
+    if (nb == 1) w[1] = SpkWs{};                      // all-null second set
+    const int M = nb * B;
+    // Dual{a, b}: slab t of buffer `f` in both workspaces (b is null for a single decode)
+#define SLAB(f, n) Dual<float>{w[0].f + (size_t)t * (n), nb == 2 ? w[1].f + (size_t)t * (n) : nullptr}
+#define CSLAB(f, n) Dual<const float>{w[0].f + (size_t)t * (n), nb == 2 ? w[1].f + (size_t)t * (n) : nullptr}
+    auto keep_at = [&](const uint8_t* base, size_t off) -> const uint8_t* { return base ? base + off : nullptr; };
+    // per-step products over the rows of both decodes: second row block at the b pointers
+    auto pair_gemm = [&](cic_gemm_args& g, const float* A_b, const float* A2_b, float* C_b) {
+        if (nb == 2) { g.rows_blk = B; g.A_b = A_b; g.A2_b = A2_b; g.C_b = C_b; }
+        return cic_gemm_f32(&g, st);
+    };
 
     for (int t = 0; t < T; ++t) {
-        float* x = w.x_all + (size_t)t * B * E;
-        float* h = w.h_all + (size_t)t * B * H;
-        float* c = w.c_all + (size_t)t * B * H;
-        float* att_h = w.att_h_all + (size_t)t * B * A;
-        float* att_res = w.att_res_all + (size_t)t * B * H;
-        float* pre = w.pre_all + (size_t)t * B * 5 * H;
-        float* out = w.out_all + (size_t)t * B * H;
-        float* logp = w.logp_all + (size_t)t * B * V1;
-        const uint8_t* xk = io->x_keep ? io->x_keep + (size_t)t * B * E : nullptr;
-        const uint8_t* ok = io->out_keep ? io->out_keep + (size_t)t * B * H : nullptr;
+        const Dual<float> x = SLAB(x_all, B * E), att_h = SLAB(att_h_all, B * A), att_res = SLAB(att_res_all, B * H),
+                          pre = SLAB(pre_all, B * 5 * H), out = SLAB(out_all, B * H), logp = SLAB(logp_all, B * V1);
+        const Dual<const float> h = CSLAB(h_all, B * H), c = CSLAB(c_all, B * H);
+        const Dual<float> h_new{w[0].h_all + (size_t)(t + 1) * B * H, nb == 2 ? w[1].h_all + (size_t)(t + 1) * B * H : nullptr};
+        const Dual<float> c_new{w[0].c_all + (size_t)(t + 1) * B * H, nb == 2 ? w[1].c_all + (size_t)(t + 1) * B * H : nullptr};
+        const Dual<const uint8_t> xk{keep_at(io[0]->x_keep, (size_t)t * B * E), nb == 2 ? keep_at(io[1]->x_keep, (size_t)t * B * E) : nullptr};
+        const Dual<const uint8_t> ok{keep_at(io[0]->out_keep, (size_t)t * B * H), nb == 2 ? keep_at(io[1]->out_keep, (size_t)t * B * H) : nullptr};
+        // dropout is on or off for the whole model (same p_drop); a decode without masks passes NULL
+        CIC_REQUIRE(nb == 1 || ((io[0]->x_keep != nullptr) == (io[1]->x_keep != nullptr) &&
+                                (io[0]->out_keep != nullptr) == (io[1]->out_keep != nullptr)));
         if (ps && t >= 1) {
             // xt = relu_dropout(soft_vec @ embed.weight)                   (:395-397), soft_vec un-masked
-            float* xp = io->xpre + (size_t)t * B * E;
-            RUN(gemm_nn(io->soft_raw + (size_t)(t - 1) * B * V1, V1, p->embed_w, E, xp, E, B, E, V1, false, st));
-            RUN(cic_relu_keep_fwd(xp, xk, xk ? p_drop : 0.f, x, (int64_t)B * E, st));
+            float* xp = io[0]->xpre + (size_t)t * B * E;
+            RUN(gemm_nn_fwd(io[0]->soft_raw + (size_t)(t - 1) * B * V1, V1, p->embed_w, E, xp, E, B, E, V1, false, st));
+            RUN(cic_relu_keep_fwd(xp, xk.a, xk.a ? p_drop : 0.f, x.a, (int64_t)B * E, st));
         } else {
             // xt = embed(it)                                               (:399)
-            RUN(cic_embed_fwd(p->embed_w, w.it_all + (size_t)t * B, xk, xk ? p_drop : 0.f, x, B, E, s));
+            RUN(cic_embed_fwd2(p->embed_w,
+                               Dual<const int32_t>{w[0].it_all + (size_t)t * B, nb == 2 ? w[1].it_all + (size_t)t * B : nullptr},
+                               xk, xk.a ? p_drop : 0.f, x, B, nb, E, st));
         }
         // attention                                                        (:465-489)
-        RUN(gemm_nt(h, H, p->h2att_w, H, att_h, A, B, A, H, p->h2att_b, false, false, st));
+        {
+            cic_gemm_args g = {};
+            g.M = M; g.N = A; g.K = H; g.A = h.a; g.lda = H; g.a_kc = 1; g.B = p->h2att_w; g.ldb = H; g.b_kc = 1;
+            g.C = att_h.a; g.ldc = A; g.bias = p->h2att_b;
+            RUN(pair_gemm(g, h.b, nullptr, att_h.b));
+        }
+        // att_masks are an input of the step (the same images in both decodes)
+        CIC_REQUIRE(nb == 1 || io[0]->att_masks == io[1]->att_masks);
         CIC_PROF(CIC_PROF_ATTN_FWD, st,
-                 rc = cic_attn_fwd(att_h, w.p_att, w.att, p->alpha_w, p->alpha_b, io->att_masks, att_res,
-                                   w.alpha_all + (size_t)t * B * K, w.dot_all + (size_t)t * B * K, B, K, A, H, s));
+                 rc = cic_attn_fwd2(Dual<const float>{att_h.a, att_h.b}, Dual<const float>{w[0].p_att, w[1].p_att},
+                                    Dual<const float>{w[0].att, w[1].att}, p->alpha_w, p->alpha_b, io[0]->att_masks, att_res,
+                                    SLAB(alpha_all, B * K), SLAB(dot_all, B * K), B, nb, K, A, H, st));
         if (rc) return rc;
         // all_input_sums = i2h(xt) + h2h(h);  in_transform += a2c(att_res)   (:514,521-522)
-        RUN(gemm_nt2(x, E, p->i2h_w, E, E, h, H, p->h2h_w, H, H, pre, 5 * H, B, 5 * H, w.bias_ih, st));
-        RUN(gemm_nt(att_res, H, p->a2c_w, H, pre + 3 * H, 5 * H, B, 2 * H, H, p->a2c_b, true, false, st));
-        RUN(cic_cell_fwd(pre, c, ok, ok ? p_drop : 0.f, h + (size_t)B * H, c + (size_t)B * H, out, B, H, s));
+        {
+            cic_gemm_args g = {};
+            g.M = M; g.N = 5 * H; g.K = E; g.A = x.a; g.lda = E; g.a_kc = 1; g.B = p->i2h_w; g.ldb = E; g.b_kc = 1;
+            g.K2 = H; g.A2 = h.a; g.lda2 = H; g.B2 = p->h2h_w; g.ldb2 = H;
+            g.C = pre.a; g.ldc = 5 * H; g.bias = w[0].bias_ih;
+            RUN(pair_gemm(g, x.b, h.b, pre.b));
+        }
+        {
+            cic_gemm_args g = {};
+            g.M = M; g.N = 2 * H; g.K = H; g.A = att_res.a; g.lda = H; g.a_kc = 1; g.B = p->a2c_w; g.ldb = H; g.b_kc = 1;
+            g.C = pre.a + 3 * H; g.ldc = 5 * H; g.bias = p->a2c_b; g.accumulate = 1;
+            RUN(pair_gemm(g, att_res.b, nullptr, nb == 2 ? pre.b + 3 * H : nullptr));
+        }
+        RUN(cic_cell_fwd2(Dual<const float>{pre.a, pre.b}, c, ok, ok.a ? p_drop : 0.f, h_new, c_new, out, B, nb, H, st));
         // logprobs = log_softmax(logit(output)); choose the input of step t+1   (:328-365,444)
-        CIC_PROF(CIC_PROF_LOGIT_GEMM, st,
-                 rc = gemm_nt(out, H, p->logit_w, H, logp, V1, B, V1, H, p->logit_b, false, false, st));
-        if (rc) return rc;
-        cic_sampler_args a;
-        a.logits = logp; a.B = B; a.V1 = V1; a.ld = V1;
-        a.mode = io->mode; a.temp = io->temp;
-        a.U = io->U ? io->U + (size_t)(t + 1) * B * V1 : nullptr; a.ldu = V1;
-        a.pick = io->pick ? io->pick + (size_t)(t + 1) * B : nullptr;
-        a.soft = ps ? io->soft_raw + (size_t)t * B * V1 : nullptr;
-        a.ld_soft = V1;
-        a.ps_u = (ps && io->ps_u) ? io->ps_u + (size_t)(t + 1) * B : nullptr;
-        a.ps_prob = io->ps_prob;
-        a.ss_u = io->ss_u ? io->ss_u + (size_t)(t + 1) * B : nullptr;
-        a.ss_prob = io->ss_prob;
-        a.ss_pick = io->ss_pick ? io->ss_pick + (size_t)(t + 1) * B : nullptr;
-        a.decoding_constraint = io->decoding_constraint;
-        a.step = t + 1;
-        a.unfinished = w.unfinished;
-        a.it_next = w.it_all + (size_t)(t + 1) * B;
-        a.seq = io->seq; a.slp = io->slp; a.stv = io->stv; a.seq_ld = T;
-        a.any_unfinished = w.any_unf;
-        CIC_PROF(CIC_PROF_SAMPLER, st, rc = cic_logsoftmax_sample(&a, s));
+        {
+            cic_gemm_args g = {};
+            g.M = M; g.N = V1; g.K = H; g.A = out.a; g.lda = H; g.a_kc = 1; g.B = p->logit_w; g.ldb = H; g.b_kc = 1;
+            g.C = logp.a; g.ldc = V1; g.bias = p->logit_b;
+            CIC_PROF(CIC_PROF_LOGIT_GEMM, st, rc = pair_gemm(g, out.b, nullptr, logp.b));
+            if (rc) return rc;
+        }
+        cic_sampler_args sa[2];
+        for (int q = 0; q < nb; ++q) {
+            cic_sampler_args& a = sa[q];
+            a = cic_sampler_args{};
+            a.logits = q ? logp.b : logp.a; a.B = B; a.V1 = V1; a.ld = V1;
+            a.mode = io[q]->mode; a.temp = io[q]->temp;
+            a.U = io[q]->U ? io[q]->U + (size_t)(t + 1) * B * V1 : nullptr; a.ldu = V1;
+            a.pick = io[q]->pick ? io[q]->pick + (size_t)(t + 1) * B : nullptr;
+            a.soft = ps ? io[q]->soft_raw + (size_t)t * B * V1 : nullptr;
+            a.ld_soft = V1;
+            a.ps_u = (ps && io[q]->ps_u) ? io[q]->ps_u + (size_t)(t + 1) * B : nullptr;
+            a.ps_prob = io[q]->ps_prob;
+            a.ss_u = io[q]->ss_u ? io[q]->ss_u + (size_t)(t + 1) * B : nullptr;
+            a.ss_prob = io[q]->ss_prob;
+            a.ss_pick = io[q]->ss_pick ? io[q]->ss_pick + (size_t)(t + 1) * B : nullptr;
+            a.decoding_constraint = io[q]->decoding_constraint;
+            a.step = t + 1;
+            a.unfinished = w[q].unfinished;
+            a.it_next = w[q].it_all + (size_t)(t + 1) * B;
+            a.seq = io[q]->seq; a.slp = io[q]->slp; a.stv = io[q]->stv; a.seq_ld = T;
+            a.any_unfinished = w[q].any_unf;
+        }
+        CIC_PROF(CIC_PROF_SAMPLER, st, rc = cic_logsoftmax_sample2(&sa[0], nb == 2 ? &sa[1] : nullptr, st));
         if (rc) return rc;
     }
-    if (io->first_token) {
-        RUN(cic_fill_i32(io->L, 1, T, st));      // teacher forcing: every step carries a target
-    } else {
-        RUN(cic_finalize_len(w.any_unf, T, io->L, s));
+#undef SLAB
+#undef CSLAB
+    for (int q = 0; q < nb; ++q) {
+        if (io[q]->first_token) {
+            RUN(cic_fill_i32(io[q]->L, 1, T, st));      // teacher forcing: every step carries a target
+        } else {
+            RUN(cic_finalize_len(w[q].any_unf, T, io[q]->L, s));
+        }
     }
-    if (ps) RUN(cic_soft_mask(io->soft_raw, io->seq, io->L, io->soft_out, T, B, V1, st));
+    if (ps) RUN(cic_soft_mask(io[0]->soft_raw, io[0]->seq, io[0]->L, io[0]->soft_out, T, B, V1, st));
 #undef RUN
     return 0;
 }

@@ -6,6 +6,7 @@
 // for the per-region reductions, LDS only for the cross-wave hand-off.  The GEMMs around them
 // (h2att, i2h/h2h, a2c, logit) are cic_gemm_f32.
 #include "cic_common.h"
+#include "engine_util.h"
 
 namespace {
 
@@ -159,16 +160,25 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const float* __restri
 __device__ unsigned long long* g_attn_stamps = nullptr;   // diagnostics (cic_debug_set_attn_stamps)
 
 template <int JMAX, int NCG>   // region groups of 8: K <= 8*JMAX;  NCG 32-column groups per wave
-__global__ __launch_bounds__(1024) void attn_fwd_cols_kernel(const float* __restrict__ att_h, const float* __restrict__ p_att,
-                                                             const float* __restrict__ att, const float* __restrict__ w_alpha,
+__global__ __launch_bounds__(1024) void attn_fwd_cols_kernel(Dual<const float> att_h_d, Dual<const float> p_att_d,
+                                                             Dual<const float> att_d, const float* __restrict__ w_alpha,
                                                              const float* __restrict__ b_alpha, const float* __restrict__ masks,
-                                                             float* __restrict__ att_res, float* __restrict__ alpha_out,
-                                                             float* __restrict__ dot_out, int K, int H) {
+                                                             Dual<float> att_res_d, Dual<float> alpha_d, Dual<float> dot_d, int B0,
+                                                             int K, int H) {
     __shared__ float sp[16 * 64];
     unsigned long long* stamps = g_attn_stamps;
     unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     if (stamps) s0 = __builtin_amdgcn_s_memrealtime();
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // rows [0,B0) are images of decode a, rows [B0, 2*B0) the same images in decode b (its own activations)
+    const bool second = (int)blockIdx.x >= B0;
+    const int b = second ? blockIdx.x - B0 : blockIdx.x;
+    const float* __restrict__ att_h = att_h_d.sel(second);
+    const float* __restrict__ p_att = p_att_d.sel(second);
+    const float* __restrict__ att = att_d.sel(second);
+    float* __restrict__ att_res = att_res_d.sel(second);
+    float* __restrict__ alpha_out = alpha_d.sel(second);
+    float* __restrict__ dot_out = dot_d.sel(second);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int NW = blockDim.x >> 6;                     // H / (32 * NCG) waves
     const int c = lane & 7, rg = lane >> 3;
     const int H4 = H >> 2;
@@ -251,13 +261,20 @@ extern "C" int cic_debug_set_attn_stamps(unsigned long long* buf);
 // K4 cell pointwise  (Att2in2Core.forward, models/AttModel.py:515-529)
 //   pre[b, 0:5H] = i2h(x)+h2h(h) with a2c(att_res) already added to [3H:5H]
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cell_fwd_kernel(const float* __restrict__ pre, const float* __restrict__ c_prev,
-                                                       const uint8_t* __restrict__ keep, float scale,
-                                                       float* __restrict__ h_new, float* __restrict__ c_new,
-                                                       float* __restrict__ out, int B, int H) {
+__global__ __launch_bounds__(256) void cell_fwd_kernel(Dual<const float> pre_d, Dual<const float> c_prev_d,
+                                                       Dual<const uint8_t> keep_d, float scale, Dual<float> h_new_d,
+                                                       Dual<float> c_new_d, Dual<float> out_d, int B, int nb, int H) {
     const int H4 = H >> 2;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * H4) return;
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nb * B * H4) return;
+    const bool second = idx >= B * H4;            // rows [B, 2B): the second decode of a pair
+    if (second) idx -= B * H4;
+    const float* __restrict__ pre = pre_d.sel(second);
+    const float* __restrict__ c_prev = c_prev_d.sel(second);
+    const uint8_t* __restrict__ keep = keep_d.sel(second);
+    float* __restrict__ h_new = h_new_d.sel(second);
+    float* __restrict__ c_new = c_new_d.sel(second);
+    float* __restrict__ out = out_d.sel(second);
     const int b = idx / H4, j = idx % H4;
     const f32x4* p = reinterpret_cast<const f32x4*>(pre + (size_t)b * 5 * H);
     const f32x4 pi = p[j], pf = p[H4 + j], po = p[2 * H4 + j], pa = p[3 * H4 + j], pb = p[4 * H4 + j];
@@ -284,12 +301,17 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------
 // K7 token embedding: x = dropout(relu(E[it]))   (models/AttModel.py:74-76,399)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict__ E, const int32_t* __restrict__ it,
-                                                        const uint8_t* __restrict__ keep, float scale,
-                                                        float* __restrict__ x, int B, int Ed) {
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict__ E, Dual<const int32_t> it_d,
+                                                        Dual<const uint8_t> keep_d, float scale, Dual<float> x_d, int B,
+                                                        int nb, int Ed) {
     const int E4 = Ed >> 2;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * E4) return;
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nb * B * E4) return;
+    const bool second = idx >= B * E4;
+    if (second) idx -= B * E4;
+    const int32_t* __restrict__ it = it_d.sel(second);
+    const uint8_t* __restrict__ keep = keep_d.sel(second);
+    float* __restrict__ x = x_d.sel(second);
     const int b = idx / E4, j = idx % E4;
     f32x4 v = reinterpret_cast<const f32x4*>(E + (size_t)it[b] * Ed)[j];
     uint32_t kp = 0x01010101u;
@@ -408,11 +430,15 @@ __device__ __forceinline__ float gumbel_from_u(float u) {
 }
 
 template <int RV>   // RV float4 per thread: rows up to RV*4096 floats
-__global__ __launch_bounds__(SNW * 64) void logsoftmax_sample_kernel(cic_sampler_args a) {
+__global__ __launch_bounds__(SNW * 64) void logsoftmax_sample_kernel(cic_sampler_args a0, cic_sampler_args a1) {
     constexpr int NT = SNW * 64;
     __shared__ float shf[SNW];
     __shared__ int shi[SNW];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    // rows [0, a0.B) run the sampler of decode a, rows beyond it that of decode b (own mode, noise and outputs):
+    // a uniform, field-wise select of the kernel arguments
+    const bool second = (int)blockIdx.x >= a0.B;
+    const cic_sampler_args a = second ? a1 : a0;
+    const int b = second ? blockIdx.x - a0.B : blockIdx.x, tid = threadIdx.x;
     const int V1 = a.V1;
     float* row = a.logits + (size_t)b * a.ld;
     const bool vec = ((a.ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.logits) & 15) == 0);
@@ -618,23 +644,34 @@ extern "C" int cic_debug_set_attn_stamps(unsigned long long* buf) {
 extern "C" int cic_attn_fwd(const float* att_h, const float* p_att, const float* att, const float* w_alpha,
                             const float* b_alpha, const float* masks, float* att_res, float* alpha,
                             float* dot, int B, int K, int A, int H, cic_stream_t s) {
+    return cic_attn_fwd2(dual1(att_h), dual1(p_att), dual1(att), w_alpha, b_alpha, masks, dual1(att_res), dual1(alpha),
+                         dual1(dot), B, 1, K, A, H, cic_s(s));
+}
+
+bool cic_attn_pair_ok(int K, int A, int H) { return A == H && (H & 63) == 0 && H <= 512 && K <= 64; }
+
+int cic_attn_fwd2(Dual<const float> att_h_d, Dual<const float> p_att_d, Dual<const float> att_d, const float* w_alpha,
+                  const float* b_alpha, const float* masks, Dual<float> att_res_d, Dual<float> alpha_d, Dual<float> dot_d,
+                  int B, int nb, int K, int A, int H, hipStream_t st) {
+    const float *att_h = att_h_d.a, *p_att = p_att_d.a, *att = att_d.a;
+    float *att_res = att_res_d.a, *alpha = alpha_d.a, *dot = dot_d.a;
     CIC_REQUIRE(att_h && p_att && att && w_alpha && b_alpha && att_res && alpha);
     CIC_REQUIRE(B > 0 && K > 0 && K <= 64 && (A & 3) == 0 && (H & 3) == 0);
+    CIC_REQUIRE(nb == 1 || (nb == 2 && cic_attn_pair_ok(K, A, H) && att_h_d.b && p_att_d.b && att_d.b && att_res_d.b && alpha_d.b));
     const int mx = A > H ? A : H;
     CIC_REQUIRE(mx <= 1024);
-    dim3 grid(B);
-    hipStream_t st = cic_s(s);
-    if (A == H && (H & 63) == 0 && H <= 512 && K <= 64) {   // column-owner kernel (one barrier, no vector reduce)
+    dim3 grid(nb * B);
+    if (cic_attn_pair_ok(K, A, H)) {   // column-owner kernel (one barrier, no vector reduce)
         // one 32-column group per wave (16 waves at H = 512).  Two groups per wave (8 waves) measured slower:
         // 6.9 us vs 6.4 us in-kernel span at B = 128.
         const int ncg = 1;
         dim3 blk((H / 32 / ncg) * 64);
 #define GOC(J)                                                                                                       \
     do {                                                                                                             \
-        if (ncg == 2) hipLaunchKernelGGL((attn_fwd_cols_kernel<J, 2>), grid, blk, 0, st, att_h, p_att, att, w_alpha,  \
-                                         b_alpha, masks, att_res, alpha, dot, K, H);                                 \
-        else hipLaunchKernelGGL((attn_fwd_cols_kernel<J, 1>), grid, blk, 0, st, att_h, p_att, att, w_alpha, b_alpha,  \
-                                masks, att_res, alpha, dot, K, H);                                                   \
+        if (ncg == 2) hipLaunchKernelGGL((attn_fwd_cols_kernel<J, 2>), grid, blk, 0, st, att_h_d, p_att_d, att_d, w_alpha, \
+                                         b_alpha, masks, att_res_d, alpha_d, dot_d, B, K, H);                        \
+        else hipLaunchKernelGGL((attn_fwd_cols_kernel<J, 1>), grid, blk, 0, st, att_h_d, p_att_d, att_d, w_alpha,     \
+                                b_alpha, masks, att_res_d, alpha_d, dot_d, B, K, H);                                 \
     } while (0)
         if (K <= 8) GOC(1); else if (K <= 16) GOC(2); else if (K <= 24) GOC(3); else if (K <= 32) GOC(4);
         else if (K <= 40) GOC(5); else if (K <= 48) GOC(6); else GOC(8);
@@ -713,20 +750,31 @@ extern "C" int cic_attn_fwd_timed(const float* att_h, const float* p_att, const 
 
 extern "C" int cic_cell_fwd(const float* pre, const float* c_prev, const uint8_t* keep, float p_drop,
                             float* h_new, float* c_new, float* out, int B, int H, cic_stream_t s) {
-    CIC_REQUIRE(pre && c_prev && h_new && c_new && out && B > 0 && H > 0 && (H & 3) == 0);
-    const int n = B * (H / 4);
-    hipLaunchKernelGGL(cell_fwd_kernel, dim3(cic_cdiv(n, 256)), dim3(256), 0, cic_s(s), pre, c_prev, keep,
-                       1.0f / (1.0f - p_drop), h_new, c_new, out, B, H);
+    return cic_cell_fwd2(dual1(pre), dual1(c_prev), dual1(keep), p_drop, dual1(h_new), dual1(c_new), dual1(out), B, 1, H,
+                         cic_s(s));
+}
+int cic_cell_fwd2(Dual<const float> pre, Dual<const float> c_prev, Dual<const uint8_t> keep, float p_drop, Dual<float> h_new,
+                  Dual<float> c_new, Dual<float> out, int B, int nb, int H, hipStream_t st) {
+    CIC_REQUIRE(pre.a && c_prev.a && h_new.a && c_new.a && out.a && B > 0 && H > 0 && (H & 3) == 0);
+    CIC_REQUIRE(nb == 1 || (nb == 2 && pre.b && c_prev.b && h_new.b && c_new.b && out.b));
+    const int n = nb * B * (H / 4);
+    hipLaunchKernelGGL(cell_fwd_kernel, dim3(cic_cdiv(n, 256)), dim3(256), 0, st, pre, c_prev, keep,
+                       1.0f / (1.0f - p_drop), h_new, c_new, out, B, nb, H);
     CIC_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int cic_embed_fwd(const float* E, const int32_t* it, const uint8_t* keep, float p_drop, float* x,
                              int B, int Ed, cic_stream_t s) {
-    CIC_REQUIRE(E && it && x && B > 0 && Ed > 0 && (Ed & 3) == 0);
-    const int n = B * (Ed / 4);
-    hipLaunchKernelGGL(embed_fwd_kernel, dim3(cic_cdiv(n, 256)), dim3(256), 0, cic_s(s), E, it, keep,
-                       1.0f / (1.0f - p_drop), x, B, Ed);
+    return cic_embed_fwd2(E, dual1(it), dual1(keep), p_drop, dual1(x), B, 1, Ed, cic_s(s));
+}
+int cic_embed_fwd2(const float* E, Dual<const int32_t> it, Dual<const uint8_t> keep, float p_drop, Dual<float> x, int B,
+                   int nb, int Ed, hipStream_t st) {
+    CIC_REQUIRE(E && it.a && x.a && B > 0 && Ed > 0 && (Ed & 3) == 0);
+    CIC_REQUIRE(nb == 1 || (nb == 2 && it.b && x.b));
+    const int n = nb * B * (Ed / 4);
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(cic_cdiv(n, 256)), dim3(256), 0, st, E, it, keep, 1.0f / (1.0f - p_drop), x,
+                       B, nb, Ed);
     CIC_LAUNCH_CHECK();
     return 0;
 }
@@ -754,7 +802,33 @@ int cic_soft_mask(const float* soft_raw, const int32_t* seq, const int32_t* L, f
     return 0;
 }
 
+static int check_sampler_args(const cic_sampler_args* a);
+
 extern "C" int cic_logsoftmax_sample(const cic_sampler_args* a, cic_stream_t s) {
+    return cic_logsoftmax_sample2(a, nullptr, cic_s(s));
+}
+
+// one launch for the samplers of one decode (b == NULL) or of a pair of decodes (rows of b follow those of a)
+int cic_logsoftmax_sample2(const cic_sampler_args* a, const cic_sampler_args* b, hipStream_t st) {
+    if (int rc = check_sampler_args(a)) return rc;
+    if (b) {
+        if (int rc = check_sampler_args(b)) return rc;
+        CIC_REQUIRE(b->V1 == a->V1);
+    }
+    dim3 grid(a->B + (b ? b->B : 0)), blk(1024);
+    const cic_sampler_args& b_ = b ? *b : *a;
+    if (a->V1 <= 4096) hipLaunchKernelGGL((logsoftmax_sample_kernel<1>), grid, blk, 0, st, *a, b_);
+    else if (a->V1 <= 12288) hipLaunchKernelGGL((logsoftmax_sample_kernel<3>), grid, blk, 0, st, *a, b_);
+    else if (a->V1 <= 32768) hipLaunchKernelGGL((logsoftmax_sample_kernel<8>), grid, blk, 0, st, *a, b_);
+    else {
+        cic_set_error("cic_logsoftmax_sample: vocabulary %d too large (max 32768)", a->V1);
+        return 1;
+    }
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+
+static int check_sampler_args(const cic_sampler_args* a) {
     CIC_REQUIRE(a && a->logits && a->B > 0 && a->V1 > 0 && a->ld >= a->V1);
     if (a->mode != CIC_SAMPLE_NONE) {
         CIC_REQUIRE(a->unfinished && a->it_next && a->seq && a->slp && a->any_unfinished && a->step >= 1);
@@ -768,16 +842,6 @@ extern "C" int cic_logsoftmax_sample(const cic_sampler_args* a, cic_stream_t s) 
         CIC_REQUIRE(!ps || (a->soft && a->ld_soft >= a->V1));
         CIC_REQUIRE(!needs_u || (a->U && a->ldu >= a->V1));
     }
-    dim3 grid(a->B), blk(1024);
-    hipStream_t st = cic_s(s);
-    if (a->V1 <= 4096) hipLaunchKernelGGL((logsoftmax_sample_kernel<1>), grid, blk, 0, st, *a);
-    else if (a->V1 <= 12288) hipLaunchKernelGGL((logsoftmax_sample_kernel<3>), grid, blk, 0, st, *a);
-    else if (a->V1 <= 32768) hipLaunchKernelGGL((logsoftmax_sample_kernel<8>), grid, blk, 0, st, *a);
-    else {
-        cic_set_error("cic_logsoftmax_sample: vocabulary %d too large (max 32768)", a->V1);
-        return 1;
-    }
-    CIC_LAUNCH_CHECK();
     return 0;
 }
 

@@ -79,9 +79,34 @@ def speaker_att_embed_fwd(dims, params, att_raw, att_pre=None):
     return att_pre
 
 
-def speaker_decode_fwd(dims, params, att_pre, mode, temp=1.0, att_masks=None, att_keep=None, x_keep=None,
-                       out_keep=None, U=None, pick=None, decoding_constraint=0, want_stv=False, ws=None,
-                       first_token=None, out=None, ss_u=None, ss_prob=0.0, ss_pick=None, ps_u=None, ps_prob=0.0):
+lib.cic_speaker_decode_fwd_pair.argtypes = [C.POINTER(SpeakerDims), C.POINTER(SpeakerParams), C.POINTER(DecodeIO), P,
+                                            C.c_size_t, C.POINTER(DecodeIO), P, C.c_size_t, P]
+lib.cic_speaker_decode_fwd_pair.restype = C.c_int
+
+
+def speaker_decode_fwd(dims, params, att_pre, mode, temp=1.0, *args, **kw):
+    return speaker_decode_launch(dims, params, speaker_decode_io(dims, params, att_pre, mode, temp, *args, **kw))
+
+
+def speaker_decode_launch(dims, params, out):
+    ws = out['ws']
+    check(lib.cic_speaker_decode_fwd(C.byref(dims), C.byref(params), C.byref(out['io']), ws.data_ptr(), ws.numel(),
+                                     stream()), 'cic_speaker_decode_fwd')
+    return out
+
+
+def speaker_decode_fwd_pair(dims, params, a, b):
+    """a, b: dicts from speaker_decode_io (two decodes of the same images and weights).  One launch per
+    per-timestep kernel over the rows of both; results identical to two speaker_decode_fwd calls."""
+    check(lib.cic_speaker_decode_fwd_pair(C.byref(dims), C.byref(params), C.byref(a['io']), a['ws'].data_ptr(),
+                                          a['ws'].numel(), C.byref(b['io']), b['ws'].data_ptr(), b['ws'].numel(),
+                                          stream()), 'cic_speaker_decode_fwd_pair')
+    return a, b
+
+
+def speaker_decode_io(dims, params, att_pre, mode, temp=1.0, att_masks=None, att_keep=None, x_keep=None,
+                      out_keep=None, U=None, pick=None, decoding_constraint=0, want_stv=False, ws=None,
+                      first_token=None, out=None, ss_u=None, ss_prob=0.0, ss_pick=None, ps_u=None, ps_prob=0.0):
     """-> dict(seq i32[B,T], slp f32[B,T], stv f32[B,T]|None, L i32[1], ws); partial-sampling modes add
     soft f32[T,B,V+1] (the caption rows handed to the listener) and the saved soft_raw / xpre."""
     dev = att_pre.device
@@ -108,8 +133,6 @@ def speaker_decode_fwd(dims, params, att_pre, mode, temp=1.0, att_masks=None, at
     io.U, io.pick, io.first_token = _p(U), _p(pick), _p(first_token)
     io.ss_u, io.ss_prob, io.ss_pick = _p(ss_u), float(ss_prob), _p(ss_pick)
     io.seq, io.slp, io.stv, io.L = _p(out['seq']), _p(out['slp']), _p(out['stv']), _p(out['L'])
-    check(lib.cic_speaker_decode_fwd(C.byref(dims), C.byref(params), C.byref(io), ws.data_ptr(), ws.numel(),
-                                     stream()), 'cic_speaker_decode_fwd')
     out['io'] = io
     out['_keep'] = (att_pre, att_masks, att_keep, x_keep, out_keep, U, pick, first_token, ss_u, ss_pick, ps_u)   # alive until the backward call
     return out

@@ -53,11 +53,10 @@ class AlternatingJointModel(nn.Module):
         self.cider_optimization = getattr(opt, 'cider_optimization', 0)
         self.use_gen_cider_scores = getattr(opt, 'use_gen_cider_scores', 0)
         self._loss = {}
-        # MI355X: the greedy (baseline) decode of the CIDEr term is independent of the sampled decode and the
-        # listener pass until the reward: it runs on a second HIP stream so that two latency-bound launch
-        # chains share the chip.  Off by default: see the measurement below.
-        self.overlap_greedy = False   # measured: 8.9 ms/step overlapped vs 8.2 ms serial (side-stream launches are slower on this stack)
-        self._side_stream = None
+        # MI355X: the greedy (baseline) decode and the sampled decode of a step read the same images and weights
+        # and are independent until the reward, so they advance in lock step through shared launches
+        # (cic_speaker_decode_fwd_pair: every per-timestep kernel once over 2B rows; bit-identical results).
+        self.pair_decodes = True
         # Load model (:131-177)
         if opt.is_alternating:
             if getattr(opt, 'continue_from_existing_models', False):
@@ -151,25 +150,21 @@ class AlternatingJointModel(nn.Module):
         sample = None
         greedy = None
         dslp = None
-        greedy_event = None
-        wants_async_greedy = bool(ciw) and self.overlap_greedy and not (
-            dw > 0 and rr == 'reinforce' and self.reinforce_baseline_type == 'greedy')
-        if wants_async_greedy:
-            main = torch.cuda.current_stream(dev)
-            if self._side_stream is None or self._side_stream.device != dev:
-                self._side_stream = torch.cuda.Stream(device=dev)
-            side = self._side_stream
-            side.wait_stream(main)                                     # att_pre, staged inputs, parameters
-            with torch.cuda.stream(side):
-                greedy = cg.decode(att_feats, att_masks, 'greedy', att_pre=att_pre, tag='greedy')   # :391-403
-                greedy_event = side.record_event()
+        need_greedy = bool(ciw) or (dw > 0 and rr == 'reinforce' and self.reinforce_baseline_type == 'greedy')
+
+        def sampled_with_greedy(**spec):
+            """The sampled decode of the step, together with the greedy decode when the step needs one."""
+            if need_greedy and greedy is None and self.pair_decodes:
+                return cg.decode_pair(att_feats, att_masks, spec, dict(mode='greedy', tag='greedy'), att_pre=att_pre)
+            return cg.decode(att_feats, att_masks, att_pre=att_pre, **spec), greedy
         if dw > 0:                                                     # DISC loss :455-488
             if rr == 'reinforce':
-                sample = cg.decode(att_feats, att_masks, 'multinomial', 1.0, att_pre=att_pre, grad=spk_grad)  # :226-247
+                sample, greedy = sampled_with_greedy(mode='multinomial', temp=1.0, grad=spk_grad)   # :226-247
                 gen = vse.run(fc_feats, decode=sample, only_one_retrieval=oor, slot=2)
                 btype = self.reinforce_baseline_type
                 if btype == 'greedy':                                  # :250-298
-                    greedy = cg.decode(att_feats, att_masks, 'greedy', att_pre=att_pre, tag='greedy')
+                    if greedy is None:
+                        greedy = cg.decode(att_feats, att_masks, 'greedy', att_pre=att_pre, tag='greedy')
                     base = vse.run(fc_feats, decode=greedy, only_one_retrieval=oor, slot=3).loss_rows
                 elif btype == 'gt':                                    # :300-310
                     base = vse.run(fc_feats, labels=seq, masks=masks, only_one_retrieval=oor, slot=3).loss_rows
@@ -187,7 +182,10 @@ class AlternatingJointModel(nn.Module):
                         'multinomial_soft': 'multinomial_ps'}[rr]
                 temp = cg.gumbel_temp if rr in ('gumbel', 'gumbel_softmax') else cg.multinomial_temp
                 ps_prob = {'gumbel_softmax': cg.prob_gumbel_softmax, 'multinomial_soft': cg.prob_multinomial_soft}.get(rr, 0.0)
-                sample = cg.decode(att_feats, att_masks, mode, temp, att_pre=att_pre, grad=spk_grad, ps_prob=ps_prob)
+                if mode.endswith('_ps'):     # soft-input steps: not row-wise launches, decoded on its own
+                    sample = cg.decode(att_feats, att_masks, mode, temp, att_pre=att_pre, grad=spk_grad, ps_prob=ps_prob)
+                else:
+                    sample, greedy = sampled_with_greedy(mode=mode, temp=temp, grad=spk_grad)
                 gen = vse.run(fc_feats, decode=sample, only_one_retrieval=oor, slot=2)
                 vse._loss['contrastive'] = gen.loss_sum.detach()[0]
                 terms.append((dw, gen.loss_sum))
@@ -207,12 +205,10 @@ class AlternatingJointModel(nn.Module):
                 raise ValueError(f'unknown retrieval_reward {rr!r}')
         if ciw:                                                        # CIDEr loss :490-503
             if sample is None or rr in ('multinomial_soft', 'gumbel_softmax'):
-                sample = cg.decode(att_feats, att_masks, 'multinomial', 1.0, att_pre=att_pre, grad=spk_grad,
-                                   tag='cider_gen')                    # gen_result_for_cider :378-389
+                sample, greedy = sampled_with_greedy(mode='multinomial', temp=1.0, grad=spk_grad,
+                                                     tag='cider_gen')  # gen_result_for_cider :378-389
             if greedy is None:
                 greedy = cg.decode(att_feats, att_masks, 'greedy', att_pre=att_pre, tag='greedy')   # :391-403
-            if greedy_event is not None:
-                torch.cuda.current_stream(dev).wait_event(greedy_event)
             refs, ref_off = self._refs(data, dev)
             rw = rewards.get_self_critical_reward_device(refs, ref_off, sample, greedy)
             coef = rw['scores'][:B].float().contiguous() if self.use_gen_cider_scores else rw['reward']

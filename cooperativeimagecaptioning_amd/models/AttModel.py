@@ -127,9 +127,26 @@ class AttModel(nn.Module):
         att_pre = self._buf.get('att_pre', (B, K, self.rnn_size), torch.float32, att_raw.device)
         return engine.speaker_att_embed_fwd(dims, params, att_raw, att_pre)
 
-    def decode(self, att_feats, att_masks, mode, temp=1.0, att_pre=None, grad=False, T=None, pick=None,
-               first_token=None, decoding_constraint=None, tag='sample', want_stv=None, ss_prob=0.0, ps_prob=0.0):
+    def decode(self, att_feats, att_masks, mode, temp=1.0, **kw):
         """One AttModel.sample / AttModel.forward pass on the device -> DecodeResult."""
+        dims, params, io, (mode, att_raw, grad, ws_key) = self._decode_io(att_feats, att_masks, mode, temp, **kw)
+        engine.speaker_decode_launch(dims, params, io)
+        return DecodeResult(io, mode, dims, params, att_raw, grad)
+
+    def decode_pair(self, att_feats, att_masks, spec_a, spec_b, att_pre=None):
+        """Two decodes of the same images (spec = dict(mode=..., temp=..., **decode kwargs)) advanced in lock step
+        through shared launches: every per-timestep kernel runs once over 2B rows.  Same results as two decode()
+        calls, bit for bit.  -> (DecodeResult a, DecodeResult b)."""
+        ra = self._decode_io(att_feats, att_masks, att_pre=att_pre, **spec_a)
+        rb = self._decode_io(att_feats, att_masks, att_pre=att_pre, **spec_b)
+        (dims, params, ia, (ma, att_raw, ga, _)), (dims_b, _, ib, (mb, _, gb, _)) = ra, rb
+        assert (dims.B, dims.K, dims.T) == (dims_b.B, dims_b.K, dims_b.T), 'paired decodes share their shapes'
+        engine.speaker_decode_fwd_pair(dims, params, ia, ib)
+        return DecodeResult(ia, ma, dims, params, att_raw, ga), DecodeResult(ib, mb, dims_b, params, att_raw, gb)
+
+    def _decode_io(self, att_feats, att_masks, mode, temp=1.0, att_pre=None, grad=False, T=None, pick=None,
+                   first_token=None, decoding_constraint=None, tag='sample', want_stv=None, ss_prob=0.0, ps_prob=0.0):
+        """Stages inputs, draws the noise and fills the C-ABI io struct of one decode (no launch of the loop)."""
         self._check_inputs(att_feats)
         fl = self.flat()
         B, K, _ = att_feats.shape
@@ -177,15 +194,16 @@ class AttModel(nn.Module):
             pick = self._buf.stage((tag, 'pick'), pick.contiguous(), torch.int64)
         if first_token is not None:
             first_token = self._buf.stage((tag, 'first'), first_token.contiguous(), torch.int64)
-        fwd = engine.speaker_decode_fwd(dims, params, att_pre, MODES[mode], temp, att_masks,
-                                        nz.get('att_keep'), nz.get('x_keep'), nz.get('out_keep'), nz.get('gumbel_u'),
-                                        pick, self.decoding_constraint if decoding_constraint is None else decoding_constraint,
-                                        want_stv=want_stv, ws=self._ws.get(ws_key), first_token=first_token, out=out,
-                                        ss_u=nz.get('ss_u') if ss else None, ss_prob=ss_prob if ss else 0.0,
-                                        ss_pick=ss_pick, ps_u=nz.get('ps_u') if ps else None,
-                                        ps_prob=ps_prob if ps else 0.0)
+        fwd = engine.speaker_decode_io(dims, params, att_pre, MODES[mode], temp, att_masks=att_masks,
+                                       att_keep=nz.get('att_keep'), x_keep=nz.get('x_keep'), out_keep=nz.get('out_keep'),
+                                       U=nz.get('gumbel_u'), pick=pick,
+                                       decoding_constraint=self.decoding_constraint if decoding_constraint is None else decoding_constraint,
+                                       want_stv=want_stv, ws=self._ws.get(ws_key), first_token=first_token, out=out,
+                                       ss_u=nz.get('ss_u') if ss else None, ss_prob=ss_prob if ss else 0.0,
+                                       ss_pick=ss_pick, ps_u=nz.get('ps_u') if ps else None,
+                                       ps_prob=ps_prob if ps else 0.0)
         self._ws[ws_key] = fwd['ws']
-        return DecodeResult(fwd, mode, dims, params, att_raw, grad)
+        return dims, params, fwd, (mode, att_raw, grad, ws_key)
 
     def decode_backward(self, res, d_onehot=None, dslp=None):
         fl = self.flat()

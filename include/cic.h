@@ -59,6 +59,8 @@ int cic_debug_empty(int grid, int block, cic_stream_t s);
 /* diagnostics: per-workgroup phase stamps of the register-streaming GEMM (NULL = off) */
 int cic_debug_set_stamps(unsigned long long* buf);
 int cic_debug_set_attn_stamps(unsigned long long* buf);
+/* diagnostics: 0 turns the K-sliced tail tiles of the large GEMMs off (fixed summation order; A/B timing) */
+int cic_debug_gemm_tail_split(int on);
 
 /* ---- RNG (replaces torch.rand / nn.Dropout's bernoulli_ draws) ---------------------- */
 /* Philox4x32-10 counter RNG.  u[i] = (r >> 8) * 2^-24 in [0,1), as torch.rand does
@@ -88,6 +90,16 @@ typedef struct {
     const float* bias;            /* [N] or NULL */
     int accumulate;               /* C += ... */
     int relu;
+    /* Row blocks (optional, per-timestep products of a PAIR of decodes advancing in lock step): when
+     * rows_blk > 0, rows [rows_blk, M) of op(A), op(A2) and C live at A_b, A2_b and C_b (row 0 of those
+     * = row rows_blk of the product).  Requires a_kc != 0, rows_blk % 32 == 0, M <= 2*rows_blk <= 256. */
+    int sum_order_free;           /* != 0: the caller accepts a summation order that varies run to run (partial tiles
+                                     combined with float atomics).  The engines set it for gradient products only;
+                                     forward activations keep a fixed order. */
+    int rows_blk;
+    const float* A_b;
+    const float* A2_b;
+    float* C_b;
 } cic_gemm_args;
 int cic_gemm_f32(const cic_gemm_args* a, cic_stream_t s);
 /* out[n] (+)= sum_m X[m*ldx + n]   — bias gradients. */
@@ -230,6 +242,14 @@ size_t cic_speaker_decode_ws_bytes(const cic_speaker_dims* d);
  * sync (the reference's early break is replaced by the device-side length L). */
 int cic_speaker_decode_fwd(const cic_speaker_dims* d, const cic_speaker_params* p, const cic_decode_io* io,
                            void* ws, size_t ws_bytes, cic_stream_t s);
+
+/* Two decodes of the same images and parameters (same dims, e.g. the sampled and the greedy decode of a
+ * joint step, AlternatingJointModel.py:346,391-403) advanced in lock step: every per-timestep kernel runs once
+ * over 2B rows.  Bit-identical to two cic_speaker_decode_fwd calls (which is also the fallback for shapes the
+ * paired kernels do not cover); each decode keeps its own workspace for its backward pass. */
+int cic_speaker_decode_fwd_pair(const cic_speaker_dims* d, const cic_speaker_params* p,
+                                const cic_decode_io* io_a, void* ws_a, size_t ws_a_bytes,
+                                const cic_decode_io* io_b, void* ws_b, size_t ws_b_bytes, cic_stream_t s);
 
 typedef struct {
     const float* d_onehot;   /* [T,B,V+1] gradient w.r.t. the ST one-hot rows / the soft rows io->soft_out (from

@@ -87,3 +87,52 @@ def test_decode_matches_reference(name, mode):
         np.testing.assert_allclose(soft, ref[:, :, :V1], rtol=2e-4, atol=2e-7)
         np.testing.assert_array_equal(soft == 0, ref[:, :, :V1] == 0)          # same rows are hard / finished
         assert not ref[:, :, V1:].any()
+
+
+@pytest.mark.parametrize('B,dims', [(32, dict(K=36, D=64, H=512, V=9487, T=16)), (64, dict(K=9, D=32, H=64, V=199, T=16)),
+                                    (6, dict(K=9, D=32, H=64, V=199, T=16))])
+def test_paired_decodes_equal_sequential_decodes(B, dims):
+    """cic_speaker_decode_fwd_pair (sampled + greedy decode in lock step, one launch per kernel over 2B rows) leaves
+    exactly the bytes two sequential cic_speaker_decode_fwd calls leave: outputs AND the whole saved-activation
+    workspaces.  B = 6 takes the documented fallback (row blocks need B % 32 == 0)."""
+    from cooperativeimagecaptioning_amd import engine, _lib
+    K, D, H, V, T = dims['K'], dims['D'], dims['H'], dims['V'], dims['T']
+    g = torch.Generator().manual_seed(100 + B)
+
+    def lin(o, i, s=1.0):
+        r = s / np.sqrt(i)
+        return ((torch.rand(o, i, generator=g) * 2 - 1) * r).cuda(), ((torch.rand(o, generator=g) * 2 - 1) * r).cuda()
+    W = {'embed.0.weight': torch.randn(V + 2, H, generator=g).cuda()}
+    for nm, (o, i, s) in {'att_embed.0': (H, D, 1), 'logit': (V + 1, H, 6), 'ctx2att': (H, H, 1), 'core.a2c': (2 * H, H, 1),
+                          'core.i2h': (5 * H, H, 1), 'core.h2h': (5 * H, H, 1), 'core.attention.h2att': (H, H, 1),
+                          'core.attention.alpha_net': (1, H, 3)}.items():
+        W[nm + '.weight'], W[nm + '.bias'] = lin(o, i, s)
+    W['logit.bias'][0] = 2.5          # captions end at different steps
+    p = 0.5
+    d = engine.speaker_dims(B, K, D, H, H, H, V, T, p)
+    params = engine.speaker_params(W)
+    att_pre = engine.speaker_att_embed_fwd(d, params, (torch.randn(B, K, D, generator=g).abs() * 0.5).cuda())
+
+    def noise():
+        return dict(att_keep=(torch.rand(B, K, H, generator=g) >= p).to(torch.uint8).cuda(),
+                    x_keep=(torch.rand(T + 1, B, H, generator=g) >= p).to(torch.uint8).cuda(),
+                    out_keep=(torch.rand(T + 1, B, H, generator=g) >= p).to(torch.uint8).cuda())
+    na, nb_ = noise(), noise()
+    U = torch.rand(T + 1, B, V + 1, generator=g).cuda()
+
+    def specs():
+        a = engine.speaker_decode_io(d, params, att_pre, _lib.SAMPLE_GUMBEL_ST, 1.0, U=U, want_stv=True, **na)
+        b = engine.speaker_decode_io(d, params, att_pre, _lib.SAMPLE_GREEDY, 1.0, **nb_)
+        a['ws'].zero_(), b['ws'].zero_()
+        return a, b
+    a0, b0 = specs()
+    engine.speaker_decode_launch(d, params, a0)
+    engine.speaker_decode_launch(d, params, b0)
+    a1, b1 = specs()
+    engine.speaker_decode_fwd_pair(d, params, a1, b1)
+    torch.cuda.synchronize()
+    assert 0 < int(a0['L']) <= T and 0 < int(b0['L']) <= T
+    for x, y in ((a0, a1), (b0, b1)):
+        for k in ('seq', 'slp', 'stv', 'L', 'ws'):
+            if x[k] is not None:
+                assert torch.equal(x[k], y[k]), k

@@ -26,7 +26,11 @@ def main():
     shapes = [(128, 512, 512, 1, 1), (128, 2560, 512, 1, 1), (128, 1024, 512, 1, 1), (128, 9488, 512, 1, 1),
               (128, 3072, 1024, 1, 1), (4608, 512, 2048, 1, 1), (4608, 512, 512, 1, 1),
               (2048, 512, 9488, 1, 0), (9488, 512, 2048, 0, 0), (2560, 512, 2048, 0, 0),
-              (2048, 9488, 512, 1, 1), (512, 2048, 4608, 0, 0), (128, 512, 2560, 1, 0), (2176, 3072, 512, 1, 1)]
+              (2048, 9488, 512, 1, 1), (512, 2048, 4608, 0, 0), (128, 512, 2560, 1, 0), (2176, 3072, 512, 1, 1),
+              (128, 512, 1024, 1, 0), (128, 512, 3072, 1, 0), (128, 1024, 3072, 1, 0), (4608, 512, 512, 1, 0),
+              (512, 512, 4608, 0, 0), (2048, 512, 2560, 1, 0), (512, 512, 2048, 0, 0), (1024, 512, 2048, 0, 0),
+              (2176, 512, 3072, 1, 0), (3072, 512, 2176, 0, 0), (3072, 1024, 2176, 0, 0), (2176, 9488, 512, 1, 1),
+              (9488, 512, 2176, 0, 0), (128, 128, 1024, 1, 1)]
     for M, N, K, akc, bkc in shapes:
         A = torch.randn((M, K) if akc else (K, M), device=dev)
         B = torch.randn((N, K) if bkc else (K, N), device=dev)
