@@ -73,12 +73,12 @@ static inline int gemm_nt2(const float* A1, int lda1, const float* W1, int ldw1,
 // C[M,N] = A[M,K] Bm[K,N] (+C)                    — dX = dY W   (W stored [K=out, N=in]); a gradient product:
 // the summation order is free
 static inline int gemm_nn(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K,
-                          bool accumulate, hipStream_t st, bool order_free = true) {
+                          bool accumulate, hipStream_t st, bool order_free = true, bool c_is_zero = false) {
     cic_gemm_args g = {};
     g.M = M; g.N = N; g.K = K;
     g.A = A; g.lda = lda; g.a_kc = 1;
     g.B = Bm; g.ldb = ldb; g.b_kc = 0;
-    g.C = C; g.ldc = ldc; g.accumulate = accumulate; g.sum_order_free = order_free;
+    g.C = C; g.ldc = ldc; g.accumulate = accumulate; g.sum_order_free = order_free; g.c_is_zero = c_is_zero;
     return cic_gemm_f32(&g, st);
 }
 // the same product in a FORWARD pass (soft caption rows @ embedding): fixed summation order
@@ -89,13 +89,13 @@ static inline int gemm_nn_fwd(const float* A, int lda, const float* Bm, int ldb,
 // C = A1 B1 + A2 B2 (+C), all B stored [K,N]
 static inline int gemm_nn2(const float* A1, int lda1, const float* B1, int ldb1, int K1, const float* A2, int lda2,
                            const float* B2, int ldb2, int K2, float* C, int ldc, int M, int N, bool accumulate,
-                           hipStream_t st) {
+                           hipStream_t st, bool c_is_zero = false) {
     cic_gemm_args g = {};
     g.M = M; g.N = N; g.K = K1;
     g.A = A1; g.lda = lda1; g.a_kc = 1;
     g.B = B1; g.ldb = ldb1; g.b_kc = 0;
     g.K2 = K2; g.A2 = A2; g.lda2 = lda2; g.B2 = B2; g.ldb2 = ldb2;
-    g.C = C; g.ldc = ldc; g.accumulate = accumulate; g.sum_order_free = 1;
+    g.C = C; g.ldc = ldc; g.accumulate = accumulate; g.sum_order_free = 1; g.c_is_zero = c_is_zero;
     return cic_gemm_f32(&g, st);
 }
 // C[M,N] = At[K,M]^T Bm[K,N] (+C)                 — dW = dY^T X

@@ -20,6 +20,11 @@ namespace {
 
 bool aligned16(const void* p);
 
+// measurement / determinism switches, set through cic_debug_gemm_tail_split(flags)
+int g_tail_split = 1;   // bit 0: K-sliced tail tiles and K split over workgroups (float atomics) on / off
+int g_force_tile = 0;   // bits 8..15: 1 = 128x128, 2 = 64x64 tiles forced
+int g_walk = 1;         // bit 16 set: strip walkers off
+
 constexpr int BK = 32;
 constexpr int KCS = BK + 4;  // row stride of a K-contiguous LDS image (floats)
 
@@ -389,7 +394,8 @@ __global__ __launch_bounds__(KS * 64) void gemm_rega_kernel(cic_gemm_args g, int
     auto load_chunk = [&](f32x4 (&af)[CH], f32x4 (&bf)[CH], int c) {
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            const int k = 8 * (ks * gps + c * CH + i) + 4 * h;   // first of this lane's 4 k's (K1 % 8 == 0)
+            // first of this lane's 4 k's (K1 % 8 == 0); blockIdx.y = K part of a product split over workgroups
+            const int k = 8 * ((blockIdx.y * KS + ks) * gps + c * CH + i) + 4 * h;
             const bool kok = k < Kt;
             const bool second = kok && k >= K1;
             const float* A = second ? gA2 : gA;
@@ -444,10 +450,17 @@ __global__ __launch_bounds__(KS * 64) void gemm_rega_kernel(cic_gemm_args g, int
         const int mm = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (mm < Mloc && nok) {
             float* c = gC + (size_t)mm * g.ldc + n;
-            if (g.bias) v += g.bias[n];
-            if (g.accumulate) v += *c;
-            if (g.relu) v = fmaxf(v, 0.f);
-            *c = v;
+            if (gridDim.y > 1) {
+                // K split over workgroups (gradient products only): partial tiles meet in C through float atomics;
+                // C holds the accumulation target, or zeros written by the launcher / the producing kernel
+                if (g.bias && blockIdx.y == 0) v += g.bias[n];
+                atomicAdd(c, v);
+            } else {
+                if (g.bias) v += g.bias[n];
+                if (g.accumulate) v += *c;
+                if (g.relu) v = fmaxf(v, 0.f);
+                *c = v;
+            }
         }
     }
     if (stamps && lane == 0) {   // [block][wave][5]: start, first chunk done, MFMAs done, barrier passed, end (100 MHz ticks)
@@ -474,7 +487,11 @@ __global__ __launch_bounds__(KS * 64) void gemm_rega_loop_kernel(cic_gemm_args g
     const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
     const int h = lane >> 5, r = lane & 31;
     const int tiles_n = (g.N + 31) / 32;
-    const int strip = blockIdx.x % strips, first = blockIdx.x / strips, step = gridDim.x / strips;
+    // blockIdx -> (strip, walker): workgroups b and b+8 share an XCD (and its L2).  All `strips` workgroups that walk
+    // the SAME column tiles must sit on one XCD, so that a weight tile leaves the Infinity Cache / HBM once per
+    // launch and its other readers hit the L2: walker = blockIdx % step with step a multiple of 8.
+    const int step = gridDim.x / strips;
+    const int first = blockIdx.x % step, strip = blockIdx.x / step;
     int m0 = strip * 32;
     const bool blk2 = g.rows_blk > 0 && m0 >= g.rows_blk;   // row blocks: see gemm_rega_kernel
     const float* __restrict__ gA = blk2 ? g.A_b : g.A;
@@ -561,6 +578,129 @@ __global__ __launch_bounds__(KS * 64) void gemm_rega_loop_kernel(cic_gemm_args g
     }
 }
 
+
+// Strip walker: the persistent-strip idea above with FEWER, LONGER K slices.  A workgroup of KS waves owns one 32-row
+// strip of A (each wave keeps the MFMA A fragments of its K slice of 8*GPS in registers for the whole launch) and
+// walks column tiles first, first+step, ...; the next tile's B fragments are in flight under the current tile's
+// MFMA chain (GPS*4 MFMAs per wave and tile, 64 at GPS = 16 against 16 in the 16-wave kernels), and only KS
+// partial tiles meet in LDS.  With KS = 4 two or three workgroups share a CU, so one workgroup's cross-wave sum
+// and store run under the other's MFMAs.  The summation order (k inside a slice, then slices 0..KS-1) depends on
+// (K, KS, GPS) only, never on M or on the launch geometry.
+template <int GPS, int KS, bool KCB>
+__global__ __launch_bounds__(KS * 64) void gemm_walk_kernel(cic_gemm_args g, int strips) {
+    static_assert(16 % KS == 0, "accumulator registers are dealt evenly to the waves");
+    constexpr int EPW = 16 / KS;                       // accumulator registers each wave finishes
+    __shared__ float red[2 * KS * 16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
+    const int h = lane >> 5, r = lane & 31;
+    const int tiles_n = (g.N + 31) / 32;
+    // walker = blockIdx % step (step a multiple of 8): the workgroups that read the same weight tiles share an XCD
+    const int step = gridDim.x / strips;
+    const int first = blockIdx.x % step, strip = blockIdx.x / step;
+    int m0 = strip * 32;
+    const bool blk2 = g.rows_blk > 0 && m0 >= g.rows_blk;   // row blocks: see gemm_rega_kernel
+    const float* __restrict__ gA = blk2 ? g.A_b : g.A;
+    const float* __restrict__ gA2 = blk2 ? g.A2_b : g.A2;
+    float* __restrict__ gC = blk2 ? g.C_b : g.C;
+    const int Mloc = g.rows_blk > 0 ? (blk2 ? g.M - g.rows_blk : min(g.M, g.rows_blk)) : g.M;
+    if (blk2) m0 -= g.rows_blk;
+    const int m = m0 + r;
+    const int K1 = g.K, Kt = g.K + g.K2;
+    const bool mok = m < Mloc;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const int mc = mok ? m : Mloc - 1;
+    f32x4 af[GPS];
+#pragma unroll
+    for (int i = 0; i < GPS; ++i) {
+        const int k = 8 * (ks * GPS + i) + 4 * h;
+        const bool kok = k < Kt;
+        const bool second = kok && k >= K1;
+        const int kp = second ? g.K2 : K1;
+        int kk = second ? k - K1 : k;
+        kk = kk < kp - 4 ? kk : kp - 4;
+        const f32x4 a = *reinterpret_cast<const f32x4*>((second ? gA2 : gA) + (size_t)mc * (second ? g.lda2 : g.lda) + kk);
+        af[i] = (kok && mok) ? a : z4;
+    }
+    // B fragments live in ONE register set that is refilled chunk by chunk: as soon as the MFMAs of chunk c (CH groups
+    // of 8 k) of the current tile are issued, the loads of chunk c of the NEXT tile go out into the same registers, a
+    // full tile period (~GPS*4 MFMAs) before they are needed.
+    constexpr int CH = 4;
+    static_assert(GPS % CH == 0, "whole chunks");
+    f32x4 bf[GPS];
+    auto load_chunk = [&](int c, int t) {
+        const int tt = t < tiles_n ? t : tiles_n - 1;
+        const int n = tt * 32 + r;
+        const bool nok = t < tiles_n && n < g.N;
+        const int nc = n < g.N ? n : g.N - 1;
+#pragma unroll
+        for (int ii = 0; ii < CH; ++ii) {
+            const int i = c * CH + ii;
+            const int k = 8 * (ks * GPS + i) + 4 * h;
+            const bool kok = k < Kt;
+            const bool second = kok && k >= K1;
+            const float* B = second ? g.B2 : g.B;
+            const int ldb = second ? g.ldb2 : g.ldb;
+            const int kp = second ? g.K2 : K1;
+            int kk = second ? k - K1 : k;
+            kk = kk < kp - 4 ? kk : kp - 4;
+            f32x4 b;
+            if (KCB) {
+                b = *reinterpret_cast<const f32x4*>(B + (size_t)nc * ldb + kk);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = B[(size_t)(kk + j) * ldb + nc];
+            }
+            bf[i] = (kok && nok) ? b : z4;
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < GPS / CH; ++c) load_chunk(c, first);
+    int buf = 0;
+#pragma unroll 1
+    for (int t = first; t < tiles_n; t += step) {
+        const int n = t * 32 + r;
+        const int ncl = n < g.N ? n : g.N - 1;
+        float bias_v = 0.f, cold[EPW];                 // epilogue operands fetched before the barrier
+        if (g.bias) bias_v = g.bias[ncl];
+#pragma unroll
+        for (int q = 0; q < EPW; ++q) {
+            const int e = ks + KS * q;
+            const int mm = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const int mcl = mm < Mloc ? mm : Mloc - 1;
+            cold[q] = g.accumulate ? gC[(size_t)mcl * g.ldc + ncl] : 0.f;
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int c = 0; c < GPS / CH; ++c) {
+#pragma unroll
+            for (int ii = 0; ii < CH; ++ii)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c * CH + ii][s], bf[c * CH + ii][s], acc, 0, 0, 0);
+            load_chunk(c, t + step);                   // refill: the same chunk of the next tile
+        }
+        float* rb = red + buf * (KS * 16 * 64);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rb[(ks * 16 + e) * 64 + lane] = acc[e];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < EPW; ++q) {
+            const int e = ks + KS * q;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < KS; ++w) v += rb[(w * 16 + e) * 64 + lane];
+            v += bias_v + cold[q];
+            if (g.relu) v = fmaxf(v, 0.f);
+            const int mm = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (mm < Mloc && n < g.N) gC[(size_t)mm * g.ldc + n] = v;
+        }
+        buf ^= 1;
+    }
+}
+
+
 bool rega_ok(const cic_gemm_args& g) {
     if (!g.a_kc || g.M > (g.rows_blk > 0 ? 256 : 128)) return false;
     if (g.rows_blk > 0 && (!aligned16(g.A_b) || (g.K2 > 0 && !aligned16(g.A2_b)))) return false;
@@ -576,25 +716,50 @@ int launch_rega(const cic_gemm_args& g, hipStream_t st) {
     const int groups = cic_cdiv(Kt, 8);
     const int gps = cic_cdiv(cic_cdiv(groups, 16), 4) * 4;   // groups per K slice, multiple of the chunk size
     const int strips = cic_cdiv(g.M, 32), tiles_n = cic_cdiv(g.N, 32);
+    // Many column tiles (the logit, i2h/h2h and GRU products): strip walkers.  The choice depends on N and K only
+    // (never on M) so that a pair of decodes and a single decode sum every output in the same order.
+    // (measured, tools/step_gemms.py: at K = 1024 [M x 2560]: 30 vs 36 us, [128 x 3072]: 23 vs 26 us; at K = 512 the
+    // 16-wave persistent strips below are faster: 36 vs 42 us for the logit product.  With no B reloads and no
+    // cross-wave sum the walkers run their MFMA chains at ~90 % of the f32 rate: what holds these launches at 2x the
+    // MFMA floor is operand delivery, 32 cache lines per fragment load, and ~5 us of launch + first-load latency.)
+    if (g_walk && g.b_kc && tiles_n >= 64 && Kt == 1024) {
+        int nb = 256 / strips;                         // 8-wave workgroups, one per CU
+        if (nb > tiles_n) nb = tiles_n;
+        if (nb >= 8) nb &= ~7;
+        if (nb < 1) nb = 1;
+        hipLaunchKernelGGL((gemm_walk_kernel<16, 8, true>), dim3(strips * nb), dim3(512), 0, st, g, strips);
+        CIC_LAUNCH_CHECK();
+        return 0;
+    }
     if (gps <= 4 && strips * tiles_n > 512) {
         // persistent strips: one workgroup per CU, each walking several column tiles
         int nb = 256 / strips;
         if (nb < 1) nb = 1;
         if (nb > tiles_n) nb = tiles_n;
+        if (nb >= 8) nb &= ~7;            // walkers per strip: a multiple of the XCD count (see the kernel)
         dim3 lgrid(strips * nb), blk(1024);
         if (g.b_kc) hipLaunchKernelGGL((gemm_rega_loop_kernel<4, 16, true>), lgrid, blk, 0, st, g, strips);
         else hipLaunchKernelGGL((gemm_rega_loop_kernel<4, 16, false>), lgrid, blk, 0, st, g, strips);
         CIC_LAUNCH_CHECK();
         return 0;
     }
-    if (g.b_kc) hipLaunchKernelGGL((gemm_rega_kernel<16, true>), dim3(grid), dim3(1024), 0, st, g, gps);
-    else hipLaunchKernelGGL((gemm_rega_kernel<16, false>), dim3(grid), dim3(1024), 0, st, g, gps);
+    // Few output tiles and a long K (dX = dY W of the BPTT loops: 64..128 tiles, K = 1024..3072): split K over
+    // `ky` workgroups per tile so that the launch covers the chip; the partial tiles are summed with float atomics,
+    // which the caller allows for gradient products (sum_order_free) whose C accumulates or is already zero
+    // (c_is_zero: the caller or the producing kernel cleared it).
+    int ky = 1, gps_y = gps;
+    if (g_tail_split && g.sum_order_free && !g.relu && (g.accumulate || g.c_is_zero) && grid <= 128 && groups >= 128) {
+        ky = 256 / grid;
+        if (ky > groups / 64) ky = groups / 64;        // at least 4 groups (32 k) per wave
+        if (ky > 8) ky = 8;
+        if (ky >= 2) gps_y = cic_cdiv(cic_cdiv(groups, 16 * ky), 4) * 4; else ky = 1;
+    }
+    if (g.b_kc) hipLaunchKernelGGL((gemm_rega_kernel<16, true>), dim3(grid, ky), dim3(1024), 0, st, g, gps_y);
+    else hipLaunchKernelGGL((gemm_rega_kernel<16, false>), dim3(grid, ky), dim3(1024), 0, st, g, gps_y);
     CIC_LAUNCH_CHECK();
     return 0;
 }
 
-int g_tail_split = 1;   // cic_debug_gemm_tail_split: 0 disables the K-sliced tail (A/B measurements, determinism)
-int g_force_tile = 0;   // cic_debug_gemm_tail_split bits 8..: 1 = 128x128, 2 = 64x64 (A/B measurements)
 
 template <int BM, int BN, int WM, int WN>
 int launch_shape(const cic_gemm_args& g, bool vec, bool want_tail, hipStream_t st) {
@@ -680,6 +845,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
 extern "C" int cic_debug_gemm_tail_split(int on) {
     g_tail_split = on & 0xff;
     g_force_tile = (on >> 8) & 0xff;
+    g_walk = ((on >> 16) & 1) ? 0 : 1;
     return 0;
 }
 
@@ -724,6 +890,26 @@ extern "C" int cic_gemm_f32(const cic_gemm_args* a, cic_stream_t s) {
     if (free_sum && big_tiles >= 48 && big_tiles <= 192 && g.K >= 1024 && (small_tiles % 256) != 0)
         return launch_shape<128, 128, 2, 2>(g, vec, true, cic_s(s));
     return launch_shape<64, 64, 2, 2>(g, vec, small_tiles < 256, cic_s(s));
+}
+
+// Average duration of one cic_gemm_f32 launch: `iters` back-to-back launches between two HIP events on `s`.
+extern "C" int cic_gemm_f32_timed(const cic_gemm_args* a, int iters, double* avg_us, cic_stream_t s) {
+    CIC_REQUIRE(a && iters > 0 && avg_us);
+    hipEvent_t e0, e1;
+    CIC_HIP(hipEventCreate(&e0));
+    CIC_HIP(hipEventCreate(&e1));
+    int rc = 0;
+    for (int i = 0; i < 3 && !rc; ++i) rc = cic_gemm_f32(a, s);
+    CIC_HIP(hipEventRecord(e0, cic_s(s)));
+    for (int i = 0; i < iters && !rc; ++i) rc = cic_gemm_f32(a, s);
+    CIC_HIP(hipEventRecord(e1, cic_s(s)));
+    CIC_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CIC_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_us = (double)ms * 1e3 / iters;
+    return rc;
 }
 
 extern "C" int cic_colsum_f32(const float* X, int M, int N, int ldx, float* out, int accumulate,

@@ -230,8 +230,11 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ c_new, const float* __restrict__ d_out,
                                                        const float* __restrict__ dh_carry, float* __restrict__ dc_carry,
                                                        const uint8_t* __restrict__ keep, float scale,
-                                                       float* __restrict__ dpre, int B, int H, int first) {
+                                                       float* __restrict__ dpre, int B, int H, int first,
+                                                       float* __restrict__ zero_a, float* __restrict__ zero_b) {
     // first != 0: dh_carry / dc_carry hold nothing yet (last time step)
+    // zero_a / zero_b: [B,H] buffers cleared here for the K-split products that follow in this time step (their
+    // partial tiles are added into them), or null
     const int H4 = H >> 2;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * H4) return;
@@ -267,6 +270,8 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(const float* __restrict__
     f32x4* o = reinterpret_cast<f32x4*>(dpre + (size_t)b * 5 * H);
     o[j] = gi; o[H4 + j] = gf; o[2 * H4 + j] = go; o[3 * H4 + j] = ga; o[4 * H4 + j] = gb;
     reinterpret_cast<f32x4*>(dc_carry)[idx] = dcp;
+    if (zero_a) reinterpret_cast<f32x4*>(zero_a)[idx] = zero;
+    if (zero_b) reinterpret_cast<f32x4*>(zero_b)[idx] = zero;
 }
 
 // ---- per-step attention backward ---------------------------------------------------------
@@ -679,11 +684,11 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         hipLaunchKernelGGL(cell_bwd_kernel, dim3(cic_cdiv(B * (H / 4), 256)), dim3(256), 0, st,
                            w.pre_all + (size_t)t * B * 5 * H, w.c_all + (size_t)t * B * H,
                            w.c_all + (size_t)(t + 1) * B * H, g.d_out_all + (size_t)t * B * H, dh_in, g.dc, ok, scale,
-                           dpre, B, H, t == T - 1 ? 1 : 0);
+                           dpre, B, H, t == T - 1 ? 1 : 0, g.d_att_res_all + (size_t)t * B * H, t > 0 ? dh_out : nullptr);
         CIC_LAUNCH_CHECK();
-        // d att_res = d in_transform a2c.W            [B,2H] x [2H,H]
+        // d att_res = d in_transform a2c.W            [B,2H] x [2H,H]   (into the slab the cell kernel cleared)
         float* dres = g.d_att_res_all + (size_t)t * B * H;
-        RUN(gemm_nn(dpre + 3 * H, 5 * H, p->a2c_w, H, dres, H, B, H, 2 * H, false, st));
+        RUN(gemm_nn(dpre + 3 * H, 5 * H, p->a2c_w, H, dres, H, B, H, 2 * H, false, st, true, true));
         {
             dim3 grid(B), blk(1024);
             const int mx = A > H ? A : H;
@@ -718,7 +723,7 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         if (t > 0) {
             // dh_t = dpre h2h.W + d_att_h h2att.W       [B,5H]x[5H,H] + [B,A]x[A,H]
             RUN(gemm_nn2(dpre, 5 * H, p->h2h_w, H, 5 * H, g.d_att_h_all + (size_t)t * B * A, A, p->h2att_w, H, A,
-                         dh_out, H, B, H, false, st));
+                         dh_out, H, B, H, false, st, true));
             float* tmp = dh_in; dh_in = dh_out; dh_out = tmp;
         }
         if (ps) {

@@ -96,12 +96,16 @@ typedef struct {
     int sum_order_free;           /* != 0: the caller accepts a summation order that varies run to run (partial tiles
                                      combined with float atomics).  The engines set it for gradient products only;
                                      forward activations keep a fixed order. */
+    int c_is_zero;                /* != 0 (with sum_order_free, accumulate == 0): C already holds zeros, so partial products may
+                                     be added into it */
     int rows_blk;
     const float* A_b;
     const float* A2_b;
     float* C_b;
 } cic_gemm_args;
 int cic_gemm_f32(const cic_gemm_args* a, cic_stream_t s);
+/* measurement helper: average duration (us) of `iters` back-to-back launches of the product, HIP events on s */
+int cic_gemm_f32_timed(const cic_gemm_args* a, int iters, double* avg_us, cic_stream_t s);
 /* out[n] (+)= sum_m X[m*ldx + n]   — bias gradients. */
 int cic_colsum_f32(const float* X, int M, int N, int ldx, float* out, int accumulate,
                    cic_stream_t s);

@@ -7,12 +7,12 @@ from cooperativeimagecaptioning_amd import ops, _lib
 lib = _lib.lib
 lib.cic_debug_set_stamps.argtypes = [C.c_void_p]
 dev = 'cuda'
-for (M, N, K, K2, bkc) in [(128, 2560, 512, 512, 1), (128, 1024, 512, 0, 1), (128, 512, 2560, 512, 0)]:
+for (M, N, K, K2, bkc) in [(128, 512, 512, 0, 1), (256, 512, 512, 0, 1), (256, 1024, 512, 0, 1), (128, 2560, 512, 512, 1), (128, 512, 2560, 512, 0)]:
     A = torch.randn(M, K, device=dev); B = torch.randn((N, K) if bkc else (K, N), device=dev)
     A2 = torch.randn(M, K2, device=dev) if K2 else None
     B2 = torch.randn((N, K2) if bkc else (K2, N), device=dev) if K2 else None
     Cc = torch.empty(M, N, device=dev)
-    nblk = 4 * ((N + 31) // 32)
+    nblk = (M // 32) * ((N + 31) // 32)
     buf = torch.zeros(nblk * 16 * 6, dtype=torch.int64, device=dev)
     for _ in range(5):
         ops.gemm(A, B, Cc, True, bool(bkc), A2=A2, B2=B2)
@@ -32,5 +32,10 @@ for (M, N, K, K2, bkc) in [(128, 2560, 512, 512, 1), (128, 1024, 512, 0, 1), (12
         print('  %-32s median %.2f us  p90 %.2f  max %.2f' % (nm, np.median(d[:, :, i]) / 1e3, np.percentile(d[:, :, i], 90) / 1e3, d[:, :, i].max() / 1e3))
     life = rel[:, :, 4].max(1) - rel[:, :, 0].min(1)
     print('  block lifetime us: median %.2f max %.2f' % (np.median(life) / 1e3, life.max() / 1e3))
+    tn = (N + 31) // 32
+    st = rel[:, 0, 0].reshape(M // 32, tn)
+    print('  start time by strip (median over column tiles) us:', np.round(np.median(st, 1) / 1e3, 2).tolist())
+    en = rel[:, :, 4].max(1).reshape(M // 32, tn)
+    print('  end   time by strip (median over column tiles) us:', np.round(np.median(en, 1) / 1e3, 2).tolist())
     xcc = s[:, 0, 5].astype(int)
     print('  blocks per XCC:', np.bincount(xcc, minlength=8).tolist())
