@@ -5,6 +5,11 @@ inputs, outputs and noise at stable addresses: a batch is copied into a staging 
 written into the same tensors every step."""
 import torch
 
+# Set by engine.graph_enable(): HIP-graph replay needs every pointer at a stable address, so inputs are copied into
+# persistent staging buffers.  With direct launches (the default) an input that is already a contiguous device tensor
+# of the right dtype is used in place: no copy, no extra launch.
+STABLE_ADDRESSES = False
+
 
 class BufCache:
     def __init__(self):
@@ -23,6 +28,8 @@ class BufCache:
     def stage(self, key, src, dtype=None):
         """Copy `src` into the persistent buffer of its role (same shape) and return that buffer."""
         dtype = dtype or src.dtype
+        if not STABLE_ADDRESSES and src.dtype == dtype and src.is_contiguous():
+            return src
         t = self.get(key, src.shape, dtype, src.device)
         t.copy_(src)
         return t

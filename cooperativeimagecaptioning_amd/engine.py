@@ -299,6 +299,8 @@ lib.cic_graph_stats.argtypes = [C.POINTER(C.c_int64)]
 
 def graph_enable(on):
     """Capture/replay the sequence engines as HIP graphs (needs a non-default stream and stable buffers)."""
+    from . import bufcache
+    bufcache.STABLE_ADDRESSES = bool(on)
     check(lib.cic_graph_enable(int(bool(on))), 'cic_graph_enable')
 
 

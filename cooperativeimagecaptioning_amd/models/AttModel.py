@@ -123,7 +123,7 @@ class AttModel(nn.Module):
         dims = self._dims(B, K, self.seq_length)
         params = engine.speaker_params(fl.tensors())
         att_raw = self._buf.stage('att_raw', att_feats, torch.float32)
-        self._staged_att = att_feats          # the decodes of this step reuse the staged copy
+        self._staged_att, self._staged_raw = att_feats, att_raw     # the decodes of this step reuse the staged tensor
         att_pre = self._buf.get('att_pre', (B, K, self.rnn_size), torch.float32, att_raw.device)
         return engine.speaker_att_embed_fwd(dims, params, att_raw, att_pre)
 
@@ -154,7 +154,7 @@ class AttModel(nn.Module):
         dims = self._dims(B, K, T)
         params = engine.speaker_params(fl.tensors())
         if att_pre is not None and getattr(self, '_staged_att', None) is att_feats:
-            att_raw = self._buf.get('att_raw', att_feats.shape, torch.float32, att_feats.device)   # staged by att_embed_pre
+            att_raw = self._staged_raw                                   # staged by att_embed_pre
         else:
             att_raw = self._buf.stage('att_raw', att_feats, torch.float32)
             self._staged_att = None
