@@ -10,8 +10,9 @@ decode, CIDEr-D reward, loss) -> backward -> [RCCL all-reduce of the two flat gr
   python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
 
 Prints ONE JSON line (rank 0).  `roofline` is the per-timestep attention kernel (HBM-bound):
-algorithmic bytes per launch / average in-situ launch duration (HIP events recorded by the
-engine around every attention launch of the timed steps) / 8 TB/s.  `cpu_baseline` is the CPU
+algorithmic bytes per launch (151,696 B x the 2B images one launch of the paired decodes covers) /
+average launch duration (HIP events on the step's stream, launches interleaved with a kernel that
+reproduces the cache pollution of the step) / 8 TB/s.  `cpu_baseline` is the CPU
 oracle (oracle/, a restatement of the reference pinned by golden vectors) timed on this host
 for a bounded number of steps of the same workload.
 """
@@ -96,31 +97,47 @@ def cpu_baseline(opt, steps_budget_s=20.0):
 
 
 def attention_launch_time(model, batch, stream, iters=200):
-    """Average duration of one attention launch (cic_attn_fwd) on the tensors the step just used
-    (att / p_att of the sampled decode's workspace geometry), HIP events on the step's stream."""
-    from cooperativeimagecaptioning_amd import ops
+    """Average duration of one attention launch of the step, HIP events on the step's stream (cic_attn_fwd_timed).
+    In the step the sampled and the greedy decode advance together, so ONE launch covers 2B images (B workgroups
+    per decode): the timed launches have that geometry, on `att` tensors of the step's size, interleaved with a
+    kernel that streams the ~70 MB the other kernels of a paired decode step move between two attention launches
+    (weights, logits, noise), so that att / p_att are in the cache state they have inside the step."""
+    import ctypes as C
+    from cooperativeimagecaptioning_amd import _lib
     cg = model.caption_generator
-    B, K, H = batch['att_feats'].shape[0], batch['att_feats'].shape[1], cg.rnn_size
+    B, K, H = 2 * batch['att_feats'].shape[0], batch['att_feats'].shape[1], cg.rnn_size
     dev = batch['att_feats'].device
-    att = cg._buf.get('att_pre', (B, K, H), torch.float32, dev)
+    att = torch.randn(B, K, H, device=dev).abs_()
     p_att = torch.randn(B, K, H, device=dev)
     att_h = torch.randn(B, H, device=dev)
     w = cg.core.attention.alpha_net.weight.data.view(-1)
     ba = cg.core.attention.alpha_net.bias.data
-    res, al, dot = torch.empty(B, H, device=dev), torch.empty(B, K, device=dev), torch.empty(B, K, device=dev)
-    import ctypes as C
-    from cooperativeimagecaptioning_amd import _lib
+    res, al = torch.empty(B, H, device=dev), torch.empty(B, K, device=dev)
     fn = _lib.lib.cic_attn_fwd_timed
     fn.argtypes = [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.c_void_p]
-    # between two attention launches a decode step streams ~45 MB (logit / i2h / h2h / a2c weights, logits, noise)
-    pollute = torch.randn(45 * (1 << 20) // 4, device=dev)
+    pollute = torch.randn(70 * (1 << 20) // 4, device=dev)
     us, us_warm = C.c_double(0.0), C.c_double(0.0)
     _lib.check(fn(att_h.data_ptr(), p_att.data_ptr(), att.data_ptr(), w.data_ptr(), ba.data_ptr(), res.data_ptr(),
                   al.data_ptr(), B, K, H, H, iters, pollute.data_ptr(), pollute.numel(), C.byref(us),
                   stream.cuda_stream), 'cic_attn_fwd_timed')
     _lib.check(fn(att_h.data_ptr(), p_att.data_ptr(), att.data_ptr(), w.data_ptr(), ba.data_ptr(), res.data_ptr(),
                   al.data_ptr(), B, K, H, H, iters, None, 0, C.byref(us_warm), stream.cuda_stream), 'cic_attn_fwd_timed')
-    return {'attn_fwd': dict(ms=us.value * iters / 1e3, n=iters, warm_us=us_warm.value)}
+    return {'attn_fwd': dict(ms=us.value * iters / 1e3, n=iters, warm_us=us_warm.value, images=B)}
+
+
+def pmc_traffic(images):
+    """HBM-side bytes per attention launch from the committed PMC summary (profiles/, separate FETCH_SIZE and
+    WRITE_SIZE passes of this same command, tools/pmc_summary.py), for the launch geometry of the step."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    try:
+        with open(path) as f:
+            doc = json.load(f)
+    except OSError:
+        return None
+    for k in doc.get('kernels', []):
+        if k['kernel'].startswith('attn_fwd_cols_kernel') and k['grid_threads'] == images * 1024:
+            return k['total_bytes']
+    return None
 
 
 def main():
@@ -203,7 +220,8 @@ def main():
         B = args.batch
         attn = prof.get('attn_fwd', dict(ms=0.0, n=0))
         attn_us = attn['ms'] * 1e3 / max(attn['n'], 1)
-        achieved = (ATTN_BYTES_PER_IMAGE * B) / (attn_us * 1e-6) / 1e9 if attn_us > 0 else 0.0
+        n_img = attn.get('images', B)                      # images per attention launch (2B: paired decodes)
+        achieved = (ATTN_BYTES_PER_IMAGE * n_img) / (attn_us * 1e-6) / 1e9 if attn_us > 0 else 0.0
         out = {
             'metric': 'joint-step images/sec (B=128, seq16)', 'value': B * world * args.steps / dt, 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
@@ -215,9 +233,10 @@ def main():
                        'final_loss': final_loss, 'hip_graphs': gstats},
             'roofline': {'bound': 'hbm', 'kernel': 'attn_fwd_kernel (per-timestep top-down attention)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None, 'avg_launch_us': attn_us, 'launches_timed': attn['n'],
-                         'avg_launch_us_l2_warm': attn.get('warm_us'),
-                         'algorithmic_bytes_per_launch': ATTN_BYTES_PER_IMAGE * B},
+                         'traffic': pmc_traffic(n_img), 'avg_launch_us': attn_us, 'launches_timed': attn['n'],
+                         'avg_launch_us_l2_warm': attn.get('warm_us'), 'images_per_launch': n_img,
+                         'algorithmic_bytes_per_launch': ATTN_BYTES_PER_IMAGE * n_img,
+                         'traffic_source': 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)'},
         }
         for k, v in prof.items():
             if k != 'attn_fwd' and v['n']:
