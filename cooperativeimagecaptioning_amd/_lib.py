@@ -83,12 +83,13 @@ class DecodeIO(C.Structure):
                 ('out_keep', c_ptr), ('U', c_ptr), ('pick', c_ptr),
                 ('ps_u', c_ptr), ('ps_prob', C.c_float), ('soft_raw', c_ptr), ('xpre', c_ptr), ('soft_out', c_ptr),
                 ('ss_u', c_ptr), ('ss_prob', C.c_float),
-                ('ss_pick', c_ptr), ('first_token', c_ptr),
+                ('ss_pick', c_ptr), ('fc_mode', C.c_int), ('x0', c_ptr), ('first_token', c_ptr),
                 ('seq', c_ptr), ('slp', c_ptr), ('stv', c_ptr), ('L', c_ptr)]
 
 
 class DecodeBwdIO(C.Structure):
-    _fields_ = [('d_onehot', c_ptr), ('dslp', c_ptr), ('grads', C.POINTER(SpeakerParams)), ('att_raw', c_ptr)]
+    _fields_ = [('d_onehot', c_ptr), ('dslp', c_ptr), ('grads', C.POINTER(SpeakerParams)), ('att_raw', c_ptr),
+                ('d_x0', c_ptr)]
 
 
 class CiderdArgs(C.Structure):
@@ -100,7 +101,8 @@ class CiderdArgs(C.Structure):
 
 class ListenerDims(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('B', 'F', 'E', 'J', 'V', 'T', 'Lp')] + [
-        ('margin', C.c_float), ('max_violation', C.c_int), ('no_imgnorm', C.c_int), ('use_abs', C.c_int)]
+        ('margin', C.c_float), ('max_violation', C.c_int), ('no_imgnorm', C.c_int), ('use_abs', C.c_int),
+        ('pool', C.c_int)]
 
 
 LISTENER_PARAM_FIELDS = [

@@ -27,6 +27,7 @@ struct SpkWs {
     float *alpha_all, *dot_all;               // [T,B,K]
     float *pre_all, *out_all, *logp_all;      // [T,B,5H], [T,B,H], [T,B,V+1]
     float* bias_ih;                           // [5H] = i2h.bias + h2h.bias
+    float *pre_img, *zeros;                   // [B,5H], [B,H]: the image step of an FCModel decode; a zero state
     int32_t *it_all, *unfinished, *any_unf;   // [T+1,B], [B], [T+1]
     size_t bytes;
 };
@@ -40,9 +41,9 @@ int cic_attn_fwd2(Dual<const float> att_h, Dual<const float> p_att, Dual<const f
                   const float* b_alpha, const float* masks, Dual<float> att_res, Dual<float> alpha, Dual<float> dot, int B,
                   int nb, int K, int A, int H, hipStream_t st);
 int cic_cell_fwd2(Dual<const float> pre, Dual<const float> c_prev, Dual<const uint8_t> keep, float p_drop, Dual<float> h_new,
-                  Dual<float> c_new, Dual<float> out, int B, int nb, int H, hipStream_t st);
+                  Dual<float> c_new, Dual<float> out, int B, int nb, int H, hipStream_t st, int state_dropped = 0);
 int cic_embed_fwd2(const float* E, Dual<const int32_t> it, Dual<const uint8_t> keep, float p_drop, Dual<float> x, int B,
-                   int nb, int Ed, hipStream_t st);
+                   int nb, int Ed, hipStream_t st, int plain = 0);
 int cic_logsoftmax_sample2(const cic_sampler_args* a, const cic_sampler_args* b, hipStream_t st);
 int cic_relu_keep_fwd(const float* xpre, const uint8_t* keep, float p_drop, float* x, int64_t n, hipStream_t st);
 int cic_soft_mask(const float* soft_raw, const int32_t* seq, const int32_t* L, float* soft_out, int T, int B, int V1,

@@ -110,12 +110,26 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_kernel(const float* __restri
                                                            const float* __restrict__ h, const int32_t* __restrict__ len,
                                                            int t, const float* __restrict__ dh_in,
                                                            float* __restrict__ dh_out, float* __restrict__ dgi,
-                                                           float* __restrict__ dgh, int B, int J) {
+                                                           float* __restrict__ dgh, int B, int J, int pool,
+                                                           const float* __restrict__ d_pool,
+                                                           const int32_t* __restrict__ pool_arg) {
+    // pool != 0: the caption embedding pools the per-step outputs, so step t < len receives d_pool / len (mean)
+    // or d_pool where it was the maximum (max) on top of the carried gradient
     const int J4 = J >> 2;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * J4) return;
     const int b = idx / J4, j = idx % J4;
-    const f32x4 d = reinterpret_cast<const f32x4*>(dh_in)[idx];
+    f32x4 d = reinterpret_cast<const f32x4*>(dh_in)[idx];
+    if (pool && t < len[b]) {
+        const f32x4 dp = reinterpret_cast<const f32x4*>(d_pool)[idx];
+        if (pool == 1) {
+            d += dp * (1.0f / (float)len[b]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (pool_arg[(size_t)idx * 4 + e] == t) d[e] += dp[e];
+        }
+    }
     f32x4* oi = reinterpret_cast<f32x4*>(dgi + (size_t)b * 3 * J);
     f32x4* oh = reinterpret_cast<f32x4*>(dgh + (size_t)b * 3 * J);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -149,6 +163,33 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_kernel(const float* __restri
     oi[j] = gir; oi[J4 + j] = giz; oi[2 * J4 + j] = gin;
     oh[j] = gir; oh[J4 + j] = giz; oh[2 * J4 + j] = ghn;
     reinterpret_cast<f32x4*>(dh_out)[idx] = dprev;
+}
+
+// ---- pooling over the valid GRU outputs (vse_pool_type 'mean' / 'max', VSEFCModel.py:118-127) ----------------
+// h_all: [Lp+1,B,J], slab t+1 = output of step t; pad_packed_sequence leaves zeros past a caption's length, which
+// the masks exclude (mean: sum_{t<len} h_t / len;  max: the masked maximum, ties -> lowest t).  Masks are the 0/1
+// prefix masks the reference builds (len = their sum).
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ h_all, const int32_t* __restrict__ len,
+                                                       int mode, float* __restrict__ pooled, int32_t* __restrict__ arg,
+                                                       int B, int J, int Lp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * J) return;
+    const int b = i / J;
+    const int n = len[b];
+    if (mode == 1) {
+        float s = 0.f;
+        for (int t = 0; t < n; ++t) s += h_all[(size_t)(t + 1) * B * J + i];
+        pooled[i] = s / (float)n;
+    } else {
+        float m = -1e10f;                       // an all-masked row pools to the reference's fill value
+        int a = -1;
+        for (int t = 0; t < n; ++t) {
+            const float v = h_all[(size_t)(t + 1) * B * J + i];
+            if (v > m) { m = v; a = t; }
+        }
+        pooled[i] = m;
+        arg[i] = a;
+    }
 }
 
 // ---- l2norm (VSEFCModel.py:12-17): y = x / (||x|| + 1e-7) ---------------------------------
@@ -289,6 +330,8 @@ struct LstWs {
     float *val, *x_emb, *gi_all, *gh_all, *h_all, *img_lin, *img_emb, *cap_emb, *nrm_img, *nrm_cap, *S;
     // backward scratch
     float *dS, *d_img, *d_cap, *d_lin, *dh, *dh2, *dgi_all, *dgh_all, *dx_emb;
+    float *pooled, *d_pool;   // [B,J] vse_pool_type mean / max
+    int32_t* pool_arg;        // [B,J] time step of the maximum
     size_t bytes;
 };
 LstWs lst_carve(const cic_listener_dims& d, void* base) {
@@ -319,6 +362,9 @@ LstWs lst_carve(const cic_listener_dims& d, void* base) {
     w.dgi_all = c.f32(Lp * B * 3 * J);
     w.dgh_all = c.f32(Lp * B * 3 * J);
     w.dx_emb = c.f32(Lp * B * E);
+    w.pooled = c.f32(B * J);
+    w.d_pool = c.f32(B * J);
+    w.pool_arg = c.i32(B * J);
     w.bytes = c.used();
     return w;
 }
@@ -326,6 +372,7 @@ LstWs lst_carve(const cic_listener_dims& d, void* base) {
 int check_ldims(const cic_listener_dims& d) {
     CIC_REQUIRE(d.B > 0 && d.B <= 1024 && d.Lp > 0 && d.Lp <= 128);
     CIC_REQUIRE((d.J & 3) == 0 && (d.E & 3) == 0 && d.F > 0 && d.V > 0);
+    CIC_REQUIRE(d.pool >= 0 && d.pool <= 2);
     return 0;
 }
 
@@ -420,8 +467,14 @@ static int listener_fwd_impl(const cic_listener_dims* dp, const cic_listener_par
                            w.gi_all + (size_t)t * B * 3 * J, gh, h, w.len, t, h + (size_t)B * J, B, J);
         CIC_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(B), dim3(256), 0, st, w.h_all + (size_t)Lp * B * J, w.cap_emb, w.nrm_cap,
-                       J, d.use_abs, 1);
+    const float* cap_raw = w.h_all + (size_t)Lp * B * J;      // 'last': the state after the last valid step (:128-129)
+    if (d.pool) {
+        hipLaunchKernelGGL(pool_fwd_kernel, dim3(cic_cdiv(B * J, 256)), dim3(256), 0, st, w.h_all, w.len, d.pool, w.pooled,
+                           w.pool_arg, B, J, Lp);
+        CIC_LAUNCH_CHECK();
+        cap_raw = w.pooled;
+    }
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(B), dim3(256), 0, st, cap_raw, w.cap_emb, w.nrm_cap, J, d.use_abs, 1);
     CIC_LAUNCH_CHECK();
     // contrastive loss                                                   (VSEFCModel.py:167-207)
     RUN(gemm_nt(w.img_emb, J, w.cap_emb, J, w.S, B, B, B, J, nullptr, false, false, st));
@@ -465,9 +518,10 @@ static int listener_bwd_impl(const cic_listener_dims* dp, const cic_listener_par
         RUN(cic_colsum_f32(w.d_lin, B, J, J, g->img_fc_b, 1, s));
     }
     // text branch: l2norm then GRU BPTT
-    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(B), dim3(256), 0, st, w.h_all + (size_t)Lp * B * J, w.nrm_cap, w.d_cap,
-                       w.dh, J, d.use_abs, 1);
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(B), dim3(256), 0, st, d.pool ? w.pooled : w.h_all + (size_t)Lp * B * J,
+                       w.nrm_cap, w.d_cap, d.pool ? w.d_pool : w.dh, J, d.use_abs, 1);
     CIC_LAUNCH_CHECK();
+    if (d.pool) CIC_HIP(hipMemsetAsync(w.dh, 0, sizeof(float) * B * J, st));   // nothing reaches the final state directly
     float* dh = w.dh;
     float* dh2 = w.dh2;
     for (int t = Lp - 1; t >= 0; --t) {
@@ -475,7 +529,7 @@ static int listener_bwd_impl(const cic_listener_dims* dp, const cic_listener_par
         float* dgh = w.dgh_all + (size_t)t * B * 3 * J;
         hipLaunchKernelGGL(gru_cell_bwd_kernel, dim3(cic_cdiv(B * (J / 4), 256)), dim3(256), 0, st,
                            w.gi_all + (size_t)t * B * 3 * J, w.gh_all + (size_t)t * B * 3 * J,
-                           w.h_all + (size_t)t * B * J, w.len, t, dh, dh2, dgi, dgh, B, J);
+                           w.h_all + (size_t)t * B * J, w.len, t, dh, dh2, dgi, dgh, B, J, d.pool, w.d_pool, w.pool_arg);
         CIC_LAUNCH_CHECK();
         if (t > 0) RUN(gemm_nn(dgh, 3 * J, p->w_hh, J, dh2, J, B, J, 3 * J, true, st));   // += dgh W_hh
         float* tmp = dh; dh = dh2; dh2 = tmp;

@@ -231,7 +231,10 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ dh_carry, float* __restrict__ dc_carry,
                                                        const uint8_t* __restrict__ keep, float scale,
                                                        float* __restrict__ dpre, int B, int H, int first,
-                                                       float* __restrict__ zero_a, float* __restrict__ zero_b) {
+                                                       float* __restrict__ zero_a, float* __restrict__ zero_b,
+                                                       int state_dropped) {
+    // state_dropped: the recurrent state is the dropped-out h (LSTMCore, models/FCModel.py:38-42), so the carried
+    // dh passes through the dropout mask as well
     // first != 0: dh_carry / dc_carry hold nothing yet (last time step)
     // zero_a / zero_b: [B,H] buffers cleared here for the K-split products that follow in this time step (their
     // partial tiles are added into them), or null
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(const float* __restrict__
         const float g = fmaxf(pa[e], pb[e]);
         const float tc = fast_tanh(cn[e]);
         const float kf = keep ? (float)((kp >> (8 * e)) & 0xffu) * scale : 1.0f;
-        const float dh = dout[e] * kf + dhc[e];
+        const float dh = state_dropped ? (dout[e] + dhc[e]) * kf : dout[e] * kf + dhc[e];
         const float dc = dcc[e] + dh * og * (1.0f - tc * tc);
         gi[e] = dc * g * ig * (1.0f - ig);
         gf[e] = dc * cp[e] * fg * (1.0f - fg);
@@ -539,12 +542,13 @@ __global__ __launch_bounds__(256) void attn_bwd_feats_kernel(const float* __rest
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ E, const int32_t* __restrict__ it_all,
                                                         const uint8_t* __restrict__ keep, float scale,
                                                         const float* __restrict__ dx, float* __restrict__ dE, int TB,
-                                                        int Ed) {
+                                                        int Ed, int plain) {
+    // plain: bare embedding rows (FCModel): no ReLU gate
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)TB * Ed) return;
     const int r = (int)(i / Ed), j = (int)(i % Ed);
     const int tok = it_all[r];
-    if (E[(size_t)tok * Ed + j] <= 0.f) return;
+    if (!plain && E[(size_t)tok * Ed + j] <= 0.f) return;
     float g = dx[i];
     if (keep) g *= (float)keep[i] * scale;
     if (g != 0.f) atomicAdd(dE + (size_t)tok * Ed + j, g);
@@ -571,6 +575,7 @@ __global__ __launch_bounds__(256) void relu_keep_bwd_kernel(const float* __restr
 struct SpkBws {
     float *dlogits, *d_out_all, *dpre_all, *d_att_h_all, *d_att_res_all, *ddot_all, *dh_a, *dh_b, *dc, *dx_all;
     float *d_att, *d_p_att, *d_attpre;
+    float* dpre_img;   // [B,5H] image step of an FCModel decode
     size_t bytes;
 };
 SpkBws spk_bcarve(const cic_speaker_dims& d, void* base, bool own_dlogits) {
@@ -590,6 +595,7 @@ SpkBws spk_bcarve(const cic_speaker_dims& d, void* base, bool own_dlogits) {
     w.d_att = c.f32(B * K * H);
     w.d_p_att = c.f32(B * K * A);
     w.d_attpre = c.f32(B * K * H);
+    w.dpre_img = c.f32(B * 5 * H);
     w.bytes = c.used();
     return w;
 }
@@ -608,7 +614,7 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
 extern "C" int cic_speaker_decode_bwd(const cic_speaker_dims* dp, const cic_speaker_params* p, const cic_decode_io* io,
                                       const cic_decode_bwd_io* bio, void* ws_fwd, size_t ws_fwd_bytes, void* ws_bwd,
                                       size_t ws_bwd_bytes, cic_stream_t s) {
-    CIC_REQUIRE(dp && p && io && bio && ws_fwd && ws_bwd && bio->grads && bio->att_raw);
+    CIC_REQUIRE(dp && p && io && bio && ws_fwd && ws_bwd && bio->grads && (bio->att_raw || io->fc_mode));
     uint64_t key = cic_hash_bytes("decode_bwd", 10, 1469598103934665603ull);
     key = cic_hash_bytes(dp, sizeof(*dp), key);
     key = cic_hash_bytes(p, sizeof(*p), key);
@@ -627,8 +633,10 @@ extern "C" int cic_speaker_decode_bwd(const cic_speaker_dims* dp, const cic_spea
 static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params* p, const cic_decode_io* io,
                            const cic_decode_bwd_io* bio, void* ws_fwd, size_t ws_fwd_bytes, void* ws_bwd,
                            size_t ws_bwd_bytes, cic_stream_t s) {
-    CIC_REQUIRE(dp && p && io && bio && ws_fwd && ws_bwd && bio->grads && bio->att_raw);
+    CIC_REQUIRE(dp && p && io && bio && ws_fwd && ws_bwd && bio->grads && (bio->att_raw || io->fc_mode));
     const cic_speaker_dims& d = *dp;
+    const bool fc = io->fc_mode != 0;
+    CIC_REQUIRE(!fc || (d.K == 0 && io->x0 && bio->d_x0));
     SpkWs w = spk_carve(d, ws_fwd);
     CIC_REQUIRE(ws_fwd_bytes >= w.bytes);
     SpkBws g = spk_bcarve(d, ws_bwd, true);
@@ -663,7 +671,7 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     float* dh_in = g.dh_a;
     float* dh_out = g.dh_b;
     for (int t = T - 1; t >= 0; --t) {
-        const uint8_t* ok = io->out_keep ? io->out_keep + (size_t)t * B * H : nullptr;
+        const uint8_t* ok = io->out_keep ? io->out_keep + (size_t)(t + (fc ? 1 : 0)) * B * H : nullptr;
         float* dpre = g.dpre_all + (size_t)t * B * 5 * H;
         if (ps) {
             float* dl = g.dlogits + (size_t)t * B * V1;
@@ -684,12 +692,13 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         hipLaunchKernelGGL(cell_bwd_kernel, dim3(cic_cdiv(B * (H / 4), 256)), dim3(256), 0, st,
                            w.pre_all + (size_t)t * B * 5 * H, w.c_all + (size_t)t * B * H,
                            w.c_all + (size_t)(t + 1) * B * H, g.d_out_all + (size_t)t * B * H, dh_in, g.dc, ok, scale,
-                           dpre, B, H, t == T - 1 ? 1 : 0, g.d_att_res_all + (size_t)t * B * H, t > 0 ? dh_out : nullptr);
+                           dpre, B, H, t == T - 1 ? 1 : 0, fc ? nullptr : g.d_att_res_all + (size_t)t * B * H,
+                           (t > 0 || fc) ? dh_out : nullptr, fc ? 1 : 0);
         CIC_LAUNCH_CHECK();
         // d att_res = d in_transform a2c.W            [B,2H] x [2H,H]   (into the slab the cell kernel cleared)
         float* dres = g.d_att_res_all + (size_t)t * B * H;
-        RUN(gemm_nn(dpre + 3 * H, 5 * H, p->a2c_w, H, dres, H, B, H, 2 * H, false, st, true, true));
-        {
+        if (!fc) RUN(gemm_nn(dpre + 3 * H, 5 * H, p->a2c_w, H, dres, H, B, H, 2 * H, false, st, true, true));
+        if (!fc) {
             dim3 grid(B), blk(1024);
             const int mx = A > H ? A : H;
             float* dah = g.d_att_h_all + (size_t)t * B * A;
@@ -720,7 +729,11 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
             cic_prof_end(ph, st);
             CIC_LAUNCH_CHECK();
         }
-        if (t > 0) {
+        if (fc) {
+            // dh_t = dpre h2h.W  (no attention); also at t = 0: the state came from the image step
+            RUN(gemm_nn(dpre, 5 * H, p->h2h_w, H, dh_out, H, B, H, 5 * H, false, st, true, true));
+            float* tmp = dh_in; dh_in = dh_out; dh_out = tmp;
+        } else if (t > 0) {
             // dh_t = dpre h2h.W + d_att_h h2att.W       [B,5H]x[5H,H] + [B,A]x[A,H]
             RUN(gemm_nn2(dpre, 5 * H, p->h2h_w, H, 5 * H, g.d_att_h_all + (size_t)t * B * A, A, p->h2att_w, H, A,
                          dh_out, H, B, H, false, st, true));
@@ -746,22 +759,35 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     RUN(gemm_tn(g.dpre_all, 5 * H, w.h_all, H, gr->h2h_w, H, 5 * H, H, T * B, true, st));
     RUN(cic_colsum_f32(g.dpre_all, T * B, 5 * H, 5 * H, gr->i2h_b, 1, s));
     RUN(cic_colsum_f32(g.dpre_all, T * B, 5 * H, 5 * H, gr->h2h_b, 1, s));
-    RUN(gemm_tn(g.dpre_all + 3 * H, 5 * H, w.att_res_all, H, gr->a2c_w, H, 2 * H, H, T * B, true, st));
-    RUN(cic_colsum_f32(g.dpre_all + 3 * H, T * B, 2 * H, 5 * H, gr->a2c_b, 1, s));
-    RUN(gemm_tn(g.d_att_h_all, A, w.h_all, H, gr->h2att_w, H, A, H, T * B, true, st));
-    RUN(cic_colsum_f32(g.d_att_h_all, T * B, A, A, gr->h2att_b, 1, s));
+    if (!fc) {
+        RUN(gemm_tn(g.dpre_all + 3 * H, 5 * H, w.att_res_all, H, gr->a2c_w, H, 2 * H, H, T * B, true, st));
+        RUN(cic_colsum_f32(g.dpre_all + 3 * H, T * B, 2 * H, 5 * H, gr->a2c_b, 1, s));
+        RUN(gemm_tn(g.d_att_h_all, A, w.h_all, H, gr->h2att_w, H, A, H, T * B, true, st));
+        RUN(cic_colsum_f32(g.d_att_h_all, T * B, A, A, gr->h2att_b, 1, s));
+    } else {
+        // image step (FCModel.py:97-99,121): through the cell with a zero previous state, then d x0 = dpre i2h.W
+        const uint8_t* ok_img = io->out_keep;
+        hipLaunchKernelGGL(cell_bwd_kernel, dim3(cic_cdiv(B * (H / 4), 256)), dim3(256), 0, st, w.pre_img, w.zeros, w.c_all,
+                           w.zeros, dh_in, g.dc, ok_img, scale, g.dpre_img, B, H, 0, nullptr, nullptr, 1);
+        CIC_LAUNCH_CHECK();
+        RUN(gemm_nn(g.dpre_img, 5 * H, p->i2h_w, E, bio->d_x0, E, B, E, 5 * H, false, st));
+        RUN(gemm_tn(g.dpre_img, 5 * H, io->x0, E, gr->i2h_w, E, 5 * H, E, B, true, st));
+        RUN(cic_colsum_f32(g.dpre_img, B, 5 * H, 5 * H, gr->i2h_b, 1, s));
+        RUN(cic_colsum_f32(g.dpre_img, B, 5 * H, 5 * H, gr->h2h_b, 1, s));
+    }
     // token embedding: dx = dpre i2h.W, scattered into the embedding rows
     if (!ps) RUN(gemm_nn(g.dpre_all, 5 * H, p->i2h_w, E, g.dx_all, E, T * B, E, 5 * H, false, st));
     {
         // partial sampling: only step 0 reads an embedding row (<bos>); steps >= 1 used soft_raw[t-1] @ embed
         const int rows = ps ? B : T * B;
         const int64_t n = (int64_t)rows * E;
-        hipLaunchKernelGGL(embed_bwd_kernel, dim3(cic_cdiv(n, 256)), dim3(256), 0, st, p->embed_w, w.it_all, io->x_keep,
-                           scale, g.dx_all, gr->embed_w, rows, E);
+        hipLaunchKernelGGL(embed_bwd_kernel, dim3(cic_cdiv(n, 256)), dim3(256), 0, st, p->embed_w, w.it_all,
+                           fc ? nullptr : io->x_keep, scale, g.dx_all, gr->embed_w, rows, E, fc ? 1 : 0);
         CIC_LAUNCH_CHECK();
         if (ps && T > 1)
             RUN(gemm_tn(io->soft_raw, V1, g.dx_all + (size_t)B * E, E, gr->embed_w, E, V1, E, (T - 1) * B, true, st));
     }
+    if (fc) return 0;      // no region features
     // 5. attention features: d att, d p_att, d alpha_net in one pass over p_att
     {
         const int mx = A > H ? A : H;

@@ -51,6 +51,8 @@ SpkWs spk_carve(const cic_speaker_dims& d, void* base) {
     w.out_all = c.f32(T * B * H);
     w.logp_all = c.f32(T * B * V1);
     w.bias_ih = c.f32(5 * H);
+    w.pre_img = c.f32(B * 5 * H);
+    w.zeros = c.f32(B * H);
     w.it_all = c.i32((T + 1) * B);
     w.unfinished = c.i32(B);
     w.any_unf = c.i32(T + 1);
@@ -64,7 +66,7 @@ extern "C" size_t cic_speaker_decode_ws_bytes(const cic_speaker_dims* d) {
 }
 
 static int check_dims(const cic_speaker_dims& d) {
-    CIC_REQUIRE(d.B > 0 && d.K > 0 && d.K <= 64 && d.T > 0 && d.T <= 64);
+    CIC_REQUIRE(d.B > 0 && d.K >= 0 && d.K <= 64 && d.T > 0 && d.T <= 64);
     CIC_REQUIRE((d.H & 3) == 0 && (d.E & 3) == 0 && (d.A & 3) == 0 && d.D > 0 && d.V > 0);
     CIC_REQUIRE(d.p_drop >= 0.f && d.p_drop < 1.f);
     return 0;
@@ -99,6 +101,7 @@ extern "C" int cic_speaker_decode_fwd(const cic_speaker_dims* dp, const cic_spea
 static bool pair_ok(const cic_speaker_dims& d, const cic_decode_io* a, const cic_decode_io* b) {
     auto ps = [](int m) { return m == CIC_SAMPLE_GUMBEL_PS || m == CIC_SAMPLE_MULTINOMIAL_PS; };
     if (ps(a->mode) || ps(b->mode)) return false;                 // soft-input steps are not row-wise launches
+    if (a->fc_mode || b->fc_mode || d.K == 0) return false;
     if ((a->first_token != nullptr) != (b->first_token != nullptr)) return false;
     if ((d.B & 31) || 2 * d.B > 256) return false;                // row blocks of the per-step products
     if ((d.H & 7) || (d.E & 7) || (d.A & 7)) return false;        // register-streaming GEMM operands
@@ -145,6 +148,8 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
 #define RUN(x) if ((rc = (x)) != 0) return rc
     SpkWs w[2];
     const cic_decode_io* io[2] = {ios[0], nb == 2 ? ios[1] : nullptr};
+    const bool fc = ios[0]->fc_mode != 0;               // FCModel: no attention, image step first, dropped state
+    CIC_REQUIRE(fc ? (nb == 1 && d.K == 0 && ios[0]->x0 != nullptr) : d.K > 0);
     bool ps = false;
     for (int q = 0; q < nb; ++q) {
         CIC_REQUIRE(io[q] && wss[q]);
@@ -152,15 +157,25 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         const bool psq = io[q]->mode == CIC_SAMPLE_GUMBEL_PS || io[q]->mode == CIC_SAMPLE_MULTINOMIAL_PS;
         CIC_REQUIRE(!psq || (nb == 1 && io[q]->soft_raw && io[q]->xpre && io[q]->soft_out));
         ps = ps || psq;
-        CIC_REQUIRE(io[q]->att_pre && io[q]->seq && io[q]->slp && io[q]->L);
         w[q] = spk_carve(d, wss[q]);
         CIC_REQUIRE(ws_bytes[q] >= w[q].bytes);
-        // att = dropout(relu(att_embed(att_raw)));  p_att = ctx2att(att)      (AttModel.py:315,319)
-        RUN(cic_apply_keep(io[q]->att_pre, io[q]->att_keep, io[q]->att_keep ? p_drop : 0.f, w[q].att, (int64_t)B * K * H, s));
-        RUN(gemm_nt(w[q].att, H, p->ctx2att_w, H, w[q].p_att, A, B * K, A, H, p->ctx2att_b, false, false, st));
+        CIC_REQUIRE((fc || io[q]->att_pre) && io[q]->seq && io[q]->slp && io[q]->L && !(fc && psq));
         RUN(cic_add_vec(p->i2h_b, p->h2h_b, w[q].bias_ih, 5 * H, st));
-        CIC_HIP(hipMemsetAsync(w[q].h_all, 0, sizeof(float) * B * H, st));          // init_hidden (:311)
-        CIC_HIP(hipMemsetAsync(w[q].c_all, 0, sizeof(float) * B * H, st));
+        if (!fc) {
+            // att = dropout(relu(att_embed(att_raw)));  p_att = ctx2att(att)      (AttModel.py:315,319)
+            RUN(cic_apply_keep(io[q]->att_pre, io[q]->att_keep, io[q]->att_keep ? p_drop : 0.f, w[q].att, (int64_t)B * K * H, s));
+            RUN(gemm_nt(w[q].att, H, p->ctx2att_w, H, w[q].p_att, A, B * K, A, H, p->ctx2att_b, false, false, st));
+            CIC_HIP(hipMemsetAsync(w[q].h_all, 0, sizeof(float) * B * H, st));          // init_hidden (:311)
+            CIC_HIP(hipMemsetAsync(w[q].c_all, 0, sizeof(float) * B * H, st));
+        } else {
+            // image step: (h0, c0) = LSTMCore(img_embed(fc_feats), zero state)          (FCModel.py:97-99,121,274-276,315)
+            // h = 0, so h2h contributes its bias only (already in bias_ih)
+            CIC_HIP(hipMemsetAsync(w[q].zeros, 0, sizeof(float) * B * H, st));
+            RUN(gemm_nt(io[q]->x0, E, p->i2h_w, E, w[q].pre_img, 5 * H, B, 5 * H, E, w[q].bias_ih, false, false, st));
+            RUN(cic_cell_fwd2(dual1((const float*)w[q].pre_img), dual1((const float*)w[q].zeros), dual1(io[q]->out_keep),
+                              io[q]->out_keep ? p_drop : 0.f, dual1(w[q].h_all), dual1(w[q].c_all), dual1(w[q].out_all), B, 1,
+                              H, st, 1));
+        }
         CIC_HIP(hipMemsetAsync(w[q].any_unf, 0, sizeof(int32_t) * (T + 1), st));
         RUN(cic_fill_i32(w[q].unfinished, B, 1, st));
         if (io[q]->first_token) {                                                    // AttModel.forward: seq[:, 0]  (:131)
@@ -189,7 +204,9 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         const Dual<float> h_new{w[0].h_all + (size_t)(t + 1) * B * H, nb == 2 ? w[1].h_all + (size_t)(t + 1) * B * H : nullptr};
         const Dual<float> c_new{w[0].c_all + (size_t)(t + 1) * B * H, nb == 2 ? w[1].c_all + (size_t)(t + 1) * B * H : nullptr};
         const Dual<const uint8_t> xk{keep_at(io[0]->x_keep, (size_t)t * B * E), nb == 2 ? keep_at(io[1]->x_keep, (size_t)t * B * E) : nullptr};
-        const Dual<const uint8_t> ok{keep_at(io[0]->out_keep, (size_t)t * B * H), nb == 2 ? keep_at(io[1]->out_keep, (size_t)t * B * H) : nullptr};
+        // FCModel: out_keep row 0 belongs to the image step
+        const Dual<const uint8_t> ok{keep_at(io[0]->out_keep, (size_t)(t + (fc ? 1 : 0)) * B * H),
+                                     nb == 2 ? keep_at(io[1]->out_keep, (size_t)t * B * H) : nullptr};
         // dropout is on or off for the whole model (same p_drop); a decode without masks passes NULL
         CIC_REQUIRE(nb == 1 || ((io[0]->x_keep != nullptr) == (io[1]->x_keep != nullptr) &&
                                 (io[0]->out_keep != nullptr) == (io[1]->out_keep != nullptr)));
@@ -202,10 +219,11 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
             // xt = embed(it)                                               (:399)
             RUN(cic_embed_fwd2(p->embed_w,
                                Dual<const int32_t>{w[0].it_all + (size_t)t * B, nb == 2 ? w[1].it_all + (size_t)t * B : nullptr},
-                               xk, xk.a ? p_drop : 0.f, x, B, nb, E, st));
+                               fc ? Dual<const uint8_t>{nullptr, nullptr} : xk, (xk.a && !fc) ? p_drop : 0.f, x, B, nb, E, st,
+                               fc ? 1 : 0));
         }
         // attention                                                        (:465-489)
-        {
+        if (!fc) {
             cic_gemm_args g = {};
             g.M = M; g.N = A; g.K = H; g.A = h.a; g.lda = H; g.a_kc = 1; g.B = p->h2att_w; g.ldb = H; g.b_kc = 1;
             g.C = att_h.a; g.ldc = A; g.bias = p->h2att_b;
@@ -213,11 +231,13 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         }
         // att_masks are an input of the step (the same images in both decodes)
         CIC_REQUIRE(nb == 1 || io[0]->att_masks == io[1]->att_masks);
-        CIC_PROF(CIC_PROF_ATTN_FWD, st,
-                 rc = cic_attn_fwd2(Dual<const float>{att_h.a, att_h.b}, Dual<const float>{w[0].p_att, w[1].p_att},
-                                    Dual<const float>{w[0].att, w[1].att}, p->alpha_w, p->alpha_b, io[0]->att_masks, att_res,
-                                    SLAB(alpha_all, B * K), SLAB(dot_all, B * K), B, nb, K, A, H, st));
-        if (rc) return rc;
+        if (!fc) {
+            CIC_PROF(CIC_PROF_ATTN_FWD, st,
+                     rc = cic_attn_fwd2(Dual<const float>{att_h.a, att_h.b}, Dual<const float>{w[0].p_att, w[1].p_att},
+                                        Dual<const float>{w[0].att, w[1].att}, p->alpha_w, p->alpha_b, io[0]->att_masks, att_res,
+                                        SLAB(alpha_all, B * K), SLAB(dot_all, B * K), B, nb, K, A, H, st));
+            if (rc) return rc;
+        }
         // all_input_sums = i2h(xt) + h2h(h);  in_transform += a2c(att_res)   (:514,521-522)
         {
             cic_gemm_args g = {};
@@ -226,13 +246,14 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
             g.C = pre.a; g.ldc = 5 * H; g.bias = w[0].bias_ih;
             RUN(pair_gemm(g, x.b, h.b, pre.b));
         }
-        {
+        if (!fc) {
             cic_gemm_args g = {};
             g.M = M; g.N = 2 * H; g.K = H; g.A = att_res.a; g.lda = H; g.a_kc = 1; g.B = p->a2c_w; g.ldb = H; g.b_kc = 1;
             g.C = pre.a + 3 * H; g.ldc = 5 * H; g.bias = p->a2c_b; g.accumulate = 1;
             RUN(pair_gemm(g, att_res.b, nullptr, nb == 2 ? pre.b + 3 * H : nullptr));
         }
-        RUN(cic_cell_fwd2(Dual<const float>{pre.a, pre.b}, c, ok, ok.a ? p_drop : 0.f, h_new, c_new, out, B, nb, H, st));
+        RUN(cic_cell_fwd2(Dual<const float>{pre.a, pre.b}, c, ok, ok.a ? p_drop : 0.f, h_new, c_new, out, B, nb, H, st,
+                          fc ? 1 : 0));
         // logprobs = log_softmax(logit(output)); choose the input of step t+1   (:328-365,444)
         {
             cic_gemm_args g = {};

@@ -263,7 +263,9 @@ extern "C" int cic_debug_set_attn_stamps(unsigned long long* buf);
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cell_fwd_kernel(Dual<const float> pre_d, Dual<const float> c_prev_d,
                                                        Dual<const uint8_t> keep_d, float scale, Dual<float> h_new_d,
-                                                       Dual<float> c_new_d, Dual<float> out_d, int B, int nb, int H) {
+                                                       Dual<float> c_new_d, Dual<float> out_d, int B, int nb, int H,
+                                                       int state_dropped) {
+    // state_dropped: LSTMCore (models/FCModel.py:38-42) feeds the DROPPED-OUT h back as the recurrent state
     const int H4 = H >> 2;
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nb * B * H4) return;
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(Dual<const float> pre_d, 
         const float kf = (float)((kp >> (8 * e)) & 0xffu);
         o[e] = keep ? h2 * (kf * scale) : h2;
     }
-    reinterpret_cast<f32x4*>(h_new)[idx] = hn;
+    reinterpret_cast<f32x4*>(h_new)[idx] = state_dropped ? o : hn;
     reinterpret_cast<f32x4*>(c_new)[idx] = cn;
     reinterpret_cast<f32x4*>(out)[idx] = o;
 }
@@ -303,7 +305,8 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(Dual<const float> pre_d, 
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict__ E, Dual<const int32_t> it_d,
                                                         Dual<const uint8_t> keep_d, float scale, Dual<float> x_d, int B,
-                                                        int nb, int Ed) {
+                                                        int nb, int Ed, int plain) {
+    // plain: a bare embedding row (FCModel, models/FCModel.py:66,119): no ReLU, no dropout
     const int E4 = Ed >> 2;
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nb * B * E4) return;
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float kf = (float)((kp >> (8 * e)) & 0xffu);
-        const float r = fmaxf(v[e], 0.f);
+        const float r = plain ? v[e] : fmaxf(v[e], 0.f);
         v[e] = keep ? r * (kf * scale) : r;
     }
     reinterpret_cast<f32x4*>(x)[idx] = v;
@@ -754,12 +757,12 @@ extern "C" int cic_cell_fwd(const float* pre, const float* c_prev, const uint8_t
                          cic_s(s));
 }
 int cic_cell_fwd2(Dual<const float> pre, Dual<const float> c_prev, Dual<const uint8_t> keep, float p_drop, Dual<float> h_new,
-                  Dual<float> c_new, Dual<float> out, int B, int nb, int H, hipStream_t st) {
+                  Dual<float> c_new, Dual<float> out, int B, int nb, int H, hipStream_t st, int state_dropped) {
     CIC_REQUIRE(pre.a && c_prev.a && h_new.a && c_new.a && out.a && B > 0 && H > 0 && (H & 3) == 0);
     CIC_REQUIRE(nb == 1 || (nb == 2 && pre.b && c_prev.b && h_new.b && c_new.b && out.b));
     const int n = nb * B * (H / 4);
     hipLaunchKernelGGL(cell_fwd_kernel, dim3(cic_cdiv(n, 256)), dim3(256), 0, st, pre, c_prev, keep,
-                       1.0f / (1.0f - p_drop), h_new, c_new, out, B, nb, H);
+                       1.0f / (1.0f - p_drop), h_new, c_new, out, B, nb, H, state_dropped);
     CIC_LAUNCH_CHECK();
     return 0;
 }
@@ -769,12 +772,12 @@ extern "C" int cic_embed_fwd(const float* E, const int32_t* it, const uint8_t* k
     return cic_embed_fwd2(E, dual1(it), dual1(keep), p_drop, dual1(x), B, 1, Ed, cic_s(s));
 }
 int cic_embed_fwd2(const float* E, Dual<const int32_t> it, Dual<const uint8_t> keep, float p_drop, Dual<float> x, int B,
-                   int nb, int Ed, hipStream_t st) {
+                   int nb, int Ed, hipStream_t st, int plain) {
     CIC_REQUIRE(E && it.a && x.a && B > 0 && Ed > 0 && (Ed & 3) == 0);
     CIC_REQUIRE(nb == 1 || (nb == 2 && it.b && x.b));
     const int n = nb * B * (Ed / 4);
     hipLaunchKernelGGL(embed_fwd_kernel, dim3(cic_cdiv(n, 256)), dim3(256), 0, st, E, it, keep, 1.0f / (1.0f - p_drop), x,
-                       B, nb, Ed);
+                       B, nb, Ed, plain);
     CIC_LAUNCH_CHECK();
     return 0;
 }

@@ -106,10 +106,11 @@ def speaker_decode_fwd_pair(dims, params, a, b):
 
 def speaker_decode_io(dims, params, att_pre, mode, temp=1.0, att_masks=None, att_keep=None, x_keep=None,
                       out_keep=None, U=None, pick=None, decoding_constraint=0, want_stv=False, ws=None,
-                      first_token=None, out=None, ss_u=None, ss_prob=0.0, ss_pick=None, ps_u=None, ps_prob=0.0):
+                      first_token=None, out=None, ss_u=None, ss_prob=0.0, ss_pick=None, ps_u=None, ps_prob=0.0,
+                      fc_x0=None):
     """-> dict(seq i32[B,T], slp f32[B,T], stv f32[B,T]|None, L i32[1], ws); partial-sampling modes add
     soft f32[T,B,V+1] (the caption rows handed to the listener) and the saved soft_raw / xpre."""
-    dev = att_pre.device
+    dev = att_pre.device if att_pre is not None else fc_x0.device
     B, T = dims.B, dims.T
     nbytes = lib.cic_speaker_decode_ws_bytes(C.byref(dims))
     if ws is None or ws.numel() < nbytes:
@@ -129,24 +130,27 @@ def speaker_decode_io(dims, params, att_pre, mode, temp=1.0, att_masks=None, att
         io.ps_u, io.ps_prob = _p(ps_u), float(ps_prob)
     io.mode, io.temp, io.decoding_constraint = mode, float(temp), int(decoding_constraint)
     io.att_pre, io.att_masks = _p(att_pre), _p(att_masks)
+    if fc_x0 is not None:          # FCModel decode (dims.K == 0)
+        io.fc_mode, io.x0 = 1, _p(fc_x0)
     io.att_keep, io.x_keep, io.out_keep = _p(att_keep), _p(x_keep), _p(out_keep)
     io.U, io.pick, io.first_token = _p(U), _p(pick), _p(first_token)
     io.ss_u, io.ss_prob, io.ss_pick = _p(ss_u), float(ss_prob), _p(ss_pick)
     io.seq, io.slp, io.stv, io.L = _p(out['seq']), _p(out['slp']), _p(out['stv']), _p(out['L'])
     out['io'] = io
-    out['_keep'] = (att_pre, att_masks, att_keep, x_keep, out_keep, U, pick, first_token, ss_u, ss_pick, ps_u)   # alive until the backward call
+    out['_keep'] = (att_pre, att_masks, att_keep, x_keep, out_keep, U, pick, first_token, ss_u, ss_pick, ps_u, fc_x0)   # alive until the backward call
     return out
 
 
-def speaker_decode_bwd(dims, params, fwd, grads, att_raw, d_onehot=None, dslp=None, ws_bwd=None):
+def speaker_decode_bwd(dims, params, fwd, grads, att_raw, d_onehot=None, dslp=None, ws_bwd=None, grad_params=None,
+                       d_x0=None):
     """Accumulates parameter gradients of one decode into `grads` (dict of tensors keyed like
     the parameters).  fwd: the dict returned by speaker_decode_fwd."""
     nbytes = lib.cic_speaker_decode_bwd_ws_bytes(C.byref(dims))
     if ws_bwd is None or ws_bwd.numel() < nbytes:
-        ws_bwd = torch.empty(nbytes, dtype=torch.uint8, device=att_raw.device)
+        ws_bwd = torch.empty(nbytes, dtype=torch.uint8, device=fwd['ws'].device)
     bio = DecodeBwdIO()
-    gp = speaker_params(grads)
-    bio.d_onehot, bio.dslp, bio.att_raw = _p(d_onehot), _p(dslp), _p(att_raw)
+    gp = grad_params if grad_params is not None else speaker_params(grads)
+    bio.d_onehot, bio.dslp, bio.att_raw, bio.d_x0 = _p(d_onehot), _p(dslp), _p(att_raw), _p(d_x0)
     bio.grads = C.pointer(gp)
     ws = fwd['ws']
     check(lib.cic_speaker_decode_bwd(C.byref(dims), C.byref(params), C.byref(fwd['io']), C.byref(bio),
@@ -155,10 +159,11 @@ def speaker_decode_bwd(dims, params, fwd, grads, att_raw, d_onehot=None, dslp=No
     return ws_bwd
 
 
-def listener_dims(B, F, E, J, V, T, Lp, margin=0.2, max_violation=1, no_imgnorm=0, use_abs=0):
+def listener_dims(B, F, E, J, V, T, Lp, margin=0.2, max_violation=1, no_imgnorm=0, use_abs=0, pool='last'):
     d = ListenerDims()
     d.B, d.F, d.E, d.J, d.V, d.T, d.Lp = B, F, E, J, V, T, Lp
     d.margin, d.max_violation, d.no_imgnorm, d.use_abs = float(margin), int(max_violation), int(no_imgnorm), int(use_abs)
+    d.pool = {'mean': 1, 'max': 2}.get(pool, 0)
     return d
 
 

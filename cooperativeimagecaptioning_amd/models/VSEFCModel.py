@@ -42,8 +42,6 @@ class EncoderText(nn.Module):
         self.pool_type = getattr(opt, 'vse_pool_type', '')
         if self.rnn_type.lower() != 'gru' or self.num_layers != 1:
             raise NotImplementedError('the MI355X listener path is the single-layer GRU the scripts use')
-        if self.pool_type in ('mean', 'max'):
-            raise NotImplementedError("vse_pool_type 'mean'/'max' is not on the MI355X path (scripts use 'last')")
         self.embed = nn.Embedding(self.vocab_size + 2, self.input_encoding_size)
         self.rnn = nn.GRU(self.input_encoding_size, self.embed_size, self.num_layers, batch_first=True)
         self.init_weights()
@@ -95,7 +93,8 @@ class VSEFCModel(nn.Module):
         e = self.txt_enc
         return engine.listener_dims(B, self.img_enc.fc_feat_size, e.input_encoding_size, self.embed_size,
                                     self.vocab_size, self.seq_length, Lp, self.margin,
-                                    self.contrastive_loss.max_violation, self.img_enc.no_imgnorm, self.img_enc.use_abs)
+                                    self.contrastive_loss.max_violation, self.img_enc.no_imgnorm, self.img_enc.use_abs,
+                                    pool=e.pool_type)
 
     def run(self, fc_feats, labels=None, masks=None, decode=None, only_one_retrieval='off', slot=0, want_emb=False):
         """Forward on the device.  Captions come either from ground-truth ``labels``/``masks`` or from a

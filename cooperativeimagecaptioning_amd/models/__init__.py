@@ -7,6 +7,7 @@ import torch
 from ..misc import utils
 from .AttModel import Att2in2Model, AttModel, Att2in2Core, Attention  # noqa: F401
 from .VSEFCModel import VSEFCModel  # noqa: F401
+from .FCModel import FCModel  # noqa: F401
 
 __all__ = ['setup', 'load', 'AlternatingJointModel']
 
@@ -16,8 +17,7 @@ def setup(opt, model_name, model_type='caption_model'):
         if model_name == 'att2in2':
             return Att2in2Model(opt)
         if model_name == 'fc':
-            raise NotImplementedError("caption_model 'fc' (FCModel, the reference's CPU plumbing config) is not on "
-                                      "the MI355X hot path; use 'att2in2'")
+            return FCModel(opt)
         raise Exception("Caption model not supported: {}".format(model_name))
     elif model_type == 'vse_model':
         if model_name == 'fc':

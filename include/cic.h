@@ -183,7 +183,8 @@ int cic_finalize_len(const int32_t* any_unfinished, int T, int32_t* L, cic_strea
 
 /* ---- speaker sequence engines (host loops over the kernels above, one stream, no sync) ---- */
 typedef struct {
-    int B, K, D, H, E, A, V; /* V = vocab_size: logits have V+1 columns, embedding V+2 rows */
+    int B, K, D, H, E, A, V; /* V = vocab_size: logits have V+1 columns, embedding V+2 rows.
+                                K = 0: no region features (FCModel decodes, see fc_mode) */
     int T;                   /* seq_length */
     float p_drop;            /* drop_prob_lm */
 } cic_speaker_dims;
@@ -230,6 +231,13 @@ typedef struct {
     const float* ss_u;        /* [T+1,B] scheduled-sampling uniforms, row t decides the input of step t (teacher mode) */
     float ss_prob;            /* model.ss_prob (train.py:80-85); 0 = plain teacher forcing */
     const int64_t* ss_pick;   /* [T+1,B] externally drawn scheduled-sampling tokens or NULL */
+    /* FCModel (models/FCModel.py, the fc-feature speaker of the reference's CPU configuration): fc_mode != 0 with
+     * dims.K == 0.  The decode is preceded by the image step (h0, c0) = LSTMCore(x0, 0) (:97-99,274-276), token
+     * embeddings are plain rows (no ReLU / dropout, :66,119,302), there is no attention, and the recurrent state is
+     * the DROPPED-OUT h (:38-42).  out_keep then has T+2 rows: row 0 the image step, row t+1 core step t.
+     * Parameters: embed_w, i2h, h2h, logit; the attention / att_embed / ctx2att / a2c pointers are unused. */
+    int fc_mode;
+    const float* x0;          /* [B,E] img_embed(fc_feats) (a cic_gemm_f32 call of the caller) */
     const int64_t* first_token; /* [B] input token of step 0; NULL = <bos> = vocab_size+1 (:324-326).
                                  AttModel.forward starts from labels[:, 0] = 0 instead (:131).  When set
                                  (teacher forcing) all T steps count: L is written as T. */
@@ -260,7 +268,8 @@ typedef struct {
                                 cic_listener_bwd) or NULL */
     const float* dslp;       /* [B,T] gradient w.r.t. the sampled log-probs (io->slp) or NULL */
     const cic_speaker_params* grads; /* accumulated into (+=) */
-    const float* att_raw;    /* [B,K,D] the raw region features (for the att_embed weight gradient) */
+    const float* att_raw;    /* [B,K,D] the raw region features (for the att_embed weight gradient); NULL in fc_mode */
+    float* d_x0;             /* fc_mode: out [B,E] gradient w.r.t. io->x0 (the caller back-propagates img_embed) */
 } cic_decode_bwd_io;
 size_t cic_speaker_decode_bwd_ws_bytes(const cic_speaker_dims* d);
 /* autograd of cic_speaker_decode_fwd: straight-through sampler, logit layer, BPTT through
@@ -282,6 +291,7 @@ typedef struct {
     int max_violation;   /* vse_max_violation */
     int no_imgnorm;      /* vse_no_imgnorm */
     int use_abs;         /* vse_use_abs */
+    int pool;            /* vse_pool_type: 0 'last' (the scripts' setting), 1 'mean', 2 'max' (VSEFCModel.py:118-129) */
 } cic_listener_dims;
 
 typedef struct {

@@ -174,4 +174,8 @@ def test_hip_graph_replay_matches_direct_launches():
     assert s1['captures'] - s0['captures'] >= 4 and s1['replays'] - s0['replays'] >= 8, (s0, s1)
     np.testing.assert_allclose(l1, l0, rtol=1e-5, atol=1e-6)
     for k in w0:      # four optimizer steps later the replicas still agree (float atomics: last-bit noise only)
+        if k.endswith('alpha_net.bias'):
+            # d loss / d alpha_net.bias is exactly 0 in exact arithmetic (softmax shift invariance): its fp32 gradient is
+            # rounding noise, which Adam's g / sqrt(v) turns into lr-sized steps of arbitrary sign in ANY implementation
+            continue
         np.testing.assert_allclose(w1[k].numpy(), w0[k].numpy(), rtol=1e-4, atol=2e-6, err_msg=k)

@@ -224,3 +224,31 @@ def test_clamp_adam():
     for i in range(z['grads'].shape[0]):
         J.clamp_adam_step(p, {'p': T(z['grads'][i])}, st, float(z['lr']), float(z['grad_clip']))
         close(p['p'], z['traj'][i], rtol=1e-6, atol=1e-7)
+
+
+# ---- FCModel (BASELINE configs[0], the reference's CPU plumbing case) ------------------------------------
+@pytest.mark.parametrize('name', ['fc_mle', 'fc_mle_dropout'])
+def test_fc_mle_matches_reference(name):
+    from oracle import fc as FC
+    z = GU.load_case(name)
+    cfg = GU.cfg_dict(z)
+    P = params(z, grad=True)
+    loss = FC.fc_forward(P, cfg, T(z['fc']), T(z['labels']), T(z['masks']), noise_t(z, 'noise'))
+    close(loss, z['loss'][0])
+    loss.backward()
+    for k, p in P.items():
+        check_digest(p.grad, z['gdig.' + k], k)
+
+
+@pytest.mark.parametrize('name', ['fc_sample_greedy', 'fc_sample_greedy_dropout', 'fc_sample_multinomial',
+                                  'fc_sample_multinomial_temp'])
+def test_fc_sample_matches_reference(name):
+    from oracle import fc as FC
+    z = GU.load_case(name)
+    cfg = GU.cfg_dict(z)
+    P = params(z)
+    opt = {'sample_max': int(z['opt.sample_max']), 'temperature': float(z['opt.temperature'])}
+    with torch.no_grad():
+        seq, slp = FC.fc_sample(P, cfg, T(z['fc']), opt, noise_t(z, 'noise'))
+    np.testing.assert_array_equal(seq.numpy(), z['res0'])
+    close(slp, z['res1'])

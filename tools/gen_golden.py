@@ -291,10 +291,71 @@ def opt_np(opt):
 
 
 # ----------------------------------------------------------------------------
+def gen_fc(torch, models, rec):
+    """FCModel (the fc-feature speaker of BASELINE configs[0]): MLE forward/backward and greedy / multinomial decodes."""
+    def fc_noise(events, n, B, H):
+        keep = np.ones((n, B, H), np.float32)
+        pick = np.zeros((n, B), np.int64)
+        has_pick, i = False, 0
+        for kind, t in events:
+            if kind == 'dropout':
+                keep[i] = t.numpy()
+                i += 1
+            elif kind == 'multinomial':
+                pick[i] = t.numpy()          # drawn at iteration i (before that iteration's core call)
+                has_pick = True
+        o = {'noise.out_keep': keep}
+        if has_pick:
+            o['noise.pick'] = pick
+        return o
+
+    for name, pdrop, seed in (('fc_mle', 0.0, 11), ('fc_mle_dropout', 0.5, 12)):
+        opt = make_opt(caption_model='fc', drop_prob_lm=pdrop)
+        torch.manual_seed(seed)
+        fm = models.setup(opt, 'fc', 'caption_model')
+        fm.train()
+        for w in (fm.core.i2h.weight, fm.core.h2h.weight, fm.embed.weight, fm.img_embed.weight):
+            w.data.mul_(3.0)
+        fm.logit.weight.data.mul_(6.0)
+        fm.logit.bias.data.uniform_(-0.2, 0.2)
+        batch = make_batch(torch, opt, K=7, seed=seed)
+        rec.start()
+        loss = fm(batch['fc_feats'], None, None, batch['labels'], batch['masks'])
+        ev = rec.stop()
+        loss.backward()
+        T2 = batch['labels'].shape[1]
+        save(name, **{'w.' + k: v for k, v in sd_np(fm).items()}, **opt_np(opt), fc=batch['fc_feats'],
+             labels=batch['labels'], masks=batch['masks'], loss=loss.detach().reshape(1),
+             **fc_noise(ev, T2, opt.batch_size, opt.rnn_size), **digests((k, p.grad) for k, p in fm.named_parameters()))
+
+    for name, smax, temp, pdrop, bias0, seed in (('fc_sample_greedy', 1, 1.0, 0.0, 0.6, 13), ('fc_sample_greedy_dropout', 1, 1.0, 0.5, 0.4, 14),
+                                                 ('fc_sample_multinomial', 0, 1.0, 0.5, 0.8, 15), ('fc_sample_multinomial_temp', 0, 0.7, 0.0, 1.2, 16)):
+        opt = make_opt(caption_model='fc', drop_prob_lm=pdrop)
+        torch.manual_seed(seed)
+        fm = models.setup(opt, 'fc', 'caption_model')
+        fm.train()
+        for w in (fm.core.i2h.weight, fm.core.h2h.weight, fm.embed.weight, fm.img_embed.weight):
+            w.data.mul_(3.0)
+        fm.logit.weight.data.mul_(6.0)
+        fm.logit.bias.data[0] = bias0
+        batch = make_batch(torch, opt, K=7, seed=seed)
+        rec.start()
+        with torch.no_grad():
+            seq, slp = fm.sample(batch['fc_feats'], None, None, {'sample_max': smax, 'temperature': temp})
+        ev = rec.stop()
+        print(name, 'L =', seq.shape[1], 'lens', (seq > 0).sum(1).tolist())
+        save(name, **{'w.' + k: v for k, v in sd_np(fm).items()}, **opt_np(opt), fc=batch['fc_feats'], res0=seq, res1=slp,
+             **{'opt.sample_max': np.float64(smax), 'opt.temperature': np.float64(temp)},
+             **fc_noise(ev, opt.seq_length + 2, opt.batch_size, opt.rnn_size))
+
+
 def main():
     torch, models, rewards = install_harness()
     rec = Recorder(torch)
     torch.set_num_threads(4)
+    if '--only-fc' in sys.argv:
+        gen_fc(torch, models, rec)
+        return
 
     def build(opt, seed=0, eos_bias=None):
         torch.manual_seed(seed)
@@ -573,6 +634,7 @@ def main():
         traj.append(p.detach().clone())
     save('clamp_adam', p0=p0, grads=torch.stack(gs), traj=torch.stack(traj), lr=np.float64(5e-4),
          grad_clip=np.float64(0.1))
+    gen_fc(torch, models, rec)
 
 
 if __name__ == '__main__':
