@@ -175,6 +175,8 @@ def main():
     model = models.AlternatingJointModel(opt).to(dev).train()
     model.caption_generator.noise.manual_seed(1000 + rank)
     optimizer_dict = optim.load_optimizer(model, opt)
+    if world > 1:
+        optim.overlap_gradient_exchange(model, optimizer_dict)   # listener all-reduce under the speaker backward
     batch = synthetic.make_batch(opt, seed=1234 + rank, device=dev)    # per-rank shard of the global batch
     turn = opt.alternating_turn[0]
     optimizer = optimizer_dict[turn]

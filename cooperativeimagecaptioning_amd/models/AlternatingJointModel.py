@@ -57,6 +57,9 @@ class AlternatingJointModel(nn.Module):
         # and are independent until the reward, so they advance in lock step through shared launches
         # (cic_speaker_decode_fwd_pair: every per-timestep kernel once over 2B rows; bit-identical results).
         self.pair_decodes = True
+        # data-parallel runs: optimizer.overlap_gradient_exchange() sets this to the listener optimizer's
+        # begin_all_reduce, called from backward() as soon as the listener's gradient is final
+        self.listener_grads_ready = None
         # Load model (:131-177)
         if opt.is_alternating:
             if getattr(opt, 'continue_from_existing_models', False):
@@ -153,7 +156,10 @@ class AlternatingJointModel(nn.Module):
             vse._loss['contrastive'] = gt.loss_sum.detach()[0]
             terms.append((vw, gt.loss_sum))
             if lst_grad:
-                bwd_steps.append(lambda go: vse.run_backward(gt, g_scalar=(go * vw).reshape(1).contiguous()))
+                def bwd_gt(go, gt=gt):
+                    vse.run_backward(gt, g_scalar=(go * vw).reshape(1).contiguous())
+                bwd_gt.is_listener = True
+                bwd_steps.append(bwd_gt)
 
         sample = None
         greedy = None
@@ -202,6 +208,7 @@ class AlternatingJointModel(nn.Module):
                 def bwd_listener(go, gen=gen, d_onehot=d_onehot):
                     vse.run_backward(gen, g_scalar=(go * dw).reshape(1).contiguous(), param_grads=lst_grad,
                                      d_onehot=d_onehot)
+                bwd_listener.is_listener = True
                 if spk_grad or lst_grad:
                     bwd_steps.append(bwd_listener)
                 sample.d_onehot = d_onehot
@@ -243,9 +250,14 @@ class AlternatingJointModel(nn.Module):
         if anchor is None or not torch.is_grad_enabled() or not bwd_steps:
             return loss.detach()
 
+        # the listener's gradient is final after the last step that runs a listener backward engine
+        last_lst = max([i for i, st in enumerate(bwd_steps) if getattr(st, 'is_listener', False)], default=-1)
+
         def backward(go):
-            for step in bwd_steps:
+            for i, step in enumerate(bwd_steps):
                 step(go)
+                if i == last_lst and lst_grad and self.listener_grads_ready is not None:
+                    self.listener_grads_ready()
         return EngineLoss.apply(loss, anchor, backward)
 
     def forward(self, fc_feats, seq, masks, data, att_feats, att_masks, is_alternating=False, alternating_turn=None):

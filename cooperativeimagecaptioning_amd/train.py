@@ -119,6 +119,9 @@ def train(opt, loader=None):
     model = models.AlternatingJointModel(opt).to(device).train()
     model.caption_generator.noise.manual_seed(opt.seed * 1000 + rank)
     optimizer_dict = load_optimizer(model, opt)
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        from .optimizer import overlap_gradient_exchange
+        overlap_gradient_exchange(model, optimizer_dict)
     update_lr_flag = True
     iteration, epoch, epoch_start = 0, 0, 0
     loss_history = {}

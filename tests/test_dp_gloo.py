@@ -46,8 +46,15 @@ def _worker(rank, world, port, out_dir):
         g = torch.Generator().manual_seed(100 + rank)
         local = torch.randn(fl.numel, generator=g)
         fl.grad.copy_(local)
+        if agent == 'listener':
+            # the overlapped form bench.py / train.py use for the listener: started from inside backward(),
+            # awaited by step()
+            optim.overlap_gradient_exchange(model, od)
+            assert model.listener_grads_ready is not None
+            model.listener_grads_ready()
+            assert o._pending is not None
         scale = o.all_reduce_grads()
-        assert scale == 1.0 / world
+        assert scale == 1.0 / world and o._pending is None
         res[agent] = (local.numpy(), fl.grad.numpy().copy())
         # p.grad views alias the reduced buffer
         p0 = fl.params[0]
