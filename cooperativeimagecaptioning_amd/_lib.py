@@ -92,6 +92,11 @@ class DecodeBwdIO(C.Structure):
                 ('d_x0', c_ptr)]
 
 
+class BeamIO(C.Structure):
+    _fields_ = [('beam', C.c_int), ('decoding_constraint', C.c_int), ('att_pre', c_ptr), ('att_masks', c_ptr),
+                ('seq', c_ptr), ('logps', c_ptr), ('score', c_ptr)]
+
+
 class CiderdArgs(C.Structure):
     _fields_ = [('B', C.c_int), ('T', C.c_int), ('n_images', C.c_int), ('spi', C.c_int), ('R', C.c_int),
                 ('Tr', C.c_int), ('gen', c_ptr), ('L_gen', c_ptr), ('greedy', c_ptr), ('L_greedy', c_ptr),

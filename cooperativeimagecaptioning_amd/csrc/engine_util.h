@@ -39,7 +39,7 @@ int cic_add_vec(const float* a, const float* b, float* o, int n, hipStream_t st)
 bool cic_attn_pair_ok(int K, int A, int H);
 int cic_attn_fwd2(Dual<const float> att_h, Dual<const float> p_att, Dual<const float> att, const float* w_alpha,
                   const float* b_alpha, const float* masks, Dual<float> att_res, Dual<float> alpha, Dual<float> dot, int B,
-                  int nb, int K, int A, int H, hipStream_t st);
+                  int nb, int K, int A, int H, hipStream_t st, int att_div = 1);
 int cic_cell_fwd2(Dual<const float> pre, Dual<const float> c_prev, Dual<const uint8_t> keep, float p_drop, Dual<float> h_new,
                   Dual<float> c_new, Dual<float> out, int B, int nb, int H, hipStream_t st, int state_dropped = 0);
 int cic_embed_fwd2(const float* E, Dual<const int32_t> it, Dual<const uint8_t> keep, float p_drop, Dual<float> x, int B,

@@ -30,14 +30,15 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const float* __restri
                                                        float* __restrict__ att_res,       // [B,H]
                                                        float* __restrict__ alpha_out,     // [B,K]
                                                        float* __restrict__ dot_out,       // [B,K] or null
-                                                       int K, int A, int H) {
+                                                       int K, int A, int H, int att_div) {
     __shared__ float sdot[64];
     __shared__ __attribute__((aligned(16))) float sacc[NW * NI * 256];
     __shared__ __attribute__((aligned(16))) float sacc2[4 * NI * 256];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int bi = b / att_div;                 // image whose regions row b attends to (beam search: att_div rows per image)
     const int A4 = A >> 2, H4 = H >> 2;
-    const f32x4* pa4 = reinterpret_cast<const f32x4*>(p_att + (size_t)b * K * A);
-    const f32x4* at4 = reinterpret_cast<const f32x4*>(att + (size_t)b * K * H);
+    const f32x4* pa4 = reinterpret_cast<const f32x4*>(p_att + (size_t)bi * K * A);
+    const f32x4* at4 = reinterpret_cast<const f32x4*>(att + (size_t)bi * K * H);
     const f32x4* ah4 = reinterpret_cast<const f32x4*>(att_h + (size_t)b * A);
     const f32x4* wa4 = reinterpret_cast<const f32x4*>(w_alpha);
 
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const float* __restri
     float minv = 1.0f;
     if (masks) {   // weight = weight * mask; weight /= weight.sum()   (AttModel.py:481-483)
         float ms = 0.f;
-        for (int k = 0; k < K; ++k) ms += __expf(sdot[k] - mx) * inv * masks[(size_t)b * K + k];
+        for (int k = 0; k < K; ++k) ms += __expf(sdot[k] - mx) * inv * masks[(size_t)bi * K + k];
         minv = 1.0f / ms;
     }
     f32x4 acc[NI];
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const float* __restri
         const int k = w + NW * j;
         if (k < K) {
             float a = __expf(sdot[k] - mx) * inv;
-            if (masks) a = a * masks[(size_t)b * K + k] * minv;
+            if (masks) a = a * masks[(size_t)bi * K + k] * minv;
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int c = lane + 64 * i;
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const float* __restri
     }
     if (tid < K) {
         float a = __expf(sdot[tid] - mx) * inv;
-        if (masks) a = a * masks[(size_t)b * K + tid] * minv;
+        if (masks) a = a * masks[(size_t)bi * K + tid] * minv;
         alpha_out[(size_t)b * K + tid] = a;
         if (dot_out) dot_out[(size_t)b * K + tid] = sdot[tid];
     }
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_cols_kernel(Dual<const float> a
                                                              Dual<const float> att_d, const float* __restrict__ w_alpha,
                                                              const float* __restrict__ b_alpha, const float* __restrict__ masks,
                                                              Dual<float> att_res_d, Dual<float> alpha_d, Dual<float> dot_d, int B0,
-                                                             int K, int H) {
+                                                             int K, int H, int att_div) {
     __shared__ float sp[16 * 64];
     unsigned long long* stamps = g_attn_stamps;
     unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
@@ -182,8 +183,9 @@ __global__ __launch_bounds__(1024) void attn_fwd_cols_kernel(Dual<const float> a
     const int NW = blockDim.x >> 6;                     // H / (32 * NCG) waves
     const int c = lane & 7, rg = lane >> 3;
     const int H4 = H >> 2;
-    const f32x4* pa4 = reinterpret_cast<const f32x4*>(p_att + (size_t)b * K * H);
-    const f32x4* at4 = reinterpret_cast<const f32x4*>(att + (size_t)b * K * H);
+    const int bi = b / att_div;                 // image whose regions row b attends to (beam search: att_div rows per image)
+    const f32x4* pa4 = reinterpret_cast<const f32x4*>(p_att + (size_t)bi * K * H);
+    const f32x4* at4 = reinterpret_cast<const f32x4*>(att + (size_t)bi * K * H);
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     int col4[NCG];
     f32x4 ah[NCG], wa[NCG];
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_cols_kernel(Dual<const float> a
     const float sum = wave_sum_fast(ex);
     float al = ex * (1.0f / sum);
     if (masks) {   // weight = weight * mask; weight /= weight.sum()   (AttModel.py:481-483)
-        al = lane < K ? al * masks[(size_t)b * K + lane] : 0.f;
+        al = lane < K ? al * masks[(size_t)bi * K + lane] : 0.f;
         const float ms = wave_sum_fast(al);
         al = al * (1.0f / ms);
     }
@@ -648,14 +650,15 @@ extern "C" int cic_attn_fwd(const float* att_h, const float* p_att, const float*
                             const float* b_alpha, const float* masks, float* att_res, float* alpha,
                             float* dot, int B, int K, int A, int H, cic_stream_t s) {
     return cic_attn_fwd2(dual1(att_h), dual1(p_att), dual1(att), w_alpha, b_alpha, masks, dual1(att_res), dual1(alpha),
-                         dual1(dot), B, 1, K, A, H, cic_s(s));
+                         dual1(dot), B, 1, K, A, H, cic_s(s), 1);
 }
 
 bool cic_attn_pair_ok(int K, int A, int H) { return A == H && (H & 63) == 0 && H <= 512 && K <= 64; }
 
 int cic_attn_fwd2(Dual<const float> att_h_d, Dual<const float> p_att_d, Dual<const float> att_d, const float* w_alpha,
                   const float* b_alpha, const float* masks, Dual<float> att_res_d, Dual<float> alpha_d, Dual<float> dot_d,
-                  int B, int nb, int K, int A, int H, hipStream_t st) {
+                  int B, int nb, int K, int A, int H, hipStream_t st, int att_div) {
+    CIC_REQUIRE(att_div >= 1);
     const float *att_h = att_h_d.a, *p_att = p_att_d.a, *att = att_d.a;
     float *att_res = att_res_d.a, *alpha = alpha_d.a, *dot = dot_d.a;
     CIC_REQUIRE(att_h && p_att && att && w_alpha && b_alpha && att_res && alpha);
@@ -672,9 +675,9 @@ int cic_attn_fwd2(Dual<const float> att_h_d, Dual<const float> p_att_d, Dual<con
 #define GOC(J)                                                                                                       \
     do {                                                                                                             \
         if (ncg == 2) hipLaunchKernelGGL((attn_fwd_cols_kernel<J, 2>), grid, blk, 0, st, att_h_d, p_att_d, att_d, w_alpha, \
-                                         b_alpha, masks, att_res_d, alpha_d, dot_d, B, K, H);                        \
+                                         b_alpha, masks, att_res_d, alpha_d, dot_d, B, K, H, att_div);               \
         else hipLaunchKernelGGL((attn_fwd_cols_kernel<J, 1>), grid, blk, 0, st, att_h_d, p_att_d, att_d, w_alpha,     \
-                                b_alpha, masks, att_res_d, alpha_d, dot_d, B, K, H);                                 \
+                                b_alpha, masks, att_res_d, alpha_d, dot_d, B, K, H, att_div);                        \
     } while (0)
         if (K <= 8) GOC(1); else if (K <= 16) GOC(2); else if (K <= 24) GOC(3); else if (K <= 32) GOC(4);
         else if (K <= 40) GOC(5); else if (K <= 48) GOC(6); else GOC(8);
@@ -685,7 +688,7 @@ int cic_attn_fwd2(Dual<const float> att_h_d, Dual<const float> p_att_d, Dual<con
     // 16 waves per image: each wave owns <= 4 regions, whose p_att and att rows are all in flight at once
 #define GO(NI, KPW, HOLD)                                                                                        \
     hipLaunchKernelGGL((attn_fwd_kernel<NI, KPW, 16, HOLD>), grid, dim3(1024), 0, st, att_h, p_att, att, w_alpha, \
-                       b_alpha, masks, att_res, alpha, dot, K, A, H)
+                       b_alpha, masks, att_res, alpha, dot, K, A, H, att_div)
     if (mx <= 256) {
         if (K <= 48) GO(1, 3, true); else GO(1, 4, true);
     } else if (mx <= 512) {

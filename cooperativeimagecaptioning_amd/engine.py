@@ -159,6 +159,31 @@ def speaker_decode_bwd(dims, params, fwd, grads, att_raw, d_onehot=None, dslp=No
     return ws_bwd
 
 
+lib.cic_speaker_beam_ws_bytes.argtypes = [C.POINTER(SpeakerDims), C.c_int]
+lib.cic_speaker_beam_ws_bytes.restype = C.c_size_t
+lib.cic_speaker_beam_search.argtypes = [C.POINTER(SpeakerDims), C.POINTER(SpeakerParams), C.POINTER(_lib.BeamIO), P, C.c_size_t, P]
+lib.cic_speaker_beam_search.restype = C.c_int
+
+
+def speaker_beam_search(dims, params, att_pre, beam, att_masks=None, decoding_constraint=0, ws=None):
+    """AttModel.sample_beam on the device -> dict(seq i32[B,T], logps f32[B,T], score f32[B], ws)."""
+    dev = att_pre.device
+    nbytes = lib.cic_speaker_beam_ws_bytes(C.byref(dims), int(beam))
+    if nbytes == 0:
+        raise _lib.CicError(f'beam_size {beam} is outside 1..16')
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    out = dict(seq=torch.zeros(dims.B, dims.T, dtype=torch.int32, device=dev), logps=torch.zeros(dims.B, dims.T, device=dev),
+               score=torch.zeros(dims.B, device=dev), ws=ws)
+    io = _lib.BeamIO()
+    io.beam, io.decoding_constraint = int(beam), int(decoding_constraint)
+    io.att_pre, io.att_masks = _p(att_pre), _p(att_masks)
+    io.seq, io.logps, io.score = _p(out['seq']), _p(out['logps']), _p(out['score'])
+    check(lib.cic_speaker_beam_search(C.byref(dims), C.byref(params), C.byref(io), ws.data_ptr(), ws.numel(), stream()),
+          'cic_speaker_beam_search')
+    return out
+
+
 def listener_dims(B, F, E, J, V, T, Lp, margin=0.2, max_violation=1, no_imgnorm=0, use_abs=0, pool='last'):
     d = ListenerDims()
     d.B, d.F, d.E, d.J, d.V, d.T, d.Lp = B, F, E, J, V, T, Lp

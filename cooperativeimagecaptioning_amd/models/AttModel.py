@@ -232,6 +232,32 @@ class AttModel(nn.Module):
             return loss[0].detach().clone()
         return EngineLoss.apply(loss[0], anchor, bwd)
 
+    def sample_beam(self, fc_feats, att_feats, att_masks, opt={}):
+        """models/AttModel.py:150-289: beam search over all images at once on the device (the reference decodes image
+        by image and merges beams on the host).  Evaluation semantics: no dropout.  Returns (seq, seqLogprobs) as
+        the reference does and keeps done_beams[k] = [best beam] (seq, logps, p)."""
+        self._check_inputs(att_feats)
+        beam_size = opt.get('beam_size', 10)
+        dc = opt.get('decoding_constraint', self.decoding_constraint)
+        assert beam_size <= self.vocab_size + 1, 'lets assume this for now (models/AttModel.py:164-166)'
+        fl = self.flat()
+        B, K, _ = att_feats.shape
+        dims = self._dims(B, K, self.seq_length)
+        dims.p_drop = 0.0
+        params = engine.speaker_params(fl.tensors())
+        att_raw = self._buf.stage('att_raw', att_feats, torch.float32)
+        self._staged_att = None
+        att_pre = engine.speaker_att_embed_fwd(dims, params, att_raw,
+                                               self._buf.get('att_pre', (B, K, self.rnn_size), torch.float32, att_raw.device))
+        if att_masks is not None:
+            att_masks = self._buf.stage('att_masks', att_masks, torch.float32)
+        key = ('beam', B, K, beam_size)
+        out = engine.speaker_beam_search(dims, params, att_pre, beam_size, att_masks, dc, ws=self._ws.get(key))
+        self._ws[key] = out['ws']
+        seq, logps = out['seq'].long(), out['logps']
+        self.done_beams = [[{'seq': seq[k], 'logps': logps[k], 'p': out['score'][k]}] for k in range(B)]
+        return seq, logps
+
     def sample(self, fc_feats, att_feats, att_masks, opt={}):
         """models/AttModel.py:291-452 (beam_size 1).  Outputs are detached (evaluation use); the joint
         model differentiates through decode()/decode_backward() directly."""
@@ -240,7 +266,7 @@ class AttModel(nn.Module):
         beam_size = opt.get('beam_size', 1)
         temperature = opt.get('temperature', 1.0)
         if beam_size > 1:
-            raise NotImplementedError('sample_beam (eval-only, SURVEY.md §8f N1) is not on the MI355X path yet')
+            return self.sample_beam(fc_feats, att_feats, att_masks, opt)
         dc = opt.get('decoding_constraint', self.decoding_constraint)
         plain = self.retrieval_reward == 'reinforce' or not use_one_hot
         if sample_max:

@@ -282,6 +282,23 @@ int cic_speaker_decode_bwd(const cic_speaker_dims* d, const cic_speaker_params* 
                            const cic_decode_bwd_io* bio, void* ws_fwd, size_t ws_fwd_bytes, void* ws_bwd,
                            size_t ws_bwd_bytes, cic_stream_t s);
 
+/* ---- beam-search decode (evaluation): AttModel.sample_beam, models/AttModel.py:150-289 ------------------
+ * All B x beam rows advance together; beam merge, state re-ordering and done-beam bookkeeping run on the device
+ * (the reference decodes image by image and merges on the host).  Evaluation mode: no dropout.  Returns, per
+ * image, the recorded beam the reference returns (see csrc/beam.hip for the reference's scoring quirk). */
+typedef struct {
+    int beam;                 /* beam_size, 1..16 and <= V+1 */
+    int decoding_constraint;
+    const float* att_pre;     /* [B,K,H] from cic_speaker_att_embed_fwd */
+    const float* att_masks;   /* [B,K] or NULL */
+    int32_t* seq;             /* out [B,T] tokens of the returned beam, 0 after its end */
+    float* logps;             /* out [B,T] their log-probs, 0 after the end */
+    float* score;             /* out [B]  done_beams[k][0]['p'] */
+} cic_beam_io;
+size_t cic_speaker_beam_ws_bytes(const cic_speaker_dims* d, int beam);
+int cic_speaker_beam_search(const cic_speaker_dims* d, const cic_speaker_params* p, const cic_beam_io* io, void* ws,
+                            size_t ws_bytes, cic_stream_t s);
+
 /* ---- listener (VSE-fc) engines: models/VSEFCModel.py:12-241 ------------------------------ */
 typedef struct {
     int B, F, E, J, V;   /* batch, fc_feat_size, input_encoding_size, vse_embed_size, vocab_size */

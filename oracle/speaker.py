@@ -320,3 +320,72 @@ def mle_forward(P, cfg, fc_feats, att_raw, att_masks, seq, masks, noise=None, ss
         outputs.append(logp)
     output = torch.stack(outputs, 1)                                  # :143
     return language_model_criterion(output, seq[:, 1:], masks[:, 1:])  # :144
+
+
+def sample_beam(P, cfg, fc_feats, att_raw, att_masks, opt=None):
+    """AttModel.sample_beam, AttModel.py:150-289 (evaluation mode: no dropout).  One image at a time, `beam_size`
+    beams; per step every beam's log-probs are sorted, the top beam_size words of each beam form the candidates
+    (word-rank major, beam minor), the candidates are stably sorted by cumulative log-prob and the first beam_size
+    survive.  A beam that emits <eos> = 0 is recorded as done BUT KEEPS DECODING (:256-263 record, nothing removes
+    it); at t == seq_length every beam is recorded.  The recorded score 'p' is `beam_logprobs_sum[vix]`, a 0-dim
+    VIEW of the running sums (:262), so what the final sort (:281-282) compares is the FINAL running sum of the
+    beam slot an entry was recorded from, not the sum at recording time; seq / logps are cloned snapshots.  The
+    first recorded entry among those with the largest such score is returned.
+    Returns (seq i64[B,T], logps f32[B,T], score f32[B])."""
+    opt = opt or {}
+    beam = opt.get('beam_size', 10)
+    dc = opt.get('decoding_constraint', cfg.get('decoding_constraint', 0))
+    V, T = cfg['vocab_size'], cfg['seq_length']
+    B = att_raw.shape[0]
+    H = P['core.h2h.weight'].shape[1]
+    att_all = att_embed(P, att_raw, None, 0.0)
+    p_att_all = ctx2att(P, att_all)
+    seq = torch.zeros(B, T, dtype=torch.long)
+    logps = torch.zeros(B, T)
+    score = torch.zeros(B)
+    for k in range(B):
+        att = att_all[k:k + 1].expand(beam, -1, -1)
+        p_att = p_att_all[k:k + 1].expand(beam, -1, -1)
+        am = att_masks[k:k + 1].expand(beam, -1) if att_masks is not None else None
+        h = torch.zeros(beam, H)
+        c = torch.zeros(beam, H)
+        beam_seq = torch.zeros(T, beam, dtype=torch.long)
+        beam_lp = torch.zeros(T, beam)
+        beam_sum = torch.zeros(beam)
+        done = []
+        logprobs = None
+        for t in range(T + 1):
+            if t == 0:
+                it = torch.full((beam,), V + 1, dtype=torch.long)                        # :190-193
+            else:
+                lp = logprobs.clone()
+                if dc and t > 1:                                                          # :201-204
+                    lp.scatter_(1, beam_seq[t - 2:t - 1].t(), float('-inf'))
+                ys, ix = torch.sort(lp, 1, True)                                          # :207
+                rows = 1 if t == 1 else beam                                              # :211-213
+                cands = []
+                for cc in range(min(beam, ys.shape[1])):
+                    for q in range(rows):
+                        r = ys[q, cc]
+                        cands.append((int(ix[q, cc]), q, (beam_sum[q] + r).item(), r.item()))   # fp32 add (:218-219)
+                cands = sorted(cands, key=lambda x: -x[2])                                # stable (:224)
+                h_prev, c_prev = h.clone(), c.clone()
+                seq_prev, lp_prev = beam_seq[:t - 1].clone(), beam_lp[:t - 1].clone()
+                for vix in range(beam):
+                    cw, q, p, r = cands[vix]
+                    if t > 1:
+                        beam_seq[:t - 1, vix] = seq_prev[:, q]
+                        beam_lp[:t - 1, vix] = lp_prev[:, q]
+                    h[vix], c[vix] = h_prev[q], c_prev[q]                                 # :241-246
+                    beam_seq[t - 1, vix] = cw
+                    beam_lp[t - 1, vix] = r
+                    beam_sum[vix] = p
+                    if cw == 0 or t == T:                                                 # :256-263
+                        done.append((beam_seq[:, vix].clone(), beam_lp[:, vix].clone(), vix))   # 'p' aliases slot vix
+                it = beam_seq[t - 1]
+            xt = embed_token(P, it, None, 0.0)
+            _, h, c, _ = core_step(P, xt, att, p_att, am, h, c, None, 0.0)
+            logprobs, _ = logprobs_from_output(P, h)
+        best = sorted(done, key=lambda x: -float(beam_sum[x[2]]))[0]                      # :281-285, final slot sums
+        seq[k], logps[k], score[k] = best[0], best[1], beam_sum[best[2]]
+    return seq, logps, score

@@ -252,3 +252,17 @@ def test_fc_sample_matches_reference(name):
         seq, slp = FC.fc_sample(P, cfg, T(z['fc']), opt, noise_t(z, 'noise'))
     np.testing.assert_array_equal(seq.numpy(), z['res0'])
     close(slp, z['res1'])
+
+
+# ---- AttModel.sample_beam (the evaluation decode) -------------------------------------------
+@pytest.mark.parametrize('name', ['beam2', 'beam3_early', 'beam5_constraint'])
+def test_sample_beam_matches_reference(name):
+    z = GU.load_case(name)
+    cfg = GU.cfg_dict(z)
+    P = params(z)
+    with torch.no_grad():
+        seq, lps, score = S.sample_beam(P, cfg, T(z['fc']), T(z['att_raw']), None,
+                                        {'beam_size': int(z['beam']), 'decoding_constraint': cfg['decoding_constraint']})
+    np.testing.assert_array_equal(seq.numpy(), z['res0'])
+    close(lps, z['res1'])
+    close(score, z['score'], rtol=1e-5)

@@ -349,12 +349,39 @@ def gen_fc(torch, models, rec):
              **fc_noise(ev, opt.seq_length + 2, opt.batch_size, opt.rnn_size))
 
 
+BEAM_CASES = (('beam2', 2, 0, 2.0, 22), ('beam3_early', 3, 0, 1.8, 22), ('beam5_constraint', 5, 1, 1.86, 22))
+
+
+def gen_beam(torch, models, rec):
+    """AttModel.sample_beam (evaluation decode, AttModel.py:150-289): beam 2 (eval.py's setting), 3 and 5 with the
+    decoding constraint."""
+    for name, beam, dc, bias0, seed in BEAM_CASES:
+        opt = make_opt(batch_size=5, decoding_constraint=dc)
+        torch.manual_seed(seed)
+        m = models.AlternatingJointModel(opt)
+        cg = m.caption_generator
+        batch = make_batch(torch, opt, K=7, seed=seed)
+        widen(cg, batch)
+        cg.logit.bias.data[0] = bias0
+        cg.eval()
+        with torch.no_grad():
+            seq, lps = cg.sample(batch['fc_feats'], batch['att_feats'], None, {'beam_size': beam, 'decoding_constraint': dc})
+        score = np.array([float(cg.done_beams[k][0]['p']) for k in range(opt.batch_size)], np.float32)
+        nd = np.array([len(cg.done_beams[k]) for k in range(opt.batch_size)])
+        print(name, 'lens', (seq > 0).sum(1).tolist(), 'done beams per image', nd.tolist())
+        save(name, **{'w.' + k: v for k, v in sd_np(cg).items()}, **opt_np(opt), att_raw=batch['att_feats'], fc=batch['fc_feats'],
+             res0=seq, res1=lps, score=score, beam=np.int64(beam))
+
+
 def main():
     torch, models, rewards = install_harness()
     rec = Recorder(torch)
     torch.set_num_threads(4)
     if '--only-fc' in sys.argv:
         gen_fc(torch, models, rec)
+        return
+    if '--only-beam' in sys.argv:
+        gen_beam(torch, models, rec)
         return
 
     def build(opt, seed=0, eos_bias=None):
@@ -635,6 +662,7 @@ def main():
     save('clamp_adam', p0=p0, grads=torch.stack(gs), traj=torch.stack(traj), lr=np.float64(5e-4),
          grad_clip=np.float64(0.1))
     gen_fc(torch, models, rec)
+    gen_beam(torch, models, rec)
 
 
 if __name__ == '__main__':
