@@ -352,6 +352,17 @@ int cic_listener_fwd(const cic_listener_dims* d, const cic_listener_params* p, c
 int cic_listener_bwd(const cic_listener_dims* d, const cic_listener_params* p, const cic_listener_io* io,
                      const cic_listener_bwd_io* bio, void* ws, size_t ws_bytes, cic_stream_t s);
 
+/* ---- retrieval-rank evaluation of the listener: eval_utils.i2t / t2i (eval_utils.py:545-720), cosine measure ----
+ * ims [n_images, J]: one embedding per image; caps [n_images*cpi, J]: its cpi captions in a row (5 ground-truth
+ * captions, or 1 generated caption).  One similarity GEMM + rank kernels; a rank is the position in
+ * np.argsort(d)[::-1], i.e. the number of candidates scoring higher (ties: the larger index first).
+ *   ranks_i2t/top1_i2t [n_images]      best rank among the image's own captions, arg-max caption   (may be NULL)
+ *   ranks_t2i/top1_t2i [n_images*cpi]  rank of the caption's own image, arg-max image              (may be NULL) */
+size_t cic_retrieval_ws_bytes(int n_images, int cpi);
+int cic_retrieval_ranks(const float* ims, const float* caps, int n_images, int cpi, int J, int32_t* ranks_i2t,
+                        int32_t* top1_i2t, int32_t* ranks_t2i, int32_t* top1_t2i, void* ws, size_t ws_bytes,
+                        cic_stream_t s);
+
 /* ---- loss assembly and optimiser ------------------------------------------------------- */
 /* loss = sum_{b,t<L} slp[b,t] * (coef_sign*coef[b]) * m[b,t] / sum m with m = gen_masks[:, 1:]
  * (m[b,0] = 1, m[b,t] = seq[b,t-1] > 0): the self-critical CIDEr term (coef = reward, sign -1;

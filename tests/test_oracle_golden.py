@@ -1,5 +1,7 @@
 """CPU: the oracle (oracle/) replayed against the golden fixtures made from the
 reference itself by tools/gen_golden.py.  This is what pins the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -266,3 +268,20 @@ def test_sample_beam_matches_reference(name):
     np.testing.assert_array_equal(seq.numpy(), z['res0'])
     close(lps, z['res1'])
     close(score, z['score'], rtol=1e-5)
+
+
+# ---- retrieval-rank evaluation (eval_utils.i2t / t2i) ---------------------------------------
+@pytest.mark.parametrize('name', ['retrieval_5cap', 'retrieval_gen_1cap'])
+def test_retrieval_ranks_match_reference(name):
+    from oracle import retrieval as R
+    z = dict(np.load(os.path.join(GU.GOLDEN, name + '.npz')))
+    cpi = int(z['cpi'])
+    if cpi == 5:
+        r, (ranks, top1) = R.i2t(z['images'], z['captions'])
+        np.testing.assert_array_equal(ranks, z['i2t_ranks'])
+        np.testing.assert_array_equal(top1, z['i2t_top1'])
+        np.testing.assert_allclose(np.array(r), z['i2t_r'])
+    ri, (ranks_i, top1_i) = R.t2i(z['images'], z['captions'], cpi)
+    np.testing.assert_array_equal(ranks_i, z['t2i_ranks'])
+    np.testing.assert_array_equal(top1_i, z['t2i_top1'])
+    np.testing.assert_allclose(np.array(ri), z['t2i_r'])

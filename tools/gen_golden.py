@@ -373,10 +373,34 @@ def gen_beam(torch, models, rec):
              res0=seq, res1=lps, score=score, beam=np.int64(beam))
 
 
+def gen_retrieval(torch):
+    """eval_utils.i2t / t2i (retrieval-rank evaluation of the listener, eval_utils.py:545-720) on random unit-norm
+    embeddings with a planted image-caption correlation."""
+    import eval_utils
+    for name, N, K, cpi, seed in (('retrieval_5cap', 60, 48, 5, 41), ('retrieval_gen_1cap', 80, 32, 1, 42)):
+        rs = np.random.RandomState(seed)
+        im = rs.randn(N, K).astype(np.float32)
+        im /= np.linalg.norm(im, axis=1, keepdims=True)
+        cap = (0.8 * np.repeat(im, cpi, 0) + rs.randn(N * cpi, K).astype(np.float32))
+        cap /= np.linalg.norm(cap, axis=1, keepdims=True)
+        images = np.repeat(im, cpi, 0)
+        data = [{'id': i, 'file_path': str(i)} for i in range(N)]
+        out = {}
+        if cpi == 5:
+            r, (ranks, top1) = eval_utils.i2t(images, cap, measure='cosine', return_ranks=True)
+            out.update(i2t_r=np.array(r), i2t_ranks=ranks, i2t_top1=top1)
+        ri, (ranks_i, top1_i), _ = eval_utils.t2i(images, cap, data, measure='cosine', return_ranks=True, useGenSent=(cpi == 1))
+        out.update(t2i_r=np.array(ri), t2i_ranks=ranks_i, t2i_top1=top1_i)
+        save(name, images=images, captions=cap.astype(np.float32), cpi=np.int64(cpi), **out)
+
+
 def main():
     torch, models, rewards = install_harness()
     rec = Recorder(torch)
     torch.set_num_threads(4)
+    if '--only-retrieval' in sys.argv:
+        gen_retrieval(torch)
+        return
     if '--only-fc' in sys.argv:
         gen_fc(torch, models, rec)
         return
@@ -663,6 +687,7 @@ def main():
          grad_clip=np.float64(0.1))
     gen_fc(torch, models, rec)
     gen_beam(torch, models, rec)
+    gen_retrieval(torch)
 
 
 if __name__ == '__main__':
