@@ -148,6 +148,9 @@ def main():
     ap.add_argument('--batch', type=int, default=128)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N > 1: 'nccl' (= RCCL over xGMI, the "
+                    "default) or 'gloo' (rehearsal of the multi-process path on a box with fewer GPUs than ranks)")
+    ap.add_argument('--same-device', action='store_true', help='rehearsal: every rank uses cuda:0 (gloo backend only)')
     ap.add_argument('--graphs', action='store_true',
                     help='run on a side stream and replay the sequence engines as HIP graphs (measured SLOWER on '
                          'this stack: 9.5 vs 8.2 ms/step; the default is direct launches on the default stream)')
@@ -160,8 +163,11 @@ def main():
         assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if args.same_device:
+            assert args.backend == 'gloo', '--same-device is a gloo rehearsal (RCCL wants one GPU per rank)'
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl')        # RCCL over xGMI
+        dist.init_process_group(args.backend)  # 'nccl' = RCCL over xGMI
     else:
         torch.cuda.set_device(0)
     dev = torch.device('cuda', local_rank)
