@@ -53,6 +53,10 @@ struct CicGraphScope {
 
 static inline hipStream_t cic_s(cic_stream_t s) { return (hipStream_t)s; }
 
+// side stream of an engine call (core.hip): *side = main when side streams are off or `main` is being captured
+int cic_side_fork(hipStream_t main, hipStream_t* side);
+int cic_side_join(hipStream_t main, hipStream_t side);
+
 // A pointer per decode of a PAIR of decodes that advance in lock step through the same launches
 // (rows [0,B) belong to decode a, rows [B,2B) to decode b; b is unused for a single decode).
 template <typename T>

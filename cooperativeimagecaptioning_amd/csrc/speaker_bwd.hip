@@ -667,6 +667,16 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     // 2. logit layer, batched over time: d_out = dlogits W,  dW += dlogits^T out,  db += colsum
     if (!ps) RUN(gemm_nn(g.dlogits, V1, p->logit_w, H, g.d_out_all, H, T * B, H, V1, false, st));
 
+    // 2b. the logit layer's weight gradient needs only d logits and the saved outputs: it can run on a side stream
+    //     beside the latency-bound BPTT loop (cic_debug_side_stream(1); measured slower than one stream, so the
+    //     fork is a no-op by default and the product simply runs here; not for partial sampling, whose d logits
+    //     are made inside the loop)
+    hipStream_t side = st;
+    if (!ps) {
+        RUN(cic_side_fork(st, &side));
+        RUN(gemm_tn(g.dlogits, V1, w.out_all, H, gr->logit_w, H, V1, H, T * B, true, side));
+        RUN(cic_colsum_f32(g.dlogits, T * B, V1, V1, gr->logit_b, 1, (cic_stream_t)side));
+    }
     // 3. BPTT over the cell + attention (only dh, dc are carried)
     float* dh_in = g.dh_a;
     float* dh_out = g.dh_b;
@@ -752,8 +762,11 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
             }
         }
     }
-    RUN(gemm_tn(g.dlogits, V1, w.out_all, H, gr->logit_w, H, V1, H, T * B, true, st));
-    RUN(cic_colsum_f32(g.dlogits, T * B, V1, V1, gr->logit_b, 1, s));
+    if (ps) {
+        RUN(gemm_tn(g.dlogits, V1, w.out_all, H, gr->logit_w, H, V1, H, T * B, true, st));
+        RUN(cic_colsum_f32(g.dlogits, T * B, V1, V1, gr->logit_b, 1, s));
+    }
+    RUN(cic_side_join(st, side));
     // 4. weight gradients of the recurrent part, batched over time
     RUN(gemm_tn(g.dpre_all, 5 * H, w.x_all, E, gr->i2h_w, E, 5 * H, E, T * B, true, st));
     RUN(gemm_tn(g.dpre_all, 5 * H, w.h_all, H, gr->h2h_w, H, 5 * H, H, T * B, true, st));

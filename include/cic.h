@@ -61,6 +61,8 @@ int cic_debug_set_stamps(unsigned long long* buf);
 int cic_debug_set_attn_stamps(unsigned long long* buf);
 /* diagnostics: 0 turns the K-sliced tail tiles of the large GEMMs off (fixed summation order; A/B timing) */
 int cic_debug_gemm_tail_split(int on);
+/* diagnostics: 1 runs the logit weight-gradient product on a side stream beside the BPTT loop (default 0: measured slower) */
+int cic_debug_side_stream(int on);
 
 /* ---- RNG (replaces torch.rand / nn.Dropout's bernoulli_ draws) ---------------------- */
 /* Philox4x32-10 counter RNG.  u[i] = (r >> 8) * 2^-24 in [0,1), as torch.rand does
