@@ -52,7 +52,9 @@ class SamplerArgs(C.Structure):
                 ('soft', c_ptr), ('ld_soft', C.c_int), ('ps_u', c_ptr), ('ps_prob', C.c_float),
                 ('decoding_constraint', C.c_int), ('step', C.c_int),
                 ('unfinished', c_ptr), ('it_next', c_ptr), ('seq', c_ptr), ('slp', c_ptr),
-                ('stv', c_ptr), ('seq_ld', C.c_int), ('any_unfinished', c_ptr)]
+                ('stv', c_ptr), ('seq_ld', C.c_int), ('any_unfinished', c_ptr),
+                ('emb_w', c_ptr), ('emb_x', c_ptr), ('emb_keep', c_ptr), ('emb_scale', C.c_float), ('emb_dim', C.c_int),
+                ('emb_plain', C.c_int)]
 
 
 class SpeakerDims(C.Structure):

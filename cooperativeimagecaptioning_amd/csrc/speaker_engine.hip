@@ -215,8 +215,9 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
             float* xp = io[0]->xpre + (size_t)t * B * E;
             RUN(gemm_nn_fwd(io[0]->soft_raw + (size_t)(t - 1) * B * V1, V1, p->embed_w, E, xp, E, B, E, V1, false, st));
             RUN(cic_relu_keep_fwd(xp, xk.a, xk.a ? p_drop : 0.f, x.a, (int64_t)B * E, st));
-        } else {
-            // xt = embed(it)                                               (:399)
+        } else if (t == 0 || ps) {
+            // xt = embed(it)                                               (:399); for t >= 1 the sampler launch of the
+            // previous step wrote x[t] (fused embedding)
             RUN(cic_embed_fwd2(p->embed_w,
                                Dual<const int32_t>{w[0].it_all + (size_t)t * B, nb == 2 ? w[1].it_all + (size_t)t * B : nullptr},
                                fc ? Dual<const uint8_t>{nullptr, nullptr} : xk, (xk.a && !fc) ? p_drop : 0.f, x, B, nb, E, st,
@@ -283,6 +284,11 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
             a.it_next = w[q].it_all + (size_t)(t + 1) * B;
             a.seq = io[q]->seq; a.slp = io[q]->slp; a.stv = io[q]->stv; a.seq_ld = T;
             a.any_unfinished = w[q].any_unf;
+            if (!ps && t + 1 < T) {                  // the next step's input row, embedded by the sampler itself
+                const uint8_t* xkn = (!fc && io[q]->x_keep) ? io[q]->x_keep + (size_t)(t + 1) * B * E : nullptr;
+                a.emb_w = p->embed_w; a.emb_x = w[q].x_all + (size_t)(t + 1) * B * E; a.emb_keep = xkn;
+                a.emb_scale = 1.0f / (1.0f - p_drop); a.emb_dim = E; a.emb_plain = fc ? 1 : 0;
+            }
         }
         CIC_PROF(CIC_PROF_SAMPLER, st, rc = cic_logsoftmax_sample2(&sa[0], nb == 2 ? &sa[1] : nullptr, st));
         if (rc) return rc;

@@ -396,7 +396,7 @@ __device__ __forceinline__ ArgMax wave_argmax(ArgMax a) {
 }
 constexpr int SNW = 16;   // waves per row workgroup of the sampler kernel
 __device__ __forceinline__ float block_sum(float v, float* sh) {
-    v = wave_sum(v);
+    v = wave_sum_fast(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -406,7 +406,7 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
     return r;
 }
 __device__ __forceinline__ float block_max(float v, float* sh) {
-    v = wave_max(v);
+    v = wave_max_fast(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -414,6 +414,22 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
 #pragma unroll
     for (int w = 1; w < SNW; ++w) r = fmaxf(r, sh[w]);
     return r;
+}
+// three block sums for the price of one barrier round (sh3: 3 * SNW floats)
+__device__ __forceinline__ void block_sum3(float& a, float& b, float& c, float* sh3) {
+    a = wave_sum_fast(a);
+    b = wave_sum_fast(b);
+    c = wave_sum_fast(c);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        sh3[w] = a; sh3[SNW + w] = b; sh3[2 * SNW + w] = c;
+    }
+    __syncthreads();
+    float ra = 0.f, rb = 0.f, rc = 0.f;
+#pragma unroll
+    for (int w = 0; w < SNW; ++w) { ra += sh3[w]; rb += sh3[SNW + w]; rc += sh3[2 * SNW + w]; }
+    a = ra; b = rb; c = rc;
 }
 __device__ __forceinline__ ArgMax block_argmax(ArgMax a, float* shv, int* shi) {
     a = wave_argmax(a);
@@ -439,6 +455,7 @@ __global__ __launch_bounds__(SNW * 64) void logsoftmax_sample_kernel(cic_sampler
     constexpr int NT = SNW * 64;
     __shared__ float shf[SNW];
     __shared__ int shi[SNW];
+    __shared__ float sh3[3 * SNW];
     // rows [0, a0.B) run the sampler of decode a, rows beyond it that of decode b (own mode, noise and outputs):
     // a uniform, field-wise select of the kernel arguments
     const bool second = (int)blockIdx.x >= a0.B;
@@ -451,6 +468,21 @@ __global__ __launch_bounds__(SNW * 64) void logsoftmax_sample_kernel(cic_sampler
 
     float x[RV][4];
     const int cons = (a.decoding_constraint && a.step >= 2) ? a.seq[(size_t)b * a.seq_ld + (a.step - 2)] : -1;
+    // the noise row is needed only after the log-softmax: its loads go out together with the logits'
+    const float* urow = a.U ? a.U + (size_t)b * a.ldu : nullptr;
+    const bool ss_on = a.mode == CIC_SAMPLE_TEACHER && a.ss_u && a.ss_prob > 0.f;
+    const bool gumbel_mode = a.mode == CIC_SAMPLE_GUMBEL_ST || a.mode == CIC_SAMPLE_GUMBEL_PS;
+    const bool use_noise = a.mode == CIC_SAMPLE_TEACHER
+                               ? (ss_on && !a.ss_pick)
+                               : ((a.mode != CIC_SAMPLE_GREEDY && a.mode != CIC_SAMPLE_NONE) && !(a.pick && !gumbel_mode));
+    float un[RV][4];
+#pragma unroll
+    for (int r = 0; r < RV; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int col = 4 * (tid + NT * r) + e;
+            un[r][e] = (use_noise && (tid + NT * r) < nq && col < V1) ? urow[col] : 0.5f;
+        }
     float mx = -INFINITY;
 #pragma unroll
     for (int r = 0; r < RV; ++r) {
@@ -502,12 +534,6 @@ __global__ __launch_bounds__(SNW * 64) void logsoftmax_sample_kernel(cic_sampler
     if (a.mode == CIC_SAMPLE_NONE) return;
 
     // ---- choose the token -------------------------------------------------------------
-    const float* urow = a.U ? a.U + (size_t)b * a.ldu : nullptr;
-    const bool ss_on = a.mode == CIC_SAMPLE_TEACHER && a.ss_u && a.ss_prob > 0.f;
-    const bool gumbel_mode = a.mode == CIC_SAMPLE_GUMBEL_ST || a.mode == CIC_SAMPLE_GUMBEL_PS;
-    const bool use_noise = a.mode == CIC_SAMPLE_TEACHER
-                               ? (ss_on && !a.ss_pick)
-                               : ((a.mode != CIC_SAMPLE_GREEDY) && !(a.pick && !gumbel_mode));
     const float inv_t = 1.0f / a.temp;
     ArgMax best = {-INFINITY, 0x7fffffff};
     float z[RV][4];
@@ -522,10 +548,10 @@ __global__ __launch_bounds__(SNW * 64) void logsoftmax_sample_kernel(cic_sampler
                 if (a.mode == CIC_SAMPLE_GREEDY) {
                     zz = x[r][e];
                 } else if (gumbel_mode) {
-                    zz = (x[r][e] + gumbel_from_u(urow[col])) * inv_t;           // gumbel.py:13-15
+                    zz = (x[r][e] + gumbel_from_u(un[r][e])) * inv_t;            // gumbel.py:13-15
                 } else {   // multinomial flavours: Gumbel-max draw from softmax(logp / temp)
                     zz = x[r][e] * inv_t;
-                    if (use_noise) zz += gumbel_from_u(urow[col]);
+                    if (use_noise) zz += gumbel_from_u(un[r][e]);
                 }
             }
             z[r][e] = zz;
@@ -551,42 +577,50 @@ __global__ __launch_bounds__(SNW * 64) void logsoftmax_sample_kernel(cic_sampler
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (4 * (tid + NT * r) + e == it) slp_part = x[r][e];
-    const float slp = block_sum(slp_part, shf);
+    float slp;
     float v = 1.0f;
     float zm = 0.f, s2 = 1.f;
-    if (gumbel_mode || a.mode == CIC_SAMPLE_MULTINOMIAL_ST) {
-        // y = softmax(z) with z = (logp+g)/tau  (gumbel)  or  logp/tau  (multinomial.py:10-15)
+    if (gumbel_mode) {
+        // y = softmax(z), z = (logp+g)/tau, max(z) = the arg-max value: slp, sum exp(z - zm) and z_it in ONE round
+        zm = best.v;
+        float zi = 0.f;
+        s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < RV; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s2 += __expf(z[r][e] - zm);
+                if (4 * (tid + NT * r) + e == it) zi = z[r][e];
+            }
+        block_sum3(slp_part, s2, zi, sh3);
+        slp = slp_part;
+        const float y = __expf(zi - zm) / s2;
+        v = (1.0f - y) + y;    // (y_hard - y).detach() + y at the arg-max entry, gumbel.py:28
+    } else if (a.mode == CIC_SAMPLE_MULTINOMIAL_ST) {
+        // y = softmax(logp/tau)  (multinomial.py:10-15)
+        slp = block_sum(slp_part, shf);
         float zi = -INFINITY;
         s2 = 0.f;
-        if (gumbel_mode) {
-            zm = best.v;
+        float m2 = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < RV; ++r)
+        for (int r = 0; r < RV; ++r)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    s2 += __expf(z[r][e] - zm);
-                    if (4 * (tid + NT * r) + e == it) zi = z[r][e];
-                }
-        } else {
-            float m2 = -INFINITY;
+            for (int e = 0; e < 4; ++e) m2 = fmaxf(m2, x[r][e] * inv_t);
+        zm = block_max(m2, shf);
 #pragma unroll
-            for (int r = 0; r < RV; ++r)
+        for (int r = 0; r < RV; ++r)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) m2 = fmaxf(m2, x[r][e] * inv_t);
-            zm = block_max(m2, shf);
-#pragma unroll
-            for (int r = 0; r < RV; ++r)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float t = x[r][e] * inv_t;
-                    s2 += __expf(t - zm);
-                    if (4 * (tid + NT * r) + e == it) zi = t;
-                }
-        }
+            for (int e = 0; e < 4; ++e) {
+                const float t = x[r][e] * inv_t;
+                s2 += __expf(t - zm);
+                if (4 * (tid + NT * r) + e == it) zi = t;
+            }
         s2 = block_sum(s2, shf);
         zi = block_max(zi, shf);
         const float y = __expf(zi - zm) / s2;
-        v = (1.0f - y) + y;    // (y_hard - y).detach() + y at the arg-max entry, gumbel.py:28
+        v = (1.0f - y) + y;
+    } else {
+        slp = block_sum(slp_part, shf);
     }
     if (a.soft) {
         // partial sampling (gumbel_softmax.py:30-41, multinomial_soft.py:23-33): rows drawn with u < prob get the
@@ -608,6 +642,25 @@ __global__ __launch_bounds__(SNW * 64) void logsoftmax_sample_kernel(cic_sampler
                 }
             }
         v = block_sum(v_it, shf);
+    }
+
+    // ---- next step's input: xt = dropout(relu(embed(it))) (AttModel.py:74-76,399), un-masked `it`, fused here so that
+    // the decode loop needs no embedding launch after its first step
+    if (a.emb_x) {
+        const int tok = it_feed >= 0 ? it_feed : it;
+        const int E4 = a.emb_dim >> 2;
+        if (tid < E4) {
+            f32x4 ev = reinterpret_cast<const f32x4*>(a.emb_w + (size_t)tok * a.emb_dim)[tid];
+            uint32_t kp = 0x01010101u;
+            if (a.emb_keep) kp = *reinterpret_cast<const uint32_t*>(a.emb_keep + (size_t)b * a.emb_dim + 4 * tid);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float kf = (float)((kp >> (8 * e)) & 0xffu);
+                const float r = a.emb_plain ? ev[e] : fmaxf(ev[e], 0.f);
+                ev[e] = a.emb_keep ? r * (kf * a.emb_scale) : r;
+            }
+            reinterpret_cast<f32x4*>(a.emb_x + (size_t)b * a.emb_dim)[tid] = ev;
+        }
     }
 
     // ---- EOS bookkeeping (AttModel.py:401-434) -----------------------------------------
@@ -836,6 +889,7 @@ int cic_logsoftmax_sample2(const cic_sampler_args* a, const cic_sampler_args* b,
 
 static int check_sampler_args(const cic_sampler_args* a) {
     CIC_REQUIRE(a && a->logits && a->B > 0 && a->V1 > 0 && a->ld >= a->V1);
+    CIC_REQUIRE(!a->emb_x || (a->emb_w && a->mode != CIC_SAMPLE_NONE && a->emb_dim > 0 && (a->emb_dim & 3) == 0 && a->emb_dim <= 4096));
     if (a->mode != CIC_SAMPLE_NONE) {
         CIC_REQUIRE(a->unfinished && a->it_next && a->seq && a->slp && a->any_unfinished && a->step >= 1);
         CIC_REQUIRE(a->temp > 0.f);

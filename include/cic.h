@@ -175,6 +175,15 @@ typedef struct {
     float* stv;           /* [B, seq_ld] out (ST modes, may be NULL): straight-through value */
     int seq_ld;
     int32_t* any_unfinished; /* [seq_length+1] zero-initialised flags, entry step is OR-ed */
+    /* optional fused embedding of the chosen (un-masked) token = the next core step's input (AttModel.py:399):
+     * emb_x[b,:] = dropout(relu(emb_w[it])) with keep mask emb_keep[b,:] (NULL: no dropout); emb_plain: no ReLU.
+     * emb_dim % 4 == 0 and emb_dim <= 4096.  emb_x == NULL: not fused. */
+    const float* emb_w;
+    float* emb_x;
+    const uint8_t* emb_keep;
+    float emb_scale;
+    int emb_dim;
+    int emb_plain;
 } cic_sampler_args;
 /* logit bias/GEMM output -> F.log_softmax + sampling + EOS bookkeeping,
  * models/AttModel.py:328-365,401-434,438-444. */
