@@ -125,10 +125,21 @@ class AlternatingJointModel(nn.Module):
         oor = self.only_one_retrieval
         spk_grad = any(p.requires_grad for p in cg.parameters()) and torch.is_grad_enabled()
         lst_grad = vse is not None and any(p.requires_grad for p in vse.parameters()) and torch.is_grad_enabled()
-        use_att = att_feats is not None
-        if not use_att:
-            raise NotImplementedError("caption_model 'fc' (no attention features) is plumbing-only in the reference "
-                                      "and not on the MI355X path")
+        from .FCModel import FCModel
+        if isinstance(cg, FCModel):
+            # BASELINE configs[0]: the fc-feature speaker.  Its sample() returns (seq, logprobs) only, so the reference
+            # can drive it with the MLE / VSE terms (and REINFORCE); the MLE + VSE terms are what run here.
+            if self.retrieval_reward_weight > 0 or self.cider_optimization:
+                raise NotImplementedError("caption_model 'fc': only the MLE and VSE terms are on the MI355X path")
+            loss = None
+            if self.caption_loss_weight > 0:                          # ce_loss :196-207
+                loss = self.caption_loss_weight * cg(fc_feats, att_feats, att_masks, seq, masks)
+                self._loss['loss_cap'] = cg._loss['xe']
+            if self.vse_loss_weight > 0:                              # vse_loss :209-224
+                lv = vse(fc_feats, att_feats, seq, masks, only_one_retrieval=oor)
+                self._loss['loss_vse'] = lv.detach()
+                loss = self.vse_loss_weight * lv if loss is None else loss + self.vse_loss_weight * lv
+            return loss if loss is not None else self._zero_loss(dev)
         B = fc_feats.shape[0]
         T = cg.seq_length
         terms = []          # (weight, device scalar)
@@ -244,7 +255,7 @@ class AlternatingJointModel(nn.Module):
             bwd_steps.append(bwd_speaker)
 
         if not terms:
-            return torch.zeros((), device=dev)
+            return self._zero_loss(dev)
         loss = sum(w * t[0] for w, t in terms)
         anchor = next((p for p in self.parameters() if p.requires_grad), None)
         if anchor is None or not torch.is_grad_enabled() or not bwd_steps:
@@ -281,12 +292,21 @@ class AlternatingJointModel(nn.Module):
         finally:
             self.setLossFlages(VSEWeight=oldVSE, MLEWeight=oldMLE, ciderFlag=oldCider, DISCWeight=oldDISC)
 
+    def _zero_loss(self, device):
+        """A zero loss the caller can still .backward() (the reference's `0 * loss` keeps its grad_fn and yields zero
+        gradients, e.g. the listener turn with vse_loss_weight 0)."""
+        z = torch.zeros((), device=device)
+        anchor = next((p for p in self.parameters() if p.requires_grad), None)
+        if anchor is None or not torch.is_grad_enabled():
+            return z
+        return EngineLoss.apply(z, anchor, lambda go: None)
+
     def _listener_on_generated(self, fc_feats, gen):
         """Listener turn: VSE loss on sampled captions fed as plain indices (:539-551)."""
         vse = self.vse
         vw = self.vse_loss_weight
         if not vw > 0:
-            return torch.zeros((), device=fc_feats.device)
+            return self._zero_loss(fc_feats.device)
         gen.stv = None                                               # plain index input, no straight-through values
         res = vse.run(fc_feats, decode=gen, only_one_retrieval=self.only_one_retrieval, slot=2)
         self._loss['loss_vse'] = res.loss_sum.detach()[0]
