@@ -15,6 +15,8 @@
 
 namespace {
 
+int g_gru_fused = 1;   // cic_debug_gru_fused(0): GEMM + cell launches per step (A/B measurement)
+
 // ---- token preparation -----------------------------------------------------------------
 // generated captions: tokens = [<bos>, seq[:, 0:L]], lens from masks [1,1,(seq>0)[:, :L-1]]
 // (models/AlternatingJointModel.py:353-370)
@@ -105,6 +107,124 @@ __global__ __launch_bounds__(256) void gru_cell_fwd_kernel(const float* __restri
     }
     reinterpret_cast<f32x4*>(h_new)[idx] = hn;
 }
+
+// ---- fused GRU step (flagship width J = 8*GPS*KS = 1024) ---------------------------------------------------------
+// gh = h W_hh^T + b_hh and the gate arithmetic of one time step in ONE launch.  A workgroup owns a 32-row strip of
+// the batch and one 32-wide tile j of hidden units: it computes the three gate tiles (r, z, n: weight rows j, J+j,
+// 2J+j) with the K range split over its KS waves (MFMA A fragments of the strip's h rows stay in registers, the B
+// fragments of the next gate are in flight under the current gate's MFMA chain), sums the KS partial tiles through
+// LDS and applies the cell to the outputs it holds: the pre-activations never make a round trip through memory
+// before the cell, and a step is one launch instead of a GEMM + a cell kernel.  gh is still written (the backward
+// pass reads it).  Step 0 (h = 0) skips the products: gh = b_hh.
+template <int GPS, int KS>
+__global__ __launch_bounds__(KS * 64) void gru_step_fused_kernel(const float* __restrict__ h, const float* __restrict__ W,
+                                                             const float* __restrict__ b_hh, const float* __restrict__ gi,
+                                                             const int32_t* __restrict__ len, int t, float* __restrict__ gh_out,
+                                                             float* __restrict__ h_new, int B, int J, int h_is_zero) {
+    static_assert(16 % KS == 0, "accumulator registers are dealt evenly to the waves");
+    constexpr int EPW = 16 / KS;
+    constexpr int CH = 4;
+    __shared__ float red[2 * KS * 16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
+    const int hh = lane >> 5, r = lane & 31;
+    const int tiles_j = J / 32;
+    const int strip = blockIdx.x / tiles_j, jt = blockIdx.x % tiles_j;   // blockIdx % 8 == jt % 8: a weight tile's readers share an XCD
+    const int m0 = strip * 32;
+    const int m = m0 + r;
+    const bool mok = m < B;
+    const int mc = mok ? m : B - 1;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    // epilogue operands of the outputs this wave finishes: issued first, used last
+    float gir[EPW], giz[EPW], gin[EPW], hp[EPW];
+    int row[EPW], ln[EPW];
+    const int col = jt * 32 + r;
+#pragma unroll
+    for (int q = 0; q < EPW; ++q) {
+        const int e = ks + KS * q;
+        const int mm = m0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        row[q] = mm;
+        const int mcl = mm < B ? mm : B - 1;
+        gir[q] = gi[(size_t)mcl * 3 * J + col];
+        giz[q] = gi[(size_t)mcl * 3 * J + J + col];
+        gin[q] = gi[(size_t)mcl * 3 * J + 2 * J + col];
+        hp[q] = h[(size_t)mcl * J + col];
+        ln[q] = len[mcl];
+    }
+    float ghv[3][EPW];
+    if (!h_is_zero) {
+        f32x4 af[GPS];
+#pragma unroll
+        for (int i = 0; i < GPS; ++i) {
+            const int k = 8 * (ks * GPS + i) + 4 * hh;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(h + (size_t)mc * J + k);
+            af[i] = mok ? a : z4;
+        }
+        f32x4 bf[GPS];
+        auto load_chunk = [&](int c, int g) {
+            const int gg = g < 3 ? g : 2;
+            const float* wrow = W + ((size_t)gg * J + col) * J;
+#pragma unroll
+            for (int ii = 0; ii < CH; ++ii) {
+                const int i = c * CH + ii;
+                const int k = 8 * (ks * GPS + i) + 4 * hh;
+                bf[i] = *reinterpret_cast<const f32x4*>(wrow + k);
+            }
+        };
+#pragma unroll
+        for (int c = 0; c < GPS / CH; ++c) load_chunk(c, 0);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int c = 0; c < GPS / CH; ++c) {
+#pragma unroll
+                for (int ii = 0; ii < CH; ++ii)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c * CH + ii][s], bf[c * CH + ii][s], acc, 0, 0, 0);
+                if (g < 2) load_chunk(c, g + 1);           // the same chunk of the next gate's weight tile
+            }
+            float* rb = red + (g & 1) * (KS * 16 * 64);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) rb[(ks * 16 + e) * 64 + lane] = acc[e];
+            __syncthreads();
+            const float bv = b_hh[g * J + col];
+#pragma unroll
+            for (int q = 0; q < EPW; ++q) {
+                const int e = ks + KS * q;
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < KS; ++w) v += rb[(w * 16 + e) * 64 + lane];
+                ghv[g][q] = v + bv;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int q = 0; q < EPW; ++q) ghv[g][q] = b_hh[g * J + col];
+    }
+    // the cell (torch.nn.GRU gate order r, z, n) on the outputs this wave holds; rows past their caption's length keep h
+#pragma unroll
+    for (int q = 0; q < EPW; ++q) {
+        if (row[q] >= B) continue;
+        const size_t o = (size_t)row[q] * 3 * J + col;
+        gh_out[o] = ghv[0][q];
+        gh_out[o + J] = ghv[1][q];
+        gh_out[o + 2 * J] = ghv[2][q];
+        float hn = hp[q];
+        if (t < ln[q]) {
+            const float rr = fast_sigmoid(gir[q] + ghv[0][q]);
+            const float zz = fast_sigmoid(giz[q] + ghv[1][q]);
+            const float nn = fast_tanh(gin[q] + rr * ghv[2][q]);
+            hn = (1.0f - zz) * nn + zz * hp[q];
+        }
+        h_new[(size_t)row[q] * J + col] = hn;
+    }
+}
+
 // dh (in/out): gradient w.r.t. h_{t+1} in, w.r.t. the direct h_t path out (the W_hh path is added by a GEMM)
 __global__ __launch_bounds__(256) void gru_cell_bwd_kernel(const float* __restrict__ gi, const float* __restrict__ gh,
                                                            const float* __restrict__ h, const int32_t* __restrict__ len,
@@ -378,6 +498,11 @@ int check_ldims(const cic_listener_dims& d) {
 
 }  // namespace
 
+extern "C" int cic_debug_gru_fused(int on) {
+    g_gru_fused = on;
+    return 0;
+}
+
 extern "C" size_t cic_listener_ws_bytes(const cic_listener_dims* d) {
     if (!d) return 0;
     return lst_carve(*d, nullptr).bytes;
@@ -459,9 +584,16 @@ static int listener_fwd_impl(const cic_listener_dims* dp, const cic_listener_par
     }
     RUN(gemm_nt(w.x_emb, E, p->w_ih, E, w.gi_all, 3 * J, Lp * B, 3 * J, E, p->b_ih, false, false, st));
     CIC_HIP(hipMemsetAsync(w.h_all, 0, sizeof(float) * B * J, st));
+    const bool fused_step = g_gru_fused && J == 1024;       // the flagship width: one launch per step (see the kernel)
     for (int t = 0; t < Lp; ++t) {
         float* h = w.h_all + (size_t)t * B * J;
         float* gh = w.gh_all + (size_t)t * B * 3 * J;
+        if (fused_step) {
+            hipLaunchKernelGGL((gru_step_fused_kernel<16, 8>), dim3(cic_cdiv(B, 32) * (J / 32)), dim3(512), 0, st, h, p->w_hh,
+                               p->b_hh, w.gi_all + (size_t)t * B * 3 * J, w.len, t, gh, h + (size_t)B * J, B, J, t == 0 ? 1 : 0);
+            CIC_LAUNCH_CHECK();
+            continue;
+        }
         RUN(gemm_nt(h, J, p->w_hh, J, gh, 3 * J, B, 3 * J, J, p->b_hh, false, false, st));
         hipLaunchKernelGGL(gru_cell_fwd_kernel, dim3(cic_cdiv(B * (J / 4), 256)), dim3(256), 0, st,
                            w.gi_all + (size_t)t * B * 3 * J, gh, h, w.len, t, h + (size_t)B * J, B, J);

@@ -63,6 +63,8 @@ int cic_debug_set_attn_stamps(unsigned long long* buf);
 int cic_debug_gemm_tail_split(int on);
 /* diagnostics: 1 runs the logit weight-gradient product on a side stream beside the BPTT loop (default 0: measured slower) */
 int cic_debug_side_stream(int on);
+/* diagnostics: 0 runs every listener GRU step as a GEMM launch + a cell launch instead of the fused step kernel */
+int cic_debug_gru_fused(int on);
 
 /* ---- RNG (replaces torch.rand / nn.Dropout's bernoulli_ draws) ---------------------- */
 /* Philox4x32-10 counter RNG.  u[i] = (r >> 8) * 2^-24 in [0,1), as torch.rand does
