@@ -64,6 +64,8 @@ def build_parser():
     p.add_argument('--synthetic', type=int, default=0, help='1: COCO-shaped synthetic batches (no dataset needed)')
     p.add_argument('--max_iterations', type=int, default=-1, help='stop after this many iterations (-1: never)')
     p.add_argument('--seed', type=int, default=0)
+    p.add_argument('--prefetch', type=int, default=1, help='1: upload the next batch on a copy stream while the '
+                                                            'current step computes (prefetch.PrefetchLoader)')
     return p
 
 

@@ -115,6 +115,9 @@ def train(opt, loader=None):
         loader = synthetic.SyntheticLoader(opt, seed=1234 + rank)
     else:
         opt.vocab_size, opt.seq_length = loader.vocab_size, loader.seq_length
+    if getattr(opt, 'prefetch', 1):
+        from .prefetch import PrefetchLoader          # the next batch is uploaded on a copy stream under this step's compute
+        loader = PrefetchLoader(loader, device, 'train')
     torch.manual_seed(opt.seed)                               # same initial weights on every rank
     model = models.AlternatingJointModel(opt).to(device).train()
     model.caption_generator.noise.manual_seed(opt.seed * 1000 + rank)
@@ -143,6 +146,8 @@ def train(opt, loader=None):
             loss = model(fc_feats, labels, masks, data, att_feats, att_masks)
         loss.backward()
         update_optimizer(optimizer_dict, optimizer, opt)
+        if hasattr(loader, 'prefetch'):
+            loader.prefetch()                                   # batch i+1 travels to HBM while step i computes
         train_loss = float(loss.detach())                       # the step's one host sync (train.py:533-535)
         end = time.time()
         if rank == 0:
@@ -159,6 +164,8 @@ def train(opt, loader=None):
             checkpoint(opt, model, optimizer_dict, iteration, epoch, loss_history)
         if (epoch >= opt.max_epochs != -1) or (0 < opt.max_iterations <= iteration):
             break
+    if hasattr(loader, 'close'):
+        loader.close()
     return model
 
 

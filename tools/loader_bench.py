@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Input pipeline: the joint step fed from HOST batches (the loader contract of dataloader.py:171-245:
+numpy arrays, 37.7 MB per B = 128 batch) with the synchronous per-iteration copy of the reference's trainer
+(train.py:162-178) vs prefetch.PrefetchLoader (the next batch uploaded on a copy stream under the current step)."""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cooperativeimagecaptioning_amd import models, optimizer as optim, synthetic, train as T
+from cooperativeimagecaptioning_amd.misc import rewards
+from cooperativeimagecaptioning_amd.prefetch import PrefetchLoader
+
+
+class FixedHostLoader:
+    """Four pre-generated host batches served round robin (the cost under test is the hand-over, not numpy's RNG)."""
+
+    def __init__(self, opt):
+        gen = synthetic.SyntheticLoader(opt, seed=1)
+        self.batches = [gen.get_batch('train') for _ in range(4)]
+        self.n = 0
+        self.vocab_size, self.seq_length = opt.vocab_size, opt.seq_length
+
+    def get_batch(self, split):
+        self.n += 1
+        return self.batches[self.n % 4]
+
+
+def main():
+    opt = synthetic.default_opt(batch_size=128)
+    torch.manual_seed(0)
+    rewards.init_scorer('corpus')
+    model = models.AlternatingJointModel(opt).cuda().train()
+    od = optim.load_optimizer(model, opt)
+    dev = torch.device('cuda', 0)
+
+    def run(loader, n=30):
+        for i in range(n + 5):
+            if i == 5:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            data = loader.get_batch('train')
+            fc, att, am, labels, masks = T.load_data(data, opt, dev)
+            optim.zeroing_optimizer(opt, od, od['speaker'])
+            loss = model(fc, labels, masks, data, att, am, is_alternating=True, alternating_turn='speaker')
+            loss.backward()
+            optim.update_optimizer(od, od['speaker'], opt)
+            if hasattr(loader, 'prefetch'):
+                loader.prefetch()
+            float(loss.detach())                 # the trainer's per-iteration host sync (train.py:533-535)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+    t_sync = run(FixedHostLoader(opt))
+    pf = PrefetchLoader(FixedHostLoader(opt), dev)
+    t_pf = run(pf)
+    pf.close()
+    print(f'host batches, synchronous copy per iteration: {t_sync * 1e3:.2f} ms/iteration = {128 / t_sync:.0f} images/s')
+    print(f'host batches through PrefetchLoader:          {t_pf * 1e3:.2f} ms/iteration = {128 / t_pf:.0f} images/s')
+
+
+if __name__ == '__main__':
+    main()
