@@ -101,11 +101,12 @@ static inline int gemm_nn2(const float* A1, int lda1, const float* B1, int ldb1,
 }
 // C[M,N] = At[K,M]^T Bm[K,N] (+C)                 — dW = dY^T X
 static inline int gemm_tn(const float* At, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K,
-                          bool accumulate, hipStream_t st) {
+                          bool accumulate, hipStream_t st, float* bias_grad = nullptr, float* bias_grad2 = nullptr) {
     cic_gemm_args g = {};
     g.M = M; g.N = N; g.K = K;
     g.A = At; g.lda = lda; g.a_kc = 0;
     g.B = Bm; g.ldb = ldb; g.b_kc = 0;
     g.C = C; g.ldc = ldc; g.accumulate = accumulate; g.sum_order_free = 1;   // weight gradients
+    g.colsum_A = bias_grad; g.colsum_A2 = bias_grad2;                        // db += colsum(dY), a by-product of the A tiles
     return cic_gemm_f32(&g, st);
 }

@@ -145,6 +145,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(cic_gemm_args g, int 
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     f32x4 ra[TA::NV], rb[TB::NV];
+    const bool do_colsum = g.colsum_A != nullptr && n0 == 0;
+    float csum = 0.f;
 #pragma unroll 1
     for (int pair = 0; pair < 2; ++pair) {
         const float* A = pair ? g.A2 : g.A;
@@ -165,6 +167,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(cic_gemm_args g, int 
             TA::store(ra, LA, tid);
             TB::store(rb, LB, tid);
             __syncthreads();
+            if (!KCA && do_colsum && tid < BM) {
+                // bias-gradient by-product (dW = dY^T X: the column sums of dY are db): this K-tile of op(A) is in LDS
+                // as [k][rows]; the workgroups of the first tile column add it up (out-of-range k / rows hold zeros)
+#pragma unroll 8
+                for (int kk = 0; kk < BK; ++kk) csum += LA[kk * (BM + 4) + tid];
+            }
             if (kt + 1 < nk) {   // next tile in flight under the MFMAs
                 TA::load(ra, A, lda, m0, g.M, (kt + 1) * BK, K, tid);
                 TB::load(rb, B, ldb, n0, g.N, (kt + 1) * BK, K, tid);
@@ -187,6 +195,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(cic_gemm_args g, int 
         }
     }
 
+    if (!KCA && do_colsum && tid < BM && m0 + tid < g.M) {
+        atomicAdd(g.colsum_A + m0 + tid, csum);
+        if (g.colsum_A2) atomicAdd(g.colsum_A2 + m0 + tid, csum);
+    }
     // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -864,6 +876,16 @@ extern "C" int cic_gemm_f32(const cic_gemm_args* a, cic_stream_t s) {
     if (g.K2 > 0)
         vec = vec && operand_vec_ok(g.A2, g.lda2, g.a_kc, g.M, g.K2) && operand_vec_ok(g.B2, g.ldb2, g.b_kc, g.N, g.K2);
     const int64_t big_tiles = (int64_t)cic_cdiv(g.M, 128) * cic_cdiv(g.N, 128);
+    if (g.colsum_A) {
+        CIC_REQUIRE(!g.a_kc && g.K2 == 0);      // the column sums of a [K, M] operand (dW = dY^T X)
+        if (g.M <= 128) {                       // the skinny kernels do not carry the by-product: a launch of its own
+            cic_gemm_args g2 = g;
+            g2.colsum_A = nullptr; g2.colsum_A2 = nullptr;
+            if (int rc = cic_colsum_f32(g.A, g.K, g.M, g.lda, g.colsum_A, 1, s)) return rc;
+            if (g.colsum_A2) { if (int rc = cic_colsum_f32(g.A, g.K, g.M, g.lda, g.colsum_A2, 1, s)) return rc; }
+            return cic_gemm_f32(&g2, s);
+        }
+    }
     if (g.rows_blk > 0) {
         CIC_REQUIRE(g.a_kc && (g.rows_blk & 31) == 0 && g.M > g.rows_blk && g.M <= 2 * g.rows_blk && g.A_b && g.C_b);
         CIC_REQUIRE(g.K2 == 0 || g.A2_b);

@@ -646,8 +646,7 @@ static int listener_bwd_impl(const cic_listener_dims* dp, const cic_listener_par
         hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(B), dim3(256), 0, st, w.img_lin, w.nrm_img, w.d_img, w.d_lin, J,
                            d.use_abs, !d.no_imgnorm);
         CIC_LAUNCH_CHECK();
-        RUN(gemm_tn(w.d_lin, J, io->fc_feats, d.F, g->img_fc_w, d.F, J, d.F, B, true, st));
-        RUN(cic_colsum_f32(w.d_lin, B, J, J, g->img_fc_b, 1, s));
+        RUN(gemm_tn(w.d_lin, J, io->fc_feats, d.F, g->img_fc_w, d.F, J, d.F, B, true, st, g->img_fc_b));
     }
     // text branch: l2norm then GRU BPTT
     hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(B), dim3(256), 0, st, d.pool ? w.pooled : w.h_all + (size_t)Lp * B * J,
@@ -667,10 +666,8 @@ static int listener_bwd_impl(const cic_listener_dims* dp, const cic_listener_par
         float* tmp = dh; dh = dh2; dh2 = tmp;
     }
     if (g) {
-        RUN(gemm_tn(w.dgh_all, 3 * J, w.h_all, J, g->w_hh, J, 3 * J, J, Lp * B, true, st));
-        RUN(cic_colsum_f32(w.dgh_all, Lp * B, 3 * J, 3 * J, g->b_hh, 1, s));
-        RUN(gemm_tn(w.dgi_all, 3 * J, w.x_emb, E, g->w_ih, E, 3 * J, E, Lp * B, true, st));
-        RUN(cic_colsum_f32(w.dgi_all, Lp * B, 3 * J, 3 * J, g->b_ih, 1, s));
+        RUN(gemm_tn(w.dgh_all, 3 * J, w.h_all, J, g->w_hh, J, 3 * J, J, Lp * B, true, st, g->b_hh));
+        RUN(gemm_tn(w.dgi_all, 3 * J, w.x_emb, E, g->w_ih, E, 3 * J, E, Lp * B, true, st, g->b_ih));
     }
     if ((g && g->embed_w) || bio->d_onehot) {
         // dx_emb = dgi W_ih            [Lp*B, 3J] x [3J, E]

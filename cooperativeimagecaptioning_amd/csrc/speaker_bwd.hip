@@ -674,8 +674,7 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     hipStream_t side = st;
     if (!ps) {
         RUN(cic_side_fork(st, &side));
-        RUN(gemm_tn(g.dlogits, V1, w.out_all, H, gr->logit_w, H, V1, H, T * B, true, side));
-        RUN(cic_colsum_f32(g.dlogits, T * B, V1, V1, gr->logit_b, 1, (cic_stream_t)side));
+        RUN(gemm_tn(g.dlogits, V1, w.out_all, H, gr->logit_w, H, V1, H, T * B, true, side, gr->logit_b));
     }
     // 3. BPTT over the cell + attention (only dh, dc are carried)
     float* dh_in = g.dh_a;
@@ -763,20 +762,16 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         }
     }
     if (ps) {
-        RUN(gemm_tn(g.dlogits, V1, w.out_all, H, gr->logit_w, H, V1, H, T * B, true, st));
-        RUN(cic_colsum_f32(g.dlogits, T * B, V1, V1, gr->logit_b, 1, s));
+        RUN(gemm_tn(g.dlogits, V1, w.out_all, H, gr->logit_w, H, V1, H, T * B, true, st, gr->logit_b));
     }
     RUN(cic_side_join(st, side));
     // 4. weight gradients of the recurrent part, batched over time
-    RUN(gemm_tn(g.dpre_all, 5 * H, w.x_all, E, gr->i2h_w, E, 5 * H, E, T * B, true, st));
+    // (i2h.bias and h2h.bias receive the same column sums of dpre: one by-product, two targets)
+    RUN(gemm_tn(g.dpre_all, 5 * H, w.x_all, E, gr->i2h_w, E, 5 * H, E, T * B, true, st, gr->i2h_b, gr->h2h_b));
     RUN(gemm_tn(g.dpre_all, 5 * H, w.h_all, H, gr->h2h_w, H, 5 * H, H, T * B, true, st));
-    RUN(cic_colsum_f32(g.dpre_all, T * B, 5 * H, 5 * H, gr->i2h_b, 1, s));
-    RUN(cic_colsum_f32(g.dpre_all, T * B, 5 * H, 5 * H, gr->h2h_b, 1, s));
     if (!fc) {
-        RUN(gemm_tn(g.dpre_all + 3 * H, 5 * H, w.att_res_all, H, gr->a2c_w, H, 2 * H, H, T * B, true, st));
-        RUN(cic_colsum_f32(g.dpre_all + 3 * H, T * B, 2 * H, 5 * H, gr->a2c_b, 1, s));
-        RUN(gemm_tn(g.d_att_h_all, A, w.h_all, H, gr->h2att_w, H, A, H, T * B, true, st));
-        RUN(cic_colsum_f32(g.d_att_h_all, T * B, A, A, gr->h2att_b, 1, s));
+        RUN(gemm_tn(g.dpre_all + 3 * H, 5 * H, w.att_res_all, H, gr->a2c_w, H, 2 * H, H, T * B, true, st, gr->a2c_b));
+        RUN(gemm_tn(g.d_att_h_all, A, w.h_all, H, gr->h2att_w, H, A, H, T * B, true, st, gr->h2att_b));
     } else {
         // image step (FCModel.py:97-99,121): through the cell with a zero previous state, then d x0 = dpre i2h.W
         const uint8_t* ok_img = io->out_keep;
@@ -822,8 +817,7 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     }
     // ctx2att: d att += d p_att W,  dW += d p_att^T att,  db += colsum
     RUN(gemm_nn(g.d_p_att, A, p->ctx2att_w, H, g.d_att, H, B * K, H, A, true, st));
-    RUN(gemm_tn(g.d_p_att, A, w.att, H, gr->ctx2att_w, H, A, H, B * K, true, st));
-    RUN(cic_colsum_f32(g.d_p_att, B * K, A, A, gr->ctx2att_b, 1, s));
+    RUN(gemm_tn(g.d_p_att, A, w.att, H, gr->ctx2att_w, H, A, H, B * K, true, st, gr->ctx2att_b));
     // att_embed: through dropout and ReLU, then dW += d_pre^T att_raw
     {
         const int64_t n4 = (int64_t)B * K * H / 4;
@@ -831,8 +825,7 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
                            io->att_keep, scale, g.d_attpre, n4);
         CIC_LAUNCH_CHECK();
     }
-    RUN(gemm_tn(g.d_attpre, H, bio->att_raw, D, gr->att_embed_w, D, H, D, B * K, true, st));
-    RUN(cic_colsum_f32(g.d_attpre, B * K, H, H, gr->att_embed_b, 1, s));
+    RUN(gemm_tn(g.d_attpre, H, bio->att_raw, D, gr->att_embed_w, D, H, D, B * K, true, st, gr->att_embed_b));
 #undef RUN
     return 0;
 }

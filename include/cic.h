@@ -102,6 +102,11 @@ typedef struct {
                                      forward activations keep a fixed order. */
     int c_is_zero;                /* != 0 (with sum_order_free, accumulate == 0): C already holds zeros, so partial products may
                                      be added into it */
+    /* Bias-gradient by-product of a weight-gradient product dW = dY^T X (a_kc == 0, A = dY stored [K, M]):
+     * colsum_A[m] += sum_k A[k*lda + m] (and the same into colsum_A2 if not NULL), added with float atomics by the
+     * workgroups of the first tile column while their A tiles are in LDS - no separate column-sum pass over dY. */
+    float* colsum_A;
+    float* colsum_A2;
     int rows_blk;
     const float* A_b;
     const float* A2_b;
