@@ -306,3 +306,83 @@ def test_finalize_len(ops):
         L = dev(torch.zeros(1, dtype=torch.int32))
         ops.finalize_len(dev(torch.tensor(flags, dtype=torch.int32)), 16, L)
         assert int(L) == want
+
+
+# ---- the gradient-product options of cic_gemm_f32: unordered sums (K-sliced tail tiles, K split over workgroups),
+# ---- the bias-gradient by-product, pre-zeroed targets, row blocks of a decode pair
+ORDER_FREE_SHAPES = [
+    # M, N, K, a_kc, b_kc          (what the shape exercises)
+    (2048, 512, 9488, True, False),   # 64 big tiles: every tile K-sliced, C zeroed by the launcher
+    (9488, 512, 2048, False, False),  # 1192 small tiles: no tail
+    (2560, 512, 2048, False, False),  # 80 big tiles, K-sliced + column sums
+    (512, 512, 4608, False, False),   # 64 small tiles < 256: small tiles K-sliced
+    (1000, 300, 1111, False, False),  # ragged everything (scalar loads), tail of partial tiles
+    (300, 1000, 777, True, False),
+    (128, 512, 3072, True, False),    # BPTT dX: K split over workgroups (register-streaming kernel)
+    (96, 1024, 2048, True, False),
+    (4700, 520, 600, False, True),    # 37 x 5 big tiles -> tail 185
+]
+
+
+@pytest.mark.parametrize('M,N,K,a_kc,b_kc', ORDER_FREE_SHAPES)
+@pytest.mark.parametrize('accumulate', [False, True])
+def test_gemm_order_free_and_colsum(ops, M, N, K, a_kc, b_kc, accumulate):
+    import ctypes as C
+    from cooperativeimagecaptioning_amd import _lib
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    A = torch.randn((M, K) if a_kc else (K, M), generator=g)
+    B = torch.randn((N, K) if b_kc else (K, N), generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    ref = (A if a_kc else A.t()).double() @ (B.t() if b_kc else B).double()
+    if accumulate:
+        ref = ref + C0.double()
+    Ad, Bd, Cd = dev(A), dev(B), dev(C0.clone())
+    ga = _lib.GemmArgs()
+    ga.M, ga.N, ga.K = M, N, K
+    ga.A, ga.lda, ga.a_kc = Ad.data_ptr(), A.shape[1], int(a_kc)
+    ga.B, ga.ldb, ga.b_kc = Bd.data_ptr(), B.shape[1], int(b_kc)
+    ga.C, ga.ldc, ga.accumulate, ga.sum_order_free = Cd.data_ptr(), N, int(accumulate), 1
+    cs0 = torch.randn(M, generator=g)
+    cs, cs2 = dev(cs0.clone()), dev(cs0.clone() * 2)
+    if not a_kc:                              # dW = dY^T X: db += colsum(dY) rides along
+        ga.colsum_A, ga.colsum_A2 = cs.data_ptr(), cs2.data_ptr()
+    _lib.check(_lib.lib.cic_gemm_f32(C.byref(ga), None), 'cic_gemm_f32')
+    torch.cuda.synchronize()
+    tol = 3e-6 * np.sqrt(K) * 4
+    np.testing.assert_allclose(Cd.cpu().double().numpy(), ref.numpy(), rtol=1e-5, atol=tol)
+    if not a_kc:
+        want = cs0.double() + A.double().sum(0)
+        np.testing.assert_allclose(cs.cpu().double().numpy(), want.numpy(), rtol=1e-5, atol=tol)
+        np.testing.assert_allclose(cs2.cpu().double().numpy(), (want + cs0.double()).numpy(), rtol=1e-5, atol=tol)
+
+
+@pytest.mark.parametrize('N,K,K2,b_kc', [(512, 512, 0, True), (2560, 512, 512, True), (9488, 512, 0, True), (1024, 512, 0, True)])
+def test_gemm_row_blocks_equal_two_products(ops, N, K, K2, b_kc):
+    """rows_blk (a decode pair in one launch): rows [B, 2B) through the second pointer set, bit-identical to the two
+    separate M = B products (the kernel choice depends on N and K only)."""
+    import ctypes as C
+    from cooperativeimagecaptioning_amd import _lib
+    g = torch.Generator().manual_seed(N + K)
+    Bh = 128
+    A = [dev(torch.randn(Bh, K, generator=g)) for _ in range(2)]
+    A2 = [dev(torch.randn(Bh, K2, generator=g)) for _ in range(2)] if K2 else [None, None]
+    W = dev(torch.randn(N, K, generator=g) * 0.05)
+    W2 = dev(torch.randn(N, K2, generator=g) * 0.05) if K2 else None
+    bias = dev(torch.randn(N, generator=g))
+    sep = [dev(torch.zeros(Bh, N)) for _ in range(2)]
+    for i in range(2):
+        ops.gemm(A[i], W, sep[i], True, True, bias=bias, A2=A2[i], B2=W2)
+    both = [dev(torch.zeros(Bh, N)) for _ in range(2)]
+    ga = _lib.GemmArgs()
+    ga.M, ga.N, ga.K, ga.K2 = 2 * Bh, N, K, K2
+    ga.A, ga.lda, ga.a_kc = A[0].data_ptr(), K, 1
+    ga.B, ga.ldb, ga.b_kc = W.data_ptr(), K, 1
+    if K2:
+        ga.A2, ga.lda2, ga.B2, ga.ldb2 = A2[0].data_ptr(), K2, W2.data_ptr(), K2
+        ga.A2_b = A2[1].data_ptr()
+    ga.C, ga.ldc, ga.bias = both[0].data_ptr(), N, bias.data_ptr()
+    ga.rows_blk, ga.A_b, ga.C_b = Bh, A[1].data_ptr(), both[1].data_ptr()
+    _lib.check(_lib.lib.cic_gemm_f32(C.byref(ga), None), 'cic_gemm_f32')
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert torch.equal(sep[i], both[i])
