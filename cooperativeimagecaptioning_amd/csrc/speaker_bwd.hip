@@ -445,8 +445,9 @@ __global__ __launch_bounds__(1024) void attn_bwd_cols_kernel(const float* __rest
 //   d w_alpha[a]  += sum_{t,b,k} ddot_t[b,k] * tanh(...),   d b_alpha += sum ddot
 // One workgroup per image; the per-step row vectors (att_h_t, d_att_res_t) and scalars of that
 // image are staged once in LDS (dynamic, T*(A+H+2K) floats) and re-used by all K regions.
-template <int NI>
-__global__ __launch_bounds__(256) void attn_bwd_feats_kernel(const float* __restrict__ p_att, const float* __restrict__ att_h_all,
+// NW waves per image: wave w owns regions w, w+NW, ... (12 waves x 3 regions at K = 36)
+template <int NI, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_feats_kernel(const float* __restrict__ p_att, const float* __restrict__ att_h_all,
                                                              const float* __restrict__ d_att_res_all,
                                                              const float* __restrict__ alpha_all,
                                                              const float* __restrict__ ddot_all,
@@ -459,19 +460,19 @@ __global__ __launch_bounds__(256) void attn_bwd_feats_kernel(const float* __rest
     float* s_dr = s_ah + (size_t)T * A;    // [T][H]
     float* s_al = s_dr + (size_t)T * H;    // [T][K]
     float* s_dd = s_al + (size_t)T * K;    // [T][K]
-    float* s_dw = s_dd + (size_t)T * K;    // [4][NI*256] cross-wave reduce of dw_alpha
+    float* s_dw = s_dd + (size_t)T * K;    // [NW][NI*256] cross-wave reduce of dw_alpha
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int A4 = A >> 2, H4 = H >> 2;
-    for (int i = tid; i < T * A4; i += 256) {
+    for (int i = tid; i < T * A4; i += NW * 64) {
         const int t = i / A4, c = i % A4;
         reinterpret_cast<f32x4*>(s_ah)[i] = reinterpret_cast<const f32x4*>(att_h_all + ((size_t)t * B + b) * A)[c];
     }
-    for (int i = tid; i < T * H4; i += 256) {
+    for (int i = tid; i < T * H4; i += NW * 64) {
         const int t = i / H4, c = i % H4;
         reinterpret_cast<f32x4*>(s_dr)[i] = reinterpret_cast<const f32x4*>(d_att_res_all + ((size_t)t * B + b) * H)[c];
     }
     float bsum = 0.f;
-    for (int i = tid; i < T * K; i += 256) {
+    for (int i = tid; i < T * K; i += NW * 64) {
         const int t = i / K, k = i % K;
         s_al[i] = alpha_all[((size_t)t * B + b) * K + k];
         const float dd = ddot_all[((size_t)t * B + b) * K + k];
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(256) void attn_bwd_feats_kernel(const float* __rest
         wa[i] = c < A4 ? reinterpret_cast<const f32x4*>(w_alpha)[c] : z4;
         dw[i] = z4;
     }
-    for (int k = w; k < K; k += 4) {
+    for (int k = w; k < K; k += NW) {
         f32x4 p[NI], dp[NI], da[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -527,11 +528,11 @@ __global__ __launch_bounds__(256) void attn_bwd_feats_kernel(const float* __rest
 #pragma unroll
     for (int i = 0; i < NI; ++i) *reinterpret_cast<f32x4*>(&s_dw[(w * NI * 64 + i * 64 + lane) * 4]) = dw[i];
     __syncthreads();
-    for (int a = tid; a < A; a += 256) {
+    for (int a = tid; a < A; a += NW * 64) {
         const int c = a >> 2, e = a & 3, i = c >> 6, l = c & 63;
         float s = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) s += s_dw[((ww * NI + i) * 64 + l) * 4 + e];
+        for (int ww = 0; ww < NW; ++ww) s += s_dw[((ww * NI + i) * 64 + l) * 4 + e];
         atomicAdd(dw_alpha + a, s);
     }
     bsum = wave_sum(bsum);
@@ -800,18 +801,19 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     {
         const int mx = A > H ? A : H;
         const int NIv = mx <= 256 ? 1 : (mx <= 512 ? 2 : 4);
-        const size_t shm = sizeof(float) * ((size_t)T * (A + H + 2 * K) + 4 * NIv * 256);
-        dim3 grid(B), blk(256);
-#define GO(NI)                                                                                                       \
+        dim3 grid(B);
+#define GO(NI, NWF)                                                                                                  \
     do {                                                                                                             \
-        CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_feats_kernel<NI>),                       \
+        const size_t shm = sizeof(float) * ((size_t)T * (A + H + 2 * K) + (size_t)NWF * NI * 256);                   \
+        CIC_REQUIRE(shm <= 160 * 1024);                                                                              \
+        CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_feats_kernel<NI, NWF>),                  \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));                          \
-        hipLaunchKernelGGL((attn_bwd_feats_kernel<NI>), grid, blk, shm, st, w.p_att, w.att_h_all, g.d_att_res_all,   \
-                           w.alpha_all, g.ddot_all, p->alpha_w, g.d_att, g.d_p_att, gr->alpha_w, gr->alpha_b, T, B,  \
-                           K, A, H);                                                                                 \
+        hipLaunchKernelGGL((attn_bwd_feats_kernel<NI, NWF>), grid, dim3(NWF * 64), shm, st, w.p_att, w.att_h_all,    \
+                           g.d_att_res_all, w.alpha_all, g.ddot_all, p->alpha_w, g.d_att, g.d_p_att, gr->alpha_w,    \
+                           gr->alpha_b, T, B, K, A, H);                                                              \
     } while (0)
-        CIC_REQUIRE(shm <= 160 * 1024);
-        if (NIv == 1) GO(1); else if (NIv == 2) GO(2); else GO(4);
+        // 12 waves per image (3 regions each at K = 36); the widest rows keep 4 waves (LDS budget)
+        if (NIv == 1) GO(1, 12); else if (NIv == 2) GO(2, 12); else GO(4, 4);
 #undef GO
         CIC_LAUNCH_CHECK();
     }
