@@ -205,6 +205,8 @@ def main():
     # into HIP graphs on their first call and replayed afterwards (one launch per decode / listener pass)
     stream = torch.cuda.Stream(device=dev) if args.graphs else torch.cuda.current_stream(dev)
     engine.graph_enable(args.graphs)
+    if os.environ.get('CIC_GEMM_FLAGS') is not None:       # A/B measurement of the GEMM dispatch switches
+        engine.lib.cic_debug_gemm_tail_split(int(os.environ['CIC_GEMM_FLAGS'], 0))
     if os.environ.get('CIC_GRU_FUSED') is not None:        # A/B measurement of the fused listener GRU step
         engine.lib.cic_debug_gru_fused(int(os.environ['CIC_GRU_FUSED']))
     if os.environ.get('CIC_SIDE_STREAM') is not None:      # A/B measurement of the side-stream products
