@@ -108,120 +108,100 @@ __global__ __launch_bounds__(256) void gru_cell_fwd_kernel(const float* __restri
     reinterpret_cast<f32x4*>(h_new)[idx] = hn;
 }
 
-// ---- fused GRU step (flagship width J = 8*GPS*KS = 1024) ---------------------------------------------------------
+// ---- fused GRU step (flagship width J = 1024) ---------------------------------------------------------------------
 // gh = h W_hh^T + b_hh and the gate arithmetic of one time step in ONE launch.  A workgroup owns a 32-row strip of
-// the batch and one 32-wide tile j of hidden units: it computes the three gate tiles (r, z, n: weight rows j, J+j,
-// 2J+j) with the K range split over its KS waves (MFMA A fragments of the strip's h rows stay in registers, the B
-// fragments of the next gate are in flight under the current gate's MFMA chain), sums the KS partial tiles through
-// LDS and applies the cell to the outputs it holds: the pre-activations never make a round trip through memory
-// before the cell, and a step is one launch instead of a GEMM + a cell kernel.  gh is still written (the backward
-// pass reads it).  Step 0 (h = 0) skips the products: gh = b_hh.
-template <int GPS, int KS>
+// the batch and one 16-wide tile j of hidden units: it computes the three gate tiles (r, z, n: weight rows j, J+j,
+// 2J+j) on v_mfma_f32_16x16x4_f32 (two 16-row MFMA tiles per gate share every B fragment), the K range split over
+// its KS = 8 waves (the A fragments of the strip's h rows stay in registers, the B fragments of the next gate are in
+// flight under the current gate's MFMA chain), sums the KS partial tiles through LDS and applies the cell to the
+// outputs it holds: the pre-activations never make a round trip through memory before the cell and a step is one
+// launch instead of a GEMM + a cell kernel.  16-wide unit tiles give 4 x 64 = 256 workgroups at B = 128: one per CU.
+// gh is still written (the backward pass reads it).  Step 0 (h = 0) skips the products: gh = b_hh.
+//   16x16x4 operand layout: lane l -> (i = l & 15, q = l >> 4); A: row i, k = 4q+s for MFMA s of a 16-k group
+//   (one dwordx4 per group); B: column i likewise; D: 4 registers v: row 4q+v, column i.
+typedef float f32x4acc __attribute__((ext_vector_type(4)));
+template <int GPS, int KS>   // GPS groups of 16 k per wave: K slice = 16*GPS, J = 16*GPS*KS
 __global__ __launch_bounds__(KS * 64) void gru_step_fused_kernel(const float* __restrict__ h, const float* __restrict__ W,
                                                              const float* __restrict__ b_hh, const float* __restrict__ gi,
                                                              const int32_t* __restrict__ len, int t, float* __restrict__ gh_out,
                                                              float* __restrict__ h_new, int B, int J, int h_is_zero) {
-    static_assert(16 % KS == 0, "accumulator registers are dealt evenly to the waves");
-    constexpr int EPW = 16 / KS;
-    constexpr int CH = 4;
-    __shared__ float red[2 * KS * 16 * 64];
+    static_assert(KS == 8, "8 accumulator registers (2 row tiles x 4) dealt one per wave");
+    __shared__ float red[2 * KS * 8 * 64];
     const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
-    const int hh = lane >> 5, r = lane & 31;
-    const int tiles_j = J / 32;
+    const int li = lane & 15, lq = lane >> 4;
+    const int tiles_j = J / 16;
     const int strip = blockIdx.x / tiles_j, jt = blockIdx.x % tiles_j;   // blockIdx % 8 == jt % 8: a weight tile's readers share an XCD
     const int m0 = strip * 32;
-    const int m = m0 + r;
-    const bool mok = m < B;
-    const int mc = mok ? m : B - 1;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    // epilogue operands of the outputs this wave finishes: issued first, used last
-    float gir[EPW], giz[EPW], gin[EPW], hp[EPW];
-    int row[EPW], ln[EPW];
-    const int col = jt * 32 + r;
-#pragma unroll
-    for (int q = 0; q < EPW; ++q) {
-        const int e = ks + KS * q;
-        const int mm = m0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        row[q] = mm;
-        const int mcl = mm < B ? mm : B - 1;
-        gir[q] = gi[(size_t)mcl * 3 * J + col];
-        giz[q] = gi[(size_t)mcl * 3 * J + J + col];
-        gin[q] = gi[(size_t)mcl * 3 * J + 2 * J + col];
-        hp[q] = h[(size_t)mcl * J + col];
-        ln[q] = len[mcl];
-    }
-    float ghv[3][EPW];
+    // the output this wave finishes after the cross-wave sums: register ks of the 8 -> row tile ks>>2, register ks&3
+    const int col = jt * 16 + li;
+    const int orow = m0 + 16 * (ks >> 2) + 4 * lq + (ks & 3);
+    const int orc = orow < B ? orow : B - 1;
+    const float gir = gi[(size_t)orc * 3 * J + col], giz = gi[(size_t)orc * 3 * J + J + col], gin = gi[(size_t)orc * 3 * J + 2 * J + col];
+    const float hp = h[(size_t)orc * J + col];
+    const int ln = len[orc];
+    float ghv[3];
     if (!h_is_zero) {
-        f32x4 af[GPS];
+        f32x4 af[2][GPS];
 #pragma unroll
-        for (int i = 0; i < GPS; ++i) {
-            const int k = 8 * (ks * GPS + i) + 4 * hh;
-            const f32x4 a = *reinterpret_cast<const f32x4*>(h + (size_t)mc * J + k);
-            af[i] = mok ? a : z4;
+        for (int rt = 0; rt < 2; ++rt) {
+            const int m = m0 + 16 * rt + li;
+            const int mc = m < B ? m : B - 1;
+#pragma unroll
+            for (int i = 0; i < GPS; ++i) {
+                const int k = 16 * (ks * GPS + i) + 4 * lq;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(h + (size_t)mc * J + k);
+                af[rt][i] = m < B ? a : z4;
+            }
         }
         f32x4 bf[GPS];
-        auto load_chunk = [&](int c, int g) {
-            const int gg = g < 3 ? g : 2;
-            const float* wrow = W + ((size_t)gg * J + col) * J;
+        auto load_b = [&](int g) {
+            const float* wrow = W + ((size_t)g * J + col) * J;
 #pragma unroll
-            for (int ii = 0; ii < CH; ++ii) {
-                const int i = c * CH + ii;
-                const int k = 8 * (ks * GPS + i) + 4 * hh;
-                bf[i] = *reinterpret_cast<const f32x4*>(wrow + k);
-            }
+            for (int i = 0; i < GPS; ++i) bf[i] = *reinterpret_cast<const f32x4*>(wrow + 16 * (ks * GPS + i) + 4 * lq);
         };
-#pragma unroll
-        for (int c = 0; c < GPS / CH; ++c) load_chunk(c, 0);
+        load_b(0);
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
-            f32x16 acc;
+            f32x4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            for (int i = 0; i < GPS; ++i)
 #pragma unroll
-            for (int c = 0; c < GPS / CH; ++c) {
+                for (int s = 0; s < 4; ++s) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][i][s], bf[i][s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][i][s], bf[i][s], acc1, 0, 0, 0);
+                }
+            if (g < 2) load_b(g + 1);                      // the next gate's weight tile, in flight under the sums below
+            float* rb = red + (g & 1) * (KS * 8 * 64);
 #pragma unroll
-                for (int ii = 0; ii < CH; ++ii)
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c * CH + ii][s], bf[c * CH + ii][s], acc, 0, 0, 0);
-                if (g < 2) load_chunk(c, g + 1);           // the same chunk of the next gate's weight tile
+            for (int v = 0; v < 4; ++v) {
+                rb[(ks * 8 + v) * 64 + lane] = acc0[v];
+                rb[(ks * 8 + 4 + v) * 64 + lane] = acc1[v];
             }
-            float* rb = red + (g & 1) * (KS * 16 * 64);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) rb[(ks * 16 + e) * 64 + lane] = acc[e];
             __syncthreads();
-            const float bv = b_hh[g * J + col];
+            float v = 0.f;
 #pragma unroll
-            for (int q = 0; q < EPW; ++q) {
-                const int e = ks + KS * q;
-                float v = 0.f;
-#pragma unroll
-                for (int w = 0; w < KS; ++w) v += rb[(w * 16 + e) * 64 + lane];
-                ghv[g][q] = v + bv;
-            }
+            for (int w = 0; w < KS; ++w) v += rb[(w * 8 + ks) * 64 + lane];
+            ghv[g] = v + b_hh[g * J + col];
         }
     } else {
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-            for (int q = 0; q < EPW; ++q) ghv[g][q] = b_hh[g * J + col];
+        for (int g = 0; g < 3; ++g) ghv[g] = b_hh[g * J + col];
     }
-    // the cell (torch.nn.GRU gate order r, z, n) on the outputs this wave holds; rows past their caption's length keep h
-#pragma unroll
-    for (int q = 0; q < EPW; ++q) {
-        if (row[q] >= B) continue;
-        const size_t o = (size_t)row[q] * 3 * J + col;
-        gh_out[o] = ghv[0][q];
-        gh_out[o + J] = ghv[1][q];
-        gh_out[o + 2 * J] = ghv[2][q];
-        float hn = hp[q];
-        if (t < ln[q]) {
-            const float rr = fast_sigmoid(gir[q] + ghv[0][q]);
-            const float zz = fast_sigmoid(giz[q] + ghv[1][q]);
-            const float nn = fast_tanh(gin[q] + rr * ghv[2][q]);
-            hn = (1.0f - zz) * nn + zz * hp[q];
+    // the cell (torch.nn.GRU gate order r, z, n) on the output this lane holds; rows past their caption's length keep h
+    if (orow < B) {
+        const size_t o = (size_t)orow * 3 * J + col;
+        gh_out[o] = ghv[0];
+        gh_out[o + J] = ghv[1];
+        gh_out[o + 2 * J] = ghv[2];
+        float hn = hp;
+        if (t < ln) {
+            const float rr = fast_sigmoid(gir + ghv[0]);
+            const float zz = fast_sigmoid(giz + ghv[1]);
+            const float nn = fast_tanh(gin + rr * ghv[2]);
+            hn = (1.0f - zz) * nn + zz * hp;
         }
-        h_new[(size_t)row[q] * J + col] = hn;
+        h_new[(size_t)orow * J + col] = hn;
     }
 }
 
@@ -589,7 +569,7 @@ static int listener_fwd_impl(const cic_listener_dims* dp, const cic_listener_par
         float* h = w.h_all + (size_t)t * B * J;
         float* gh = w.gh_all + (size_t)t * B * 3 * J;
         if (fused_step) {
-            hipLaunchKernelGGL((gru_step_fused_kernel<16, 8>), dim3(cic_cdiv(B, 32) * (J / 32)), dim3(512), 0, st, h, p->w_hh,
+            hipLaunchKernelGGL((gru_step_fused_kernel<8, 8>), dim3(cic_cdiv(B, 32) * (J / 16)), dim3(512), 0, st, h, p->w_hh,
                                p->b_hh, w.gi_all + (size_t)t * B * 3 * J, w.len, t, gh, h + (size_t)B * J, B, J, t == 0 ? 1 : 0);
             CIC_LAUNCH_CHECK();
             continue;
