@@ -44,6 +44,10 @@ int cic_cell_fwd2(Dual<const float> pre, Dual<const float> c_prev, Dual<const ui
                   Dual<float> c_new, Dual<float> out, int B, int nb, int H, hipStream_t st, int state_dropped = 0);
 int cic_embed_fwd2(const float* E, Dual<const int32_t> it, Dual<const uint8_t> keep, float p_drop, Dual<float> x, int B,
                    int nb, int Ed, hipStream_t st, int plain = 0);
+bool cic_a2c_cell_fused_ok(int H);
+int cic_a2c_cell_fused(Dual<const float> att_res, const float* Wa, const float* ba, Dual<float> pre, Dual<const float> c_prev,
+                       Dual<const uint8_t> keep, float p_drop, Dual<float> h_new, Dual<float> c_new, Dual<float> out, int B,
+                       int nb, int H, hipStream_t st);
 int cic_logsoftmax_sample2(const cic_sampler_args* a, const cic_sampler_args* b, hipStream_t st);
 int cic_relu_keep_fwd(const float* xpre, const uint8_t* keep, float p_drop, float* x, int64_t n, hipStream_t st);
 int cic_soft_mask(const float* soft_raw, const int32_t* seq, const int32_t* L, float* soft_out, int T, int B, int V1,

@@ -247,14 +247,20 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
             g.C = pre.a; g.ldc = 5 * H; g.bias = w[0].bias_ih;
             RUN(pair_gemm(g, x.b, h.b, pre.b));
         }
-        if (!fc) {
-            cic_gemm_args g = {};
-            g.M = M; g.N = 2 * H; g.K = H; g.A = att_res.a; g.lda = H; g.a_kc = 1; g.B = p->a2c_w; g.ldb = H; g.b_kc = 1;
-            g.C = pre.a + 3 * H; g.ldc = 5 * H; g.bias = p->a2c_b; g.accumulate = 1;
-            RUN(pair_gemm(g, att_res.b, nullptr, nb == 2 ? pre.b + 3 * H : nullptr));
+        if (!fc && cic_a2c_cell_fused_ok(H)) {
+            // a2c product + cell in one launch (flagship width)
+            RUN(cic_a2c_cell_fused(Dual<const float>{att_res.a, att_res.b}, p->a2c_w, p->a2c_b, pre, c, ok, ok.a ? p_drop : 0.f,
+                                   h_new, c_new, out, B, nb, H, st));
+        } else {
+            if (!fc) {
+                cic_gemm_args g = {};
+                g.M = M; g.N = 2 * H; g.K = H; g.A = att_res.a; g.lda = H; g.a_kc = 1; g.B = p->a2c_w; g.ldb = H; g.b_kc = 1;
+                g.C = pre.a + 3 * H; g.ldc = 5 * H; g.bias = p->a2c_b; g.accumulate = 1;
+                RUN(pair_gemm(g, att_res.b, nullptr, nb == 2 ? pre.b + 3 * H : nullptr));
+            }
+            RUN(cic_cell_fwd2(Dual<const float>{pre.a, pre.b}, c, ok, ok.a ? p_drop : 0.f, h_new, c_new, out, B, nb, H, st,
+                              fc ? 1 : 0));
         }
-        RUN(cic_cell_fwd2(Dual<const float>{pre.a, pre.b}, c, ok, ok.a ? p_drop : 0.f, h_new, c_new, out, B, nb, H, st,
-                          fc ? 1 : 0));
         // logprobs = log_softmax(logit(output)); choose the input of step t+1   (:328-365,444)
         {
             cic_gemm_args g = {};

@@ -302,6 +302,106 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(Dual<const float> pre_d, 
     reinterpret_cast<f32x4*>(out)[idx] = o;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fused a2c product + maxout-LSTM cell (flagship width H = 512): in_transform += a2c(att_res) and the whole pointwise
+// cell of Att2in2Core.forward (models/AttModel.py:515-529) in ONE launch.  A workgroup owns a 32-row strip and one
+// 16-wide tile j of hidden units: it computes the two a2c tiles the units need (weight rows j and H+j, i.e. the two
+// maxout halves) on v_mfma_f32_16x16x4_f32 with K = H split over its 8 waves, sums the partial tiles through LDS and
+// applies the cell to the outputs it holds, reading the i/f/o pre-activations the i2h/h2h product left in `pre`.
+// The summed candidates are written back into pre[:, 3H:5H] (the backward pass reads them).  Rows [B0, 2*B0) of a
+// decode pair go through the .b pointers.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4acc __attribute__((ext_vector_type(4)));
+template <int GPS, int KS>   // H = 16*GPS*KS
+__global__ __launch_bounds__(KS * 64) void a2c_cell_fused_kernel(Dual<const float> att_res_d, const float* __restrict__ Wa,
+                                                             const float* __restrict__ ba, Dual<float> pre_d,
+                                                             Dual<const float> c_prev_d, Dual<const uint8_t> keep_d, float scale,
+                                                             Dual<float> h_new_d, Dual<float> c_new_d, Dual<float> out_d,
+                                                             int B0, int nb, int H) {
+    static_assert(KS == 8, "8 accumulator registers (2 row tiles x 4) dealt one per wave");
+    __shared__ float red[2 * KS * 8 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int tiles_j = H / 16;
+    const int strips_per = (B0 + 31) / 32;
+    int strip = blockIdx.x / tiles_j;
+    const int jt = blockIdx.x % tiles_j;
+    const bool second = strip >= strips_per;
+    if (second) strip -= strips_per;
+    const float* __restrict__ att_res = att_res_d.sel(second);
+    float* __restrict__ pre = pre_d.sel(second);
+    const float* __restrict__ c_prev = c_prev_d.sel(second);
+    const uint8_t* __restrict__ keep = keep_d.sel(second);
+    float* __restrict__ h_new = h_new_d.sel(second);
+    float* __restrict__ c_new = c_new_d.sel(second);
+    float* __restrict__ out = out_d.sel(second);
+    const int m0 = strip * 32;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const int col = jt * 16 + li;
+    const int orow = m0 + 16 * (ks >> 2) + 4 * lq + (ks & 3);     // the output this wave finishes after the cross-wave sums
+    const int orc = orow < B0 ? orow : B0 - 1;
+    // epilogue operands first (used last)
+    const float* prow = pre + (size_t)orc * 5 * H;
+    const float pi = prow[col], pf = prow[H + col], po = prow[2 * H + col], pa = prow[3 * H + col], pb = prow[4 * H + col];
+    const float cp = c_prev[(size_t)orc * H + col];
+    const float kf = keep ? (float)keep[(size_t)orc * H + col] * scale : 1.0f;
+    f32x4 af[2][GPS];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int m = m0 + 16 * rt + li;
+        const int mc = m < B0 ? m : B0 - 1;
+#pragma unroll
+        for (int i = 0; i < GPS; ++i) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(att_res + (size_t)mc * H + 16 * (ks * GPS + i) + 4 * lq);
+            af[rt][i] = m < B0 ? a : z4;
+        }
+    }
+    f32x4 bf[GPS];
+    auto load_b = [&](int g) {
+        const float* wrow = Wa + ((size_t)g * H + col) * H;
+#pragma unroll
+        for (int i = 0; i < GPS; ++i) bf[i] = *reinterpret_cast<const f32x4*>(wrow + 16 * (ks * GPS + i) + 4 * lq);
+    };
+    load_b(0);
+    float av[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        f32x4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < GPS; ++i)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][i][s], bf[i][s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][i][s], bf[i][s], acc1, 0, 0, 0);
+            }
+        if (g < 1) load_b(1);
+        float* rb = red + g * (KS * 8 * 64);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            rb[(ks * 8 + v) * 64 + lane] = acc0[v];
+            rb[(ks * 8 + 4 + v) * 64 + lane] = acc1[v];
+        }
+        __syncthreads();
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < KS; ++w) v += rb[(w * 8 + ks) * 64 + lane];
+        av[g] = v + ba[g * H + col];
+    }
+    if (orow < B0) {
+        const float a = pa + av[0], b = pb + av[1];               // in_transform halves (:521-522), kept for the backward pass
+        float* pw = pre + (size_t)orow * 5 * H;
+        pw[3 * H + col] = a;
+        pw[4 * H + col] = b;
+        const float ig = fast_sigmoid(pi), fg = fast_sigmoid(pf), og = fast_sigmoid(po);
+        const float c2 = fg * cp + ig * fmaxf(a, b);              // :523-526
+        const float h2 = og * fast_tanh(c2);                      // :527
+        c_new[(size_t)orow * H + col] = c2;
+        h_new[(size_t)orow * H + col] = h2;
+        out[(size_t)orow * H + col] = keep ? h2 * kf : h2;        // :529
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // K7 token embedding: x = dropout(relu(E[it]))   (models/AttModel.py:74-76,399)
 // ---------------------------------------------------------------------------------------
@@ -819,6 +919,25 @@ int cic_cell_fwd2(Dual<const float> pre, Dual<const float> c_prev, Dual<const ui
     const int n = nb * B * (H / 4);
     hipLaunchKernelGGL(cell_fwd_kernel, dim3(cic_cdiv(n, 256)), dim3(256), 0, st, pre, c_prev, keep,
                        1.0f / (1.0f - p_drop), h_new, c_new, out, B, nb, H, state_dropped);
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+
+int g_a2c_cell_fused = 1;
+extern "C" int cic_debug_a2c_cell_fused(int on) {
+    g_a2c_cell_fused = on;
+    return 0;
+}
+bool cic_a2c_cell_fused_ok(int H) { return g_a2c_cell_fused && H == 512; }
+
+int cic_a2c_cell_fused(Dual<const float> att_res, const float* Wa, const float* ba, Dual<float> pre, Dual<const float> c_prev,
+                       Dual<const uint8_t> keep, float p_drop, Dual<float> h_new, Dual<float> c_new, Dual<float> out, int B,
+                       int nb, int H, hipStream_t st) {
+    CIC_REQUIRE(cic_a2c_cell_fused_ok(H) && att_res.a && Wa && ba && pre.a && c_prev.a && h_new.a && c_new.a && out.a && B > 0);
+    CIC_REQUIRE(nb == 1 || (nb == 2 && att_res.b && pre.b && c_prev.b && h_new.b && c_new.b && out.b));
+    const int grid = nb * cic_cdiv(B, 32) * (H / 16);
+    hipLaunchKernelGGL((a2c_cell_fused_kernel<4, 8>), dim3(grid), dim3(512), 0, st, att_res, Wa, ba, pre, c_prev, keep,
+                       1.0f / (1.0f - p_drop), h_new, c_new, out, B, nb, H);
     CIC_LAUNCH_CHECK();
     return 0;
 }

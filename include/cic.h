@@ -65,6 +65,8 @@ int cic_debug_gemm_tail_split(int on);
 int cic_debug_side_stream(int on);
 /* diagnostics: 0 runs every listener GRU step as a GEMM launch + a cell launch instead of the fused step kernel */
 int cic_debug_gru_fused(int on);
+/* diagnostics: 0 runs the speaker's a2c product and cell as two launches instead of the fused kernel */
+int cic_debug_a2c_cell_fused(int on);
 
 /* ---- RNG (replaces torch.rand / nn.Dropout's bernoulli_ draws) ---------------------- */
 /* Philox4x32-10 counter RNG.  u[i] = (r >> 8) * 2^-24 in [0,1), as torch.rand does
