@@ -24,6 +24,7 @@ bool aligned16(const void* p);
 int g_tail_split = 1;   // bit 0: K-sliced tail tiles and K split over workgroups (float atomics) on / off
 int g_force_tile = 0;   // bits 8..15: 1 = 128x128, 2 = 64x64 tiles forced
 int g_walk = 1;         // bit 16 set: strip walkers off
+int g_walk16 = 1;       // bit 21 set: 16-wide strip walkers off
 
 constexpr int BK = 32;
 constexpr int KCS = BK + 4;  // row stride of a K-contiguous LDS image (floats)
@@ -713,6 +714,117 @@ __global__ __launch_bounds__(KS * 64) void gemm_walk_kernel(cic_gemm_args g, int
 }
 
 
+
+// Strip walker on v_mfma_f32_16x16x4_f32: 16-wide column tiles.  Same structure as gemm_walk_kernel (a workgroup of
+// KS = 8 waves owns a 32-row strip, keeps the MFMA A fragments of its two 16-row tiles for its K slice in registers
+// and walks column tiles; the B fragments of the next tile are loaded while the current tile's partial sums meet in
+// LDS), but a tile is 32 x 16: twice as many work units as 32-wide tiles (9488 / 16 = 593 tiles x 8 strips spread
+// evenly over the workgroups), every B fragment feeds two MFMA chains, a fragment load touches 16 cache lines of 64 B
+// instead of 32 of 32 B, and only 8 accumulator registers per wave cross LDS.
+//   operand layout: lane l -> (i = l & 15, q = l >> 4); A: row i, k = 16g + 4q + s for MFMA s of group g (one dwordx4
+//   per group); B: column i likewise; D: 4 registers v: row 4q + v, column i.
+typedef float f32x4acc __attribute__((ext_vector_type(4)));
+template <int GPS, int KS, bool DEEP>   // K slice per wave = 16*GPS; DEEP: B fragments two tiles ahead (short K slices)
+__global__ __launch_bounds__(KS * 64) void gemm_walk16_kernel(cic_gemm_args g, int strips) {
+    static_assert(KS == 8, "8 accumulator registers (2 row tiles x 4) dealt one per wave");
+    __shared__ float red[2 * KS * 8 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int tiles_n = (g.N + 15) / 16;
+    const int step = gridDim.x / strips;                     // walkers per strip, a multiple of 8 (XCD sharing)
+    const int first = blockIdx.x % step, strip = blockIdx.x / step;
+    int m0 = strip * 32;
+    const bool blk2 = g.rows_blk > 0 && m0 >= g.rows_blk;   // row blocks: see gemm_rega_kernel
+    const float* __restrict__ gA = blk2 ? g.A_b : g.A;
+    const float* __restrict__ gA2 = blk2 ? g.A2_b : g.A2;
+    float* __restrict__ gC = blk2 ? g.C_b : g.C;
+    const int Mloc = g.rows_blk > 0 ? (blk2 ? g.M - g.rows_blk : min(g.M, g.rows_blk)) : g.M;
+    if (blk2) m0 -= g.rows_blk;
+    const int K1 = g.K, Kt = g.K + g.K2;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 af[2][GPS];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int m = m0 + 16 * rt + li;
+        const bool mok = m < Mloc;
+        const int mc = mok ? m : Mloc - 1;
+#pragma unroll
+        for (int i = 0; i < GPS; ++i) {
+            const int k = 16 * (ks * GPS + i) + 4 * lq;
+            const bool kok = k < Kt;
+            const bool second = kok && k >= K1;
+            const int kp = second ? g.K2 : K1;
+            int kk = second ? k - K1 : k;
+            kk = kk < kp - 4 ? kk : kp - 4;
+            const f32x4 a = *reinterpret_cast<const f32x4*>((second ? gA2 : gA) + (size_t)mc * (second ? g.lda2 : g.lda) + kk);
+            af[rt][i] = (kok && mok) ? a : z4;
+        }
+    }
+    f32x4 bf[GPS], bq[DEEP ? GPS : 1];
+    auto load_b = [&](f32x4 (&dst)[GPS], int t) {
+        const int tt = t < tiles_n ? t : tiles_n - 1;
+        const int n = tt * 16 + li;
+        const bool nok = t < tiles_n && n < g.N;
+        const int nc = n < g.N ? n : g.N - 1;
+#pragma unroll
+        for (int i = 0; i < GPS; ++i) {
+            const int k = 16 * (ks * GPS + i) + 4 * lq;
+            const bool kok = k < Kt;
+            const bool second = kok && k >= K1;
+            const float* B = second ? g.B2 : g.B;
+            const int ldb = second ? g.ldb2 : g.ldb;
+            const int kp = second ? g.K2 : K1;
+            int kk = second ? k - K1 : k;
+            kk = kk < kp - 4 ? kk : kp - 4;
+            const f32x4 b = *reinterpret_cast<const f32x4*>(B + (size_t)nc * ldb + kk);
+            dst[i] = (kok && nok) ? b : z4;
+        }
+    };
+    load_b(bf, first);
+    if (DEEP) load_b(reinterpret_cast<f32x4 (&)[GPS]>(bq), first + step);
+    // the output this wave finishes: accumulator register ks of the 8 -> row tile ks >> 2, register ks & 3
+    const int mm = m0 + 16 * (ks >> 2) + 4 * lq + (ks & 3);
+    const int mcl = mm < Mloc ? mm : Mloc - 1;
+    int buf = 0;
+#pragma unroll 1
+    for (int t = first; t < tiles_n; t += step) {
+        const int n = t * 16 + li;
+        const int ncl = n < g.N ? n : g.N - 1;
+        float bias_v = 0.f, cold = 0.f;                 // epilogue operands fetched before the barrier
+        if (g.bias) bias_v = g.bias[ncl];
+        if (g.accumulate) cold = gC[(size_t)mcl * g.ldc + ncl];
+        f32x4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < GPS; ++i)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][i][s], bf[i][s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][i][s], bf[i][s], acc1, 0, 0, 0);
+            }
+        if (DEEP) {                                     // tile t+1 is already here; tile t+2 goes out now
+#pragma unroll
+            for (int i = 0; i < GPS; ++i) bf[i] = bq[i];
+            load_b(reinterpret_cast<f32x4 (&)[GPS]>(bq), t + 2 * step);
+        } else {
+            load_b(bf, t + step);                       // next tile's fragments in flight under the cross-wave sum
+        }
+        float* rb = red + buf * (KS * 8 * 64);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            rb[(ks * 8 + v) * 64 + lane] = acc0[v];
+            rb[(ks * 8 + 4 + v) * 64 + lane] = acc1[v];
+        }
+        __syncthreads();
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < KS; ++w) v += rb[(w * 8 + ks) * 64 + lane];
+        v += bias_v + cold;
+        if (g.relu) v = fmaxf(v, 0.f);
+        if (mm < Mloc && n < g.N) gC[(size_t)mm * g.ldc + n] = v;
+        buf ^= 1;
+    }
+}
+
 bool rega_ok(const cic_gemm_args& g) {
     if (!g.a_kc || g.M > (g.rows_blk > 0 ? 256 : 128)) return false;
     if (g.rows_blk > 0 && (!aligned16(g.A_b) || (g.K2 > 0 && !aligned16(g.A2_b)))) return false;
@@ -734,6 +846,19 @@ int launch_rega(const cic_gemm_args& g, hipStream_t st) {
     // 16-wave persistent strips below are faster: 36 vs 42 us for the logit product.  With no B reloads and no
     // cross-wave sum the walkers run their MFMA chains at ~90 % of the f32 rate: what holds these launches at 2x the
     // MFMA floor is operand delivery, 32 cache lines per fragment load, and ~5 us of launch + first-load latency.)
+    // 16-wide walkers (see gemm_walk16_kernel) for the K = 1024 products with many column tiles (measured,
+    // tools/step_gemms.py: [256 x 2560 x 1024] 22.6 us vs 29.3 us with 32-wide tiles, [128 x 3072 x 1024] 16.6 vs 22.7;
+    // at K = 512 the 16-wave persistent strips below stay faster: 35 vs 42-48 us for the logit product)
+    if (g_walk16 && g.b_kc && g.N >= 2048 && Kt == 1024) {
+        int nb = 256 / strips;                         // 8-wave workgroups, one per CU
+        const int t16 = cic_cdiv(g.N, 16);
+        if (nb > t16) nb = t16;
+        if (nb >= 8) nb &= ~7;
+        if (nb < 1) nb = 1;
+        hipLaunchKernelGGL((gemm_walk16_kernel<8, 8, false>), dim3(strips * nb), dim3(512), 0, st, g, strips);
+        CIC_LAUNCH_CHECK();
+        return 0;
+    }
     if (g_walk && g.b_kc && tiles_n >= 64 && Kt == 1024) {
         int nb = 256 / strips;                         // 8-wave workgroups, one per CU
         if (nb > tiles_n) nb = tiles_n;
@@ -858,6 +983,7 @@ extern "C" int cic_debug_gemm_tail_split(int on) {
     g_tail_split = on & 0xff;
     g_force_tile = (on >> 8) & 0xff;
     g_walk = ((on >> 16) & 1) ? 0 : 1;
+    g_walk16 = ((on >> 21) & 1) ? 0 : 1;
     return 0;
 }
 

@@ -55,9 +55,10 @@ def main():
         name, M, N, K, K2 = sh[:5]
         fl = 2.0 * M * N * (K + K2)
         u1, e1 = run(*sh, flag=1)
-        u0, e0 = run(*sh, flag=1 | (1 << 16))
-        print(f'{name:14s} M{M:4d} N{N:5d} K{K + K2:5d}  walk/auto {u1:7.2f} us ({fl / u1 / 1e6:6.1f} TF/s, err {e1:.1e})   '
-              f'no-walk {u0:7.2f} us ({fl / u0 / 1e6:6.1f} TF/s, err {e0:.1e})   mfma floor {fl / 157e6:5.2f} us')
+        u0, e0 = run(*sh, flag=1 | (1 << 16) | (1 << 21))
+        u2, e2 = run(*sh, flag=1 | (1 << 21))
+        print(f'{name:14s} M{M:4d} N{N:5d} K{K + K2:5d}  auto(walk16) {u1:7.2f} us ({fl / u1 / 1e6:6.1f} TF/s, err {e1:.1e})   '
+              f'walk32 {u2:7.2f} us   no-walk {u0:7.2f} us (err {e0:.1e})   mfma floor {fl / 157e6:5.2f} us')
 
 
 if __name__ == '__main__':
