@@ -168,11 +168,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(cic_gemm_args g, int 
             TA::store(ra, LA, tid);
             TB::store(rb, LB, tid);
             __syncthreads();
-            if (!KCA && do_colsum && tid < BM) {
+            if (!KCA && do_colsum) {
                 // bias-gradient by-product (dW = dY^T X: the column sums of dY are db): this K-tile of op(A) is in LDS
-                // as [k][rows]; the workgroups of the first tile column add it up (out-of-range k / rows hold zeros)
-#pragma unroll 8
-                for (int kk = 0; kk < BK; ++kk) csum += LA[kk * (BM + 4) + tid];
+                // as [k][rows]; the workgroups of the first tile column add it up (out-of-range k / rows hold zeros).
+                // All threads share the work (THREADS / BM k-ranges per column): a single wave walking all 32 k's is a
+                // ~1000-cycle dependent chain per K-tile that every other wave then waits for at the barrier.
+                constexpr int PARTS = THREADS / BM, KPP = BK / PARTS;
+                const int cc = tid % BM, part = tid / BM;
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < KPP; kk += 2) {
+                    s0 += LA[(part * KPP + kk) * (BM + 4) + cc];
+                    s1 += LA[(part * KPP + kk + 1) * (BM + 4) + cc];
+                }
+                csum += s0 + s1;
             }
             if (kt + 1 < nk) {   // next tile in flight under the MFMAs
                 TA::load(ra, A, lda, m0, g.M, (kt + 1) * BK, K, tid);
@@ -196,9 +205,18 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(cic_gemm_args g, int 
         }
     }
 
-    if (!KCA && do_colsum && tid < BM && m0 + tid < g.M) {
-        atomicAdd(g.colsum_A + m0 + tid, csum);
-        if (g.colsum_A2) atomicAdd(g.colsum_A2 + m0 + tid, csum);
+    if (!KCA && do_colsum) {           // block-uniform
+        constexpr int PARTS = THREADS / BM;
+        __syncthreads();               // the last K-tile's fragment reads are done: LDS is free
+        lds[tid] = csum;
+        __syncthreads();
+        if (tid < BM && m0 + tid < g.M) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < PARTS; ++q) t += lds[q * BM + tid];
+            atomicAdd(g.colsum_A + m0 + tid, t);
+            if (g.colsum_A2) atomicAdd(g.colsum_A2 + m0 + tid, t);
+        }
     }
     // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
