@@ -346,49 +346,60 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
 // scores S[B,B] = im s^T from cic_gemm_f32.  One workgroup does the whole [B,B] reduction
 // (B <= 1024): thread i owns row i (caption retrieval) and column i (image retrieval).
 // out_rows[i] = sel_s*cost_s[i] + sel_im*cost_im[i];  out_sum = sum_i out_rows[i].
-__global__ __launch_bounds__(1024) void contrastive_fwd_kernel(const float* __restrict__ S, int B, float margin,
-                                                               int max_violation, int sel_s, int sel_im,
-                                                               float* __restrict__ out_rows, float* __restrict__ out_sum,
-                                                               int32_t* __restrict__ arg_s, int32_t* __restrict__ arg_im) {
-    __shared__ float sh[16];
-    const int i = threadIdx.x;
-    float tot = 0.f;
-    if (i < B) {
-        const float d = S[(size_t)i * B + i];
-        float cs = 0.f, ci = 0.f;
-        int as = -1, ai = -1;
+// one wave per row i: the row of cost_s and the column of cost_im reduced across the lanes (ties -> lowest index, as
+// the strict > of a left-to-right scan)
+__global__ __launch_bounds__(64) void contrastive_fwd_kernel(const float* __restrict__ S, int B, float margin,
+                                                             int max_violation, int sel_s, int sel_im,
+                                                             float* __restrict__ out_rows, int32_t* __restrict__ arg_s,
+                                                             int32_t* __restrict__ arg_im) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const float d = S[(size_t)i * B + i];
+    float cs = 0.f, ci = 0.f;
+    int as = 0x7fffffff, ai = 0x7fffffff;
+    for (int j = lane; j < B; j += 64) {
+        if (j == i) continue;
+        const float v = fmaxf(margin + S[(size_t)i * B + j] - d, 0.f);      // cost_s[i,j]   (:176)
+        const float u = fmaxf(margin + S[(size_t)j * B + i] - d, 0.f);      // cost_im[j,i]  (:179)
         if (max_violation) {
-            // masked_fill(diag, 0) then max: start from 0 (the diagonal entry), strict > keeps the first max
-            for (int j = 0; j < B; ++j) {
-                if (j == i) continue;
-                const float v = fmaxf(margin + S[(size_t)i * B + j] - d, 0.f);      // cost_s[i,j]   (:176)
-                if (v > cs) { cs = v; as = j; }
-                const float u = fmaxf(margin + S[(size_t)j * B + i] - d, 0.f);      // cost_im[j,i]  (:179)
-                if (u > ci) { ci = u; ai = j; }
-            }
+            if (v > cs) { cs = v; as = j; }
+            if (u > ci) { ci = u; ai = j; }
         } else {
-            for (int j = 0; j < B; ++j) {
-                if (j == i) continue;
-                cs += fmaxf(margin + S[(size_t)i * B + j] - d, 0.f);
-                ci += fmaxf(margin + S[(size_t)j * B + i] - d, 0.f);
-            }
-            cs /= (float)B;
-            ci /= (float)B;
+            cs += v;
+            ci += u;
         }
-        const float r = (sel_s ? cs : 0.f) + (sel_im ? ci : 0.f);
-        out_rows[i] = r;
+    }
+    if (max_violation) {
+        // masked_fill(diag, 0) then max: the maximum starts from 0 (no index) and a strict > keeps the first maximum
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(cs, o, 64);
+            const int oi = __shfl_xor(as, o, 64);
+            if (ov > cs || (ov == cs && oi < as)) { cs = ov; as = oi; }
+            const float pv = __shfl_xor(ci, o, 64);
+            const int pi = __shfl_xor(ai, o, 64);
+            if (pv > ci || (pv == ci && pi < ai)) { ci = pv; ai = pi; }
+        }
+        if (cs <= 0.f) as = -1;
+        if (ci <= 0.f) ai = -1;
+    } else {
+        cs = wave_sum(cs) / (float)B;
+        ci = wave_sum(ci) / (float)B;
+        as = ai = -1;
+    }
+    if (lane == 0) {
+        out_rows[i] = (sel_s ? cs : 0.f) + (sel_im ? ci : 0.f);
         if (arg_s) arg_s[i] = as;
         if (arg_im) arg_im[i] = ai;
-        tot = r;
     }
-    tot = wave_sum(tot);
-    if ((i & 63) == 0) sh[i >> 6] = tot;
-    __syncthreads();
-    if (i == 0) {
-        float s = 0.f;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sh[w];
-        *out_sum = s;
+}
+// scalar loss = sum of the per-row losses in row order (fixed summation order)
+__global__ __launch_bounds__(64) void contrastive_sum_kernel(const float* __restrict__ rows, int B, float* __restrict__ out_sum) {
+    float s = 0.f;
+    for (int j0 = 0; j0 < B; j0 += 64) {
+        const int j = j0 + (int)threadIdx.x;
+        s += wave_sum(j < B ? rows[j] : 0.f);
     }
+    if (threadIdx.x == 0) *out_sum = s;
 }
 // dS from per-row upstream gradients g_rows[i] (scalar loss: all equal).  dS must be zeroed first.
 __global__ __launch_bounds__(256) void contrastive_bwd_kernel(const float* __restrict__ S, int B, float margin,
@@ -591,8 +602,10 @@ static int listener_fwd_impl(const cic_listener_dims* dp, const cic_listener_par
     // contrastive loss                                                   (VSEFCModel.py:167-207)
     RUN(gemm_nt(w.img_emb, J, w.cap_emb, J, w.S, B, B, B, J, nullptr, false, false, st));
     const int sel_s = io->only_one_retrieval != 1, sel_im = io->only_one_retrieval != 2;
-    hipLaunchKernelGGL(contrastive_fwd_kernel, dim3(1), dim3(((B + 63) / 64) * 64), 0, st, w.S, B, d.margin,
-                       d.max_violation, sel_s, sel_im, io->loss_rows, io->loss_sum, w.arg_s, w.arg_im);
+    hipLaunchKernelGGL(contrastive_fwd_kernel, dim3(B), dim3(64), 0, st, w.S, B, d.margin, d.max_violation, sel_s, sel_im,
+                       io->loss_rows, w.arg_s, w.arg_im);
+    CIC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(contrastive_sum_kernel, dim3(1), dim3(64), 0, st, io->loss_rows, B, io->loss_sum);
     CIC_LAUNCH_CHECK();
     if (io->img_emb_out) CIC_HIP(hipMemcpyAsync(io->img_emb_out, w.img_emb, sizeof(float) * B * J, hipMemcpyDeviceToDevice, st));
     if (io->cap_emb_out) CIC_HIP(hipMemcpyAsync(io->cap_emb_out, w.cap_emb, sizeof(float) * B * J, hipMemcpyDeviceToDevice, st));
