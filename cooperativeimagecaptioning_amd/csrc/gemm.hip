@@ -25,6 +25,7 @@ int g_tail_split = 1;   // bit 0: K-sliced tail tiles and K split over workgroup
 int g_force_tile = 0;   // bits 8..15: 1 = 128x128, 2 = 64x64 tiles forced
 int g_walk = 1;         // bit 16 set: strip walkers off
 int g_walk16 = 1;       // bit 21 set: 16-wide strip walkers off
+int g_ldsb = 1;         // bit 22 set: LDS-staged column walker (K = 512 logit product) off
 
 constexpr int BK = 32;
 constexpr int KCS = BK + 4;  // row stride of a K-contiguous LDS image (floats)
@@ -843,6 +844,191 @@ __global__ __launch_bounds__(KS * 64) void gemm_walk16_kernel(cic_gemm_args g, i
     }
 }
 
+// Column walker with the weight tile in LDS (the logit product, K = 16*NG = 512): NO K split, so no cross-wave sum.
+// A workgroup of 4 waves (one per SIMD) owns 64 rows: wave w keeps the MFMA A fragments of its 16 rows for the WHOLE
+// K in registers (K/4 VGPRs per lane) and the workgroup walks 16-column weight tiles.  A tile [16 x K] is staged in LDS
+// once per workgroup with fully coalesced 2 KB row reads (double buffered: the next tile's global loads are issued at
+// the top of a tile, its LDS writes are interleaved with the last MFMAs of the tile, ONE barrier per tile), each wave
+// reads its B fragments back with one ds_read_b128 per four MFMAs (row stride K + 4 floats), a chunk of 8 reads ahead
+// of the MFMAs that use them, and runs four independent accumulator chains (MFMA s of every group; summed
+// (0+1)+(2+3) at the end, a fixed order that depends on K only).  The previous tile's stores ride in the first MFMA
+// chunk of the next tile.  Scheduling barriers pin this order: left alone, hipcc sinks every LDS read to just before
+// its first use and hoists the waits for the staged loads above the MFMA chain.
+// Work units = row groups x column tiles (4 x 593 for the paired logit product) dealt round-robin to one workgroup
+// per CU: 9.3 tiles per workgroup, 4096 MFMA cycles each.
+// The A fragments are read ONCE per workgroup, 16 rows x 64 B per load instruction: rows 2 KB apart fall on few L2
+// channels, and every workgroup of an XCD would walk K in the same order at the same time, so the waves start their
+// walk at different K offsets (rotation by 64 floats per (wave, walker parity)).
+//   operand layout as in gemm_walk16_kernel: lane l -> (i = l & 15, q = l >> 4); A: row i, k = 16g + 4q + s;
+//   B: column i likewise; D: 4 registers v: row 4q + v, column i.
+template <int NG, int R>
+__device__ __forceinline__ void ldsb_load_a(f32x4 (&af)[NG], const float* __restrict__ row) {
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        constexpr int dummy = 0; (void)dummy;
+        const int ii = (i + R) % NG;
+        af[ii] = *reinterpret_cast<const f32x4*>(row + 16 * ii);
+    }
+}
+
+template <int NG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_ldsb_walk_kernel(
+    cic_gemm_args g, int row_groups, int walkers) {
+    constexpr int K = 16 * NG, LDB = K + 4, TILE = 16 * LDB;
+    constexpr int CH = 8, NC = NG / CH;
+    constexpr int F4 = 16 * (K / 4) / 256;                 // float4 per thread and staged tile
+    static_assert(F4 == CH, "one staged float4 rides behind each MFMA group of the last chunk");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
+    const int li = lane & 15, lq = lane >> 4;
+    unsigned long long* stamps = g_stamp_buf;             // diagnostics: [workgroup][wave][64] phase stamps (100 MHz)
+    if (stamps) stamps += ((size_t)blockIdx.x * 4 + w) * 64;
+    int sidx = 0;
+    auto stamp = [&]() { if (stamps && lane == 0 && sidx < 60) stamps[sidx] = __builtin_amdgcn_s_memrealtime(); ++sidx; };
+    stamp();
+    // workgroups b, b+8, ... share an XCD: give the row groups that read the same weight tile at the same time
+    // consecutive ids on ONE XCD, so that a tile leaves HBM / the Infinity Cache once per launch
+    const int per_xcd = gridDim.x / 8;
+    const int wg = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * per_xcd + blockIdx.x / 8 : blockIdx.x;
+    const int rg = wg % row_groups, first = wg / row_groups;
+    if (first >= walkers) return;                          // whole workgroup: no barrier is skipped by a part of it
+    const int tiles_n = (g.N + 15) / 16;
+    // row blocks (see gemm_rega_kernel): each block is cut into its own groups of 64 rows, groups never straddle
+    const int rg_a = g.rows_blk > 0 ? (g.rows_blk + 63) / 64 : row_groups;
+    const bool blk2 = rg >= rg_a;
+    const int m0 = (blk2 ? rg - rg_a : rg) * 64;
+    const float* __restrict__ gA = blk2 ? g.A_b : g.A;
+    float* __restrict__ gC = blk2 ? g.C_b : g.C;
+    const int Mloc = g.rows_blk > 0 ? (blk2 ? g.M - g.rows_blk : min(g.M, g.rows_blk)) : g.M;
+    const int m = m0 + 16 * w + li;
+    const int mc = m < Mloc ? m : Mloc - 1;                // rows beyond M re-read row M-1: never stored
+
+    // staging: the tile is 16 rows of K floats = 16 * K/4 float4, dealt to the 256 threads row-major.  Rows beyond N
+    // re-read row N-1 (their columns are never stored; no select on the loaded value: it would make the wave wait for
+    // these loads before the MFMA chain instead of after it).
+    f32x4 stg[F4];
+    auto load_tile = [&](int t) {
+        const int tt = t < tiles_n ? t : tiles_n - 1;
+#pragma unroll
+        for (int e = 0; e < F4; ++e) {
+            const int j = tid + 256 * e;
+            const int r = j / (K / 4), c4 = j % (K / 4);
+            const int n = tt * 16 + r;
+            const int nc = n < g.N ? n : g.N - 1;
+            stg[e] = *reinterpret_cast<const f32x4*>(g.B + (size_t)nc * g.ldb + 4 * c4);
+        }
+    };
+    auto store_piece = [&](float* dst, int e) {
+        const int j = tid + 256 * e;
+        const int r = j / (K / 4), c4 = j % (K / 4);
+        *reinterpret_cast<f32x4*>(dst + r * LDB + 4 * c4) = stg[e];
+    };
+    load_tile(first);                                      // the first weight tile goes out before the A fragments
+    f32x4 af[NG];
+    {
+        const float* row = gA + (size_t)mc * g.lda + 4 * lq;
+        switch ((2 * w + (first & 1)) & 7) {
+            case 0: ldsb_load_a<NG, 0>(af, row); break;
+            case 1: ldsb_load_a<NG, 4>(af, row); break;
+            case 2: ldsb_load_a<NG, 8>(af, row); break;
+            case 3: ldsb_load_a<NG, 12>(af, row); break;
+            case 4: ldsb_load_a<NG, 16>(af, row); break;
+            case 5: ldsb_load_a<NG, 20>(af, row); break;
+            case 6: ldsb_load_a<NG, 24>(af, row); break;
+            default: ldsb_load_a<NG, 28>(af, row); break;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < F4; ++e) store_piece(lds, e);
+    __syncthreads();
+    stamp();
+    if (stamps && lane == 0) { stamps[60] = __builtin_amdgcn_s_memrealtime(); stamps[61] = __builtin_amdgcn_s_memtime(); }
+    int buf = 0;
+    f32x4acc prev[4];                                      // the previous tile's accumulators, stored under this tile's MFMAs
+    int prev_n = -1;
+    float prev_bias = 0.f;
+    auto store_row = [&](int v) {                          // output register v of the previous tile: row 4q + v, column i
+        const int mm = m0 + 16 * w + 4 * lq + v;
+        const float x = (prev[0][v] + prev[1][v]) + (prev[2][v] + prev[3][v]) + prev_bias;
+        if (prev_n >= 0 && mm < Mloc && prev_n < g.N) gC[(size_t)mm * g.ldc + prev_n] = x;
+    };
+#pragma unroll 1
+    for (int t = first; t < tiles_n; t += walkers) {
+        load_tile(t + walkers);                            // next tile's rows in flight under this tile's MFMAs
+        const int n = t * 16 + li;
+        const int ncl = n < g.N ? n : g.N - 1;
+        float bias_v = 0.f;
+        if (g.bias) bias_v = g.bias[ncl];
+        const float* bt = lds + buf * TILE + li * LDB + 4 * lq;
+        float* nxt = lds + (buf ^ 1) * TILE;               // every wave left this buffer before the last barrier
+        f32x4acc acc[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[s] = f32x4acc{0.f, 0.f, 0.f, 0.f};
+        f32x4 bq[2][CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) bq[0][i] = *reinterpret_cast<const f32x4*>(bt + 16 * i);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (c + 1 < NC) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) bq[(c + 1) & 1][i] = *reinterpret_cast<const f32x4*>(bt + 16 * ((c + 1) * CH + i));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c * CH + i][s], bq[c & 1][i][s], acc[s], 0, 0, 0);
+                if (c == 0 && i < 4) { store_row(i); __builtin_amdgcn_sched_barrier(0); }
+                if (c == NC - 1) { store_piece(nxt, i); __builtin_amdgcn_sched_barrier(0); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (stamps) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0])); stamp(); }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) prev[s] = acc[s];
+        prev_n = n;
+        prev_bias = bias_v;
+        if (stamps) stamp();
+        __syncthreads();
+        if (stamps) stamp();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) store_row(v);
+    if (stamps && lane == 0) { stamps[62] = __builtin_amdgcn_s_memrealtime(); stamps[63] = __builtin_amdgcn_s_memtime(); }
+}
+
+bool ldsb_walk_ok(const cic_gemm_args& g) {
+    return g.a_kc && g.b_kc && g.K2 == 0 && g.K == 512 && g.N >= 2048 && !g.accumulate && !g.relu &&
+           (g.lda & 3) == 0 && (g.ldb & 3) == 0 && aligned16(g.A) && aligned16(g.B) && (g.rows_blk == 0 || aligned16(g.A_b));
+}
+
+int launch_ldsb_walk(const cic_gemm_args& g, hipStream_t st) {
+    constexpr int NG = 32;
+    constexpr size_t lds_bytes = 2 * 16 * (16 * NG + 4) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb_walk_kernel<NG>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_set = true;
+    }
+    const int Mtot = g.M;
+    // row groups of 64; with row blocks each block is rounded up on its own (groups never straddle the blocks)
+    int row_groups;
+    if (g.rows_blk > 0) row_groups = cic_cdiv(g.rows_blk, 64) + cic_cdiv(Mtot - g.rows_blk, 64);
+    else row_groups = cic_cdiv(Mtot, 64);
+    const int tiles_n = cic_cdiv(g.N, 16);
+    int walkers = 256 / row_groups;                        // one workgroup per CU
+    if (walkers < 1) walkers = 1;
+    if (walkers > tiles_n) walkers = tiles_n;
+    int grid = row_groups * walkers;
+    hipLaunchKernelGGL((gemm_ldsb_walk_kernel<NG>), dim3(grid), dim3(256), lds_bytes, st, g, row_groups, walkers);
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+
 bool rega_ok(const cic_gemm_args& g) {
     if (!g.a_kc || g.M > (g.rows_blk > 0 ? 256 : 128)) return false;
     if (g.rows_blk > 0 && (!aligned16(g.A_b) || (g.K2 > 0 && !aligned16(g.A2_b)))) return false;
@@ -1002,6 +1188,7 @@ extern "C" int cic_debug_gemm_tail_split(int on) {
     g_force_tile = (on >> 8) & 0xff;
     g_walk = ((on >> 16) & 1) ? 0 : 1;
     g_walk16 = ((on >> 21) & 1) ? 0 : 1;
+    g_ldsb = ((on >> 22) & 1) ? 0 : 1;
     return 0;
 }
 
@@ -1035,6 +1222,10 @@ extern "C" int cic_gemm_f32(const cic_gemm_args* a, cic_stream_t s) {
         CIC_REQUIRE(g.K2 == 0 || g.A2_b);
         CIC_REQUIRE(rega_ok(g));     // only the register-streaming kernels address row blocks
     }
+    // the logit product of up to 256 rows (K = 512, many column tiles): weight tiles through LDS, no K split
+    // (tools/step_gemms.py: M = 256 as a pair 33.3 us vs 35.0 us, M = 128 20.0 vs 20.5; from M = 384 on the
+    // LDS-tiled kernels below win: 43.5 vs 47 us)
+    if (g_ldsb && ldsb_walk_ok(g) && g.M <= 256) return launch_ldsb_walk(g, cic_s(s));
     if (rega_ok(g)) return launch_rega(g, cic_s(s));
     if (g.M <= 128) {
         // per-timestep products: in-workgroup split-K (see gemm_skinny_kernel)

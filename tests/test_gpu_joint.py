@@ -179,3 +179,72 @@ def test_hip_graph_replay_matches_direct_launches():
             # rounding noise, which Adam's g / sqrt(v) turns into lr-sized steps of arbitrary sign in ANY implementation
             continue
         np.testing.assert_allclose(w1[k].numpy(), w0[k].numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
+
+
+@pytest.mark.timeout(600)
+def test_joint_step_full_size_matches_oracle():
+    """BASELINE configs[2] at its full size (B = 128, 36 x 2048 regions, vocabulary 9487, 16 steps, dropout 0.5,
+    ST-Gumbel + self-critical CIDEr-D): the HIP step against the CPU oracle on the same weights, batch, dropout masks
+    and Gumbel uniforms.  Loss and logged terms within 1e-4 relative, every parameter gradient within 1e-3 of its
+    norm (fp32, different summation order; the CIDEr reward is integer n-gram work and must agree exactly, which
+    it only does when every one of the 2 x 128 x 16 decoded tokens agrees)."""
+    from cooperativeimagecaptioning_amd import models, synthetic
+    from cooperativeimagecaptioning_amd.misc import rewards
+    from oracle import joint as J
+    rewards.init_scorer('corpus')
+    opt = synthetic.default_opt()
+    B, T, V, H, E = opt.batch_size, opt.seq_length, opt.vocab_size, opt.rnn_size, opt.input_encoding_size
+    torch.manual_seed(0)
+    model = models.AlternatingJointModel(opt)
+    model.caption_generator.logit.weight.data.mul_(3.0)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    batch = synthetic.make_batch(opt, seed=77)
+    g = torch.Generator().manual_seed(5)
+
+    def decode_noise(with_u):
+        d = dict(att_keep=(torch.rand(B, 36, H, generator=g) >= 0.5).float().numpy(),
+                 x_keep=(torch.rand(T + 1, B, E, generator=g) >= 0.5).float().numpy(),
+                 out_keep=(torch.rand(T + 1, B, H, generator=g) >= 0.5).float().numpy())
+        if with_u:
+            d['gumbel_u'] = torch.rand(T + 1, B, V + 1, generator=g).numpy()
+        return d
+    noise = {'sample': decode_noise(True), 'greedy': decode_noise(False)}
+
+    # oracle (CPU, torch autograd)
+    Ps = {k[len('caption_generator.'):]: v.clone().requires_grad_(True) for k, v in sd.items()
+          if k.startswith('caption_generator.')}
+    Pl = {k[len('vse.'):]: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith('vse.')}
+    cfg = dict(vars(opt))
+    tn = {t: {k: torch.from_numpy(v) for k, v in d.items()} for t, d in noise.items()}
+    ob = dict(fc_feats=batch['fc_feats'], att_feats=batch['att_feats'], att_masks=None, labels=batch['labels'],
+              masks=batch['masks'], gts=batch['gts'])
+    ref_loss, aux = J.joint_forward(Ps, Pl, cfg, ob, tn, 'speaker', True)
+    ref_loss.backward()
+
+    # HIP
+    model.cuda().train()
+    model.caption_generator.noise.override = noise
+    model.zero_grad()
+    loss = model(batch['fc_feats'].cuda(), batch['labels'].cuda(), batch['masks'].cuda(), batch,
+                 batch['att_feats'].cuda(), None, is_alternating=True, alternating_turn='speaker')
+    loss.backward()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(loss.detach()), float(ref_loss.detach()), rtol=1e-4, atol=1e-6)
+    logged = model.loss()
+    for k in ('avg_reward', 'cider_greedy'):
+        assert float(logged[k]) == pytest.approx(float(aux[k]), rel=1e-6, abs=1e-9), k     # f64 on both sides
+    np.testing.assert_allclose(float(logged['loss_cider']), float(aux['loss_cider']), rtol=1e-4, atol=1e-6)
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    checked = 0
+    for prefix, P in (('caption_generator.', Ps), ('vse.', Pl)):
+        for k, v in P.items():
+            if v.grad is None:
+                continue
+            got = grads[prefix + k].detach().cpu().double()
+            want = v.grad.double()
+            if k.endswith('alpha_net.bias'):     # a softmax shift: its gradient is mathematically 0, rounding noise
+                continue
+            err = float((got - want).norm() / want.norm())
+            assert err < 1e-3, (k, err)
+            checked += 1
+    assert checked >= 20

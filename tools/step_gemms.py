@@ -13,9 +13,15 @@ lib.cic_gemm_f32_timed.argtypes = [C.POINTER(GemmArgs), C.c_int, C.POINTER(C.c_d
 
 SHAPES = [  # name, M, N, K, K2, b_kc, accumulate
     ('h2att', 256, 512, 512, 0, 1, 0), ('i2h+h2h', 256, 2560, 512, 512, 1, 0), ('a2c', 256, 1024, 512, 0, 1, 1),
-    ('logit', 256, 9488, 512, 0, 1, 0), ('logit M128', 128, 9488, 512, 0, 1, 0), ('i2h+h2h M128', 128, 2560, 512, 512, 1, 0),
+    ('logit', 256, 9488, 512, 0, 1, 0), ('logit M128', 128, 9488, 512, 0, 1, 0), ('logit M512', 512, 9488, 512, 0, 1, 0),
+    ('logit M384', 384, 9488, 512, 0, 1, 0), ('logit M64', 64, 9488, 512, 0, 1, 0), ('i2h+h2h M128', 128, 2560, 512, 512, 1, 0),
     ('gru hh', 128, 3072, 1024, 0, 1, 0), ('dres', 128, 512, 1024, 0, 0, 0), ('dh', 128, 512, 2560, 512, 0, 0),
-    ('gru dh', 128, 1024, 3072, 0, 0, 1), ('lst img fc', 128, 1024, 2048, 0, 1, 0)]
+    ('gru dh', 128, 1024, 3072, 0, 0, 1), ('lst img fc', 128, 1024, 2048, 0, 1, 0),
+    # the BPTT dX products as the engines launch them (gradient products: K may be split over workgroups), and the
+    # same shapes with a K-contiguous (pre-transposed) weight
+    ('dres free', 128, 512, 1024, 0, 0, 2), ('dres free kc', 128, 512, 1024, 0, 1, 2),
+    ('dh free', 128, 512, 2560, 512, 0, 2), ('dh free kc', 128, 512, 2560, 512, 1, 2),
+    ('gru dh free', 128, 1024, 3072, 0, 0, 3), ('gru dh free kc', 128, 1024, 3072, 0, 1, 3)]
 
 
 def run(name, M, N, K, K2, bkc, acc, flag):
@@ -34,7 +40,7 @@ def run(name, M, N, K, K2, bkc, acc, flag):
         g.K2, g.A2, g.lda2, g.B2, g.ldb2 = K2, A2.data_ptr(), K2, B2.data_ptr(), (K2 if bkc else N)
         ref = ref + A2.double() @ (B2.t() if bkc else B2).double()
     g.C, g.ldc, g.accumulate = Cm.data_ptr(), N, 0
-    if M > 128:        # a decode pair: rows [M/2, M) through the second pointer set (same buffers here)
+    if 128 < M <= 256:        # a decode pair: rows [M/2, M) through the second pointer set (same buffers here)
         g.rows_blk = M // 2
         g.A_b, g.C_b = A.data_ptr() + 4 * (M // 2) * K, Cm.data_ptr() + 4 * (M // 2) * N
         if K2:
@@ -43,7 +49,9 @@ def run(name, M, N, K, K2, bkc, acc, flag):
     _lib.check(lib.cic_gemm_f32(C.byref(g), None), 'gemm')
     torch.cuda.synchronize()
     err = float((Cm.double() - ref).abs().max() / ref.abs().max())
-    g.accumulate = acc
+    g.accumulate = acc & 1
+    if acc & 2:
+        g.sum_order_free, g.c_is_zero = 1, 1
     us = C.c_double(0)
     _lib.check(lib.cic_gemm_f32_timed(C.byref(g), 200, C.byref(us), None), 'timed')
     lib.cic_debug_gemm_tail_split(1)
@@ -55,10 +63,12 @@ def main():
         name, M, N, K, K2 = sh[:5]
         fl = 2.0 * M * N * (K + K2)
         u1, e1 = run(*sh, flag=1)
-        u0, e0 = run(*sh, flag=1 | (1 << 16) | (1 << 21))
-        u2, e2 = run(*sh, flag=1 | (1 << 21))
-        print(f'{name:14s} M{M:4d} N{N:5d} K{K + K2:5d}  auto(walk16) {u1:7.2f} us ({fl / u1 / 1e6:6.1f} TF/s, err {e1:.1e})   '
-              f'walk32 {u2:7.2f} us   no-walk {u0:7.2f} us (err {e0:.1e})   mfma floor {fl / 157e6:5.2f} us')
+        u0, e0 = run(*sh, flag=1 | (1 << 16) | (1 << 21) | (1 << 22))
+        u2, e2 = run(*sh, flag=1 | (1 << 21) | (1 << 22))
+        u3, e3 = run(*sh, flag=1 | (1 << 22))
+        print(f'{name:14s} M{M:4d} N{N:5d} K{K + K2:5d}  auto {u1:7.2f} us ({fl / u1 / 1e6:6.1f} TF/s, err {e1:.1e})   '
+              f'no-ldsb {u3:7.2f} us   walk32 {u2:7.2f} us   no-walk {u0:7.2f} us (err {e0:.1e})   '
+              f'mfma floor {fl / 157e6:5.2f} us')
 
 
 if __name__ == '__main__':
