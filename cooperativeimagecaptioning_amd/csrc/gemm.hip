@@ -393,7 +393,8 @@ int launch_skinny(const cic_gemm_args& g, bool vec, hipStream_t st) {
 //   i.e. one float4 per group when the operand is K-contiguous (weights W[N,K], activations x[M,K]);
 //   a K-strided B (dX = dY W) is read as 4 row-coalesced dwords per group.
 // ---------------------------------------------------------------------------------------------
-__device__ unsigned long long* g_stamp_buf = nullptr;   // diagnostics: per-workgroup phase stamps (cic_debug_set_stamps)
+__device__ unsigned long long* g_stamp_buf = nullptr;
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // A operand of k's beyond K   // diagnostics: per-workgroup phase stamps (cic_debug_set_stamps)
 
 template <int KS, bool KCB>   // waves = KS (one 32-row strip per workgroup)
 __global__ __launch_bounds__(KS * 64) void gemm_rega_kernel(cic_gemm_args g, int gps) {
@@ -420,9 +421,12 @@ __global__ __launch_bounds__(KS * 64) void gemm_rega_kernel(cic_gemm_args g, int
     const int K1 = g.K, Kt = g.K + g.K2;
     const bool mok = m < Mloc, nok = n < g.N;
 
-    // Loads are UNCONDITIONAL (addresses clamped into the operand, results zeroed by a select): a branch
-    // around a load makes hipcc wait vmcnt(0) before the next MFMA chain, which serialises the prefetch.
+    // Loads are UNCONDITIONAL and nothing selects on a loaded value: rows / columns beyond M / N re-read the last
+    // valid one (their outputs are never stored), and a k beyond K reads A from a block of zeros (B from a clamped,
+    // valid k), so the padding contributes 0.  A select or a branch on the loaded data makes hipcc wait vmcnt(0)
+    // right behind each load, which serialises every round trip of the prefetch (measured: 2x on these launches).
     const int mc = mok ? m : Mloc - 1, nc = nok ? n : g.N - 1;
+    const float* zeros = g_zero16;
     auto load_chunk = [&](f32x4 (&af)[CH], f32x4 (&bf)[CH], int c) {
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
@@ -436,17 +440,15 @@ __global__ __launch_bounds__(KS * 64) void gemm_rega_kernel(cic_gemm_args g, int
             const int kp = second ? g.K2 : K1;
             int kk = second ? k - K1 : k;
             kk = kk < kp - 4 ? kk : kp - 4;
-            f32x4 a = *reinterpret_cast<const f32x4*>(A + (size_t)mc * lda + kk);
-            f32x4 b;
+            const float* pa = A + (size_t)mc * lda + kk;
+            pa = kok ? pa : zeros;
+            af[i] = *reinterpret_cast<const f32x4*>(pa);
             if (KCB) {
-                b = *reinterpret_cast<const f32x4*>(B + (size_t)nc * ldb + kk);
+                bf[i] = *reinterpret_cast<const f32x4*>(B + (size_t)nc * ldb + kk);
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) b[j] = B[(size_t)(kk + j) * ldb + nc];
+                for (int j = 0; j < 4; ++j) bf[i][j] = B[(size_t)(kk + j) * ldb + nc];
             }
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            af[i] = (kok && mok) ? a : z;
-            bf[i] = (kok && nok) ? b : z;
         }
     };
     f32x16 acc;

@@ -553,6 +553,11 @@ __device__ __forceinline__ float gumbel_from_u(float u) {
 template <int RV>   // RV float4 per thread: rows up to RV*4096 floats
 __global__ __launch_bounds__(SNW * 64) void logsoftmax_sample_kernel(cic_sampler_args a0, cic_sampler_args a1) {
     constexpr int NT = SNW * 64;
+    unsigned long long* stamps = g_attn_stamps;          // diagnostics: [row][wave][8] phase stamps (100 MHz)
+    if (stamps) stamps += ((size_t)blockIdx.x * SNW + (threadIdx.x >> 6)) * 8;
+    int sidx = 0;
+    auto stamp = [&]() { if (stamps && (threadIdx.x & 63) == 0 && sidx < 8) stamps[sidx] = __builtin_amdgcn_s_memrealtime(); ++sidx; };
+    stamp();
     __shared__ float shf[SNW];
     __shared__ int shi[SNW];
     __shared__ float sh3[3 * SNW];
@@ -576,43 +581,83 @@ __global__ __launch_bounds__(SNW * 64) void logsoftmax_sample_kernel(cic_sampler
                                ? (ss_on && !a.ss_pick)
                                : ((a.mode != CIC_SAMPLE_GREEDY && a.mode != CIC_SAMPLE_NONE) && !(a.pick && !gumbel_mode));
     float un[RV][4];
-#pragma unroll
-    for (int r = 0; r < RV; ++r)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int col = 4 * (tid + NT * r) + e;
-            un[r][e] = (use_noise && (tid + NT * r) < nq && col < V1) ? urow[col] : 0.5f;
-        }
     float mx = -INFINITY;
+    // Fast path (rows of whole, 16-byte aligned float4: the vocabulary rows of the engines): EVERY load of the row and
+    // of its noise goes out before the first use, unconditionally (threads beyond the row re-read its last float4 and
+    // mask the values afterwards).  Element loads under `col < V1` conditions compile to one load + s_waitcnt vmcnt(0)
+    // per element, i.e. 15 serial memory round trips at RV = 3 (measured: 17.4 us per launch with them).
+    const bool fast = vec && (V1 & 3) == 0 &&
+                      (!use_noise || (((a.ldu & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.U) & 15) == 0)));
+    if (fast) {
+        f32x4 xv[RV], uv[RV];
 #pragma unroll
-    for (int r = 0; r < RV; ++r) {
-        const int q = tid + NT * r;
+        for (int r = 0; r < RV; ++r) {
+            const int q = tid + NT * r;
+            xv[r] = reinterpret_cast<const f32x4*>(row)[q < nq ? q : nq - 1];
+        }
+        if (use_noise) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) x[r][e] = -INFINITY;
-        if (q < nq) {
-            if (vec && 4 * q + 3 < V1) {
-                const f32x4 v = reinterpret_cast<const f32x4*>(row)[q];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) x[r][e] = v[e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (4 * q + e < V1) x[r][e] = row[4 * q + e];
+            for (int r = 0; r < RV; ++r) {
+                const int q = tid + NT * r;
+                uv[r] = reinterpret_cast<const f32x4*>(urow)[q < nq ? q : nq - 1];
             }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RV; ++r) uv[r] = f32x4{0.5f, 0.5f, 0.5f, 0.5f};
+        }
+#pragma unroll
+        for (int r = 0; r < RV; ++r) {
+            const int q = tid + NT * r;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (4 * q + e == cons) x[r][e] = -INFINITY;   // decoding_constraint, AttModel.py:438-442
-                mx = fmaxf(mx, x[r][e]);
+                float xe = q < nq ? xv[r][e] : -INFINITY;
+                if (4 * q + e == cons) xe = -INFINITY;        // decoding_constraint, AttModel.py:438-442
+                x[r][e] = xe;
+                un[r][e] = uv[r][e];                          // beyond the row: never used (z = -inf there)
+                mx = fmaxf(mx, xe);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < RV; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int col = 4 * (tid + NT * r) + e;
+                un[r][e] = (use_noise && (tid + NT * r) < nq && col < V1) ? urow[col] : 0.5f;
+            }
+#pragma unroll
+        for (int r = 0; r < RV; ++r) {
+            const int q = tid + NT * r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[r][e] = -INFINITY;
+            if (q < nq) {
+                if (vec && 4 * q + 3 < V1) {
+                    const f32x4 v = reinterpret_cast<const f32x4*>(row)[q];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[r][e] = v[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (4 * q + e < V1) x[r][e] = row[4 * q + e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (4 * q + e == cons) x[r][e] = -INFINITY;   // decoding_constraint, AttModel.py:438-442
+                    mx = fmaxf(mx, x[r][e]);
+                }
             }
         }
     }
+    if (stamps) { asm volatile("" :: "v"(mx)); stamp(); }
     mx = block_max(mx, shf);
+    stamp();
     float se = 0.f;
 #pragma unroll
     for (int r = 0; r < RV; ++r)
 #pragma unroll
         for (int e = 0; e < 4; ++e) se += __expf(x[r][e] - mx);   // exp(-inf) = 0 for padding
     se = block_sum(se, shf);
+    stamp();
     const float lse = mx + logf(se);
     // log-probs back to memory (saved for the backward pass) and kept in registers
 #pragma unroll
@@ -620,7 +665,9 @@ __global__ __launch_bounds__(SNW * 64) void logsoftmax_sample_kernel(cic_sampler
         const int q = tid + NT * r;
 #pragma unroll
         for (int e = 0; e < 4; ++e) x[r][e] -= lse;
-        if (q < nq) {
+        if (fast) {
+            if (q < nq) reinterpret_cast<f32x4*>(row)[q] = f32x4{x[r][0], x[r][1], x[r][2], x[r][3]};
+        } else if (q < nq) {
             if (vec && 4 * q + 3 < V1) {
                 f32x4 v = {x[r][0], x[r][1], x[r][2], x[r][3]};
                 reinterpret_cast<f32x4*>(row)[q] = v;
@@ -658,7 +705,9 @@ __global__ __launch_bounds__(SNW * 64) void logsoftmax_sample_kernel(cic_sampler
             best = amax_better(best, ArgMax{zz, col});
         }
     }
+    if (stamps) { asm volatile("" :: "v"(best.v)); stamp(); }
     best = block_argmax(best, shf, shi);
+    stamp();
     int it = best.i;
     int it_feed = -1;                                   // teacher mode: token fed to the next step
     if (a.mode == CIC_SAMPLE_TEACHER) {
@@ -693,6 +742,7 @@ __global__ __launch_bounds__(SNW * 64) void logsoftmax_sample_kernel(cic_sampler
                 if (4 * (tid + NT * r) + e == it) zi = z[r][e];
             }
         block_sum3(slp_part, s2, zi, sh3);
+        stamp();
         slp = slp_part;
         const float y = __expf(zi - zm) / s2;
         v = (1.0f - y) + y;    // (y_hard - y).detach() + y at the arg-max entry, gumbel.py:28
@@ -775,6 +825,7 @@ __global__ __launch_bounds__(SNW * 64) void logsoftmax_sample_kernel(cic_sampler
         if (a.stv) a.stv[(size_t)b * a.seq_ld + (t - 1)] = unf ? v : 1.0f;   // finished rows -> exact EOS one-hot (:419-420)
         if (unf) atomicOr(a.any_unfinished + t, 1);
     }
+    stamp();
 }
 
 // L = number of appended columns: the reference breaks at the first t >= 1 whose unfinished

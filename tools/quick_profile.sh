@@ -1,0 +1,16 @@
+#!/bin/bash
+# Kernel trace of 10 bench steps -> per-kernel step breakdown (no tests, no PMC).  usage: bash tools/quick_profile.sh <tag>
+set -e
+tag=${1:-q}
+R=$(pwd)
+out=$R/gpurun_out/$tag
+mkdir -p $out
+export TMPDIR=/tmp
+cd /tmp
+rocprofv3 --kernel-trace --output-format csv -d $out/trace -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_rocprof.json 2> $out/trace.err
+cd $R
+kt=$(find $out/trace -name '*kernel_trace.csv' | head -1)
+python tools/trace_summary.py $kt 10 $out/step_breakdown.md > $out/trace_summary.log
+rm -rf $out/trace
+python bench.py --steps 30 --warmup 5 --no-cpu-baseline > $out/bench.json 2>/dev/null
+grep -o 'ms_per_step": [0-9.]*' $out/bench.json
