@@ -65,29 +65,74 @@ __global__ __launch_bounds__(SNW * 64) void sampler_bwd_kernel(const float* __re
     const bool st_mode = (mode == CIC_SAMPLE_GUMBEL_ST || mode == CIC_SAMPLE_MULTINOMIAL_ST);
     const bool unf = st_mode && g && seq && t < L && seq[(size_t)b * T + t] > 0;
     const int nq = (V1 + 3) >> 2;
+    // rows of whole, 16-byte aligned float4 (the vocabulary rows of the engines): float4 traffic, and every load of the
+    // row goes out before the first use (element loads under column conditions compile to one load + full wait each:
+    // 36 serial round trips per thread at RV = 3)
+    const bool fast = (V1 & 3) == 0 && ((reinterpret_cast<uintptr_t>(logp_all) | reinterpret_cast<uintptr_t>(dlogits) |
+                                         reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(U)) & 15) == 0;
     if (!unf && ds == 0.f) {   // block-uniform: nothing flows into this row
-        for (int c = tid; c < V1; c += NT) out[c] = 0.f;
+        if (fast) {
+            for (int q = tid; q < nq; q += NT) reinterpret_cast<f32x4*>(out)[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            for (int c = tid; c < V1; c += NT) out[c] = 0.f;
+        }
         return;
     }
     const float inv_t = 1.0f / tau;
     const float* urow = U ? U + ((size_t)(t + 1) * B + b) * V1 : nullptr;
     float x[RV][4], y[RV][4], gg[RV][4];
     float zm = -INFINITY;
+    if (fast) {
+        const bool gum = unf && mode == CIC_SAMPLE_GUMBEL_ST;
+        f32x4 xv[RV], gv[RV], uv[RV];
 #pragma unroll
-    for (int r = 0; r < RV; ++r)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = 4 * (tid + NT * r) + e;
-            const bool ok = (tid + NT * r) < nq && c < V1;
-            x[r][e] = ok ? lp[c] : -INFINITY;
-            gg[r][e] = (ok && unf) ? g[c] : 0.f;
-            float z = -INFINITY;
-            if (ok && unf) {
-                z = (mode == CIC_SAMPLE_GUMBEL_ST) ? (x[r][e] + gumbel_from_u(urow[c])) * inv_t : x[r][e] * inv_t;
-            }
-            y[r][e] = z;
-            zm = fmaxf(zm, z);
+        for (int r = 0; r < RV; ++r) {
+            const int q = tid + NT * r;
+            xv[r] = reinterpret_cast<const f32x4*>(lp)[q < nq ? q : nq - 1];
         }
+        if (unf) {
+#pragma unroll
+            for (int r = 0; r < RV; ++r) {
+                const int q = tid + NT * r;
+                gv[r] = reinterpret_cast<const f32x4*>(g)[q < nq ? q : nq - 1];
+            }
+        }
+        if (gum) {
+#pragma unroll
+            for (int r = 0; r < RV; ++r) {
+                const int q = tid + NT * r;
+                uv[r] = reinterpret_cast<const f32x4*>(urow)[q < nq ? q : nq - 1];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RV; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = (tid + NT * r) < nq;
+                x[r][e] = ok ? xv[r][e] : -INFINITY;
+                gg[r][e] = (ok && unf) ? gv[r][e] : 0.f;
+                float z = -INFINITY;
+                if (ok && unf) z = gum ? (x[r][e] + gumbel_from_u(uv[r][e])) * inv_t : x[r][e] * inv_t;
+                y[r][e] = z;
+                zm = fmaxf(zm, z);
+            }
+    } else {
+#pragma unroll
+        for (int r = 0; r < RV; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 4 * (tid + NT * r) + e;
+                const bool ok = (tid + NT * r) < nq && c < V1;
+                x[r][e] = ok ? lp[c] : -INFINITY;
+                gg[r][e] = (ok && unf) ? g[c] : 0.f;
+                float z = -INFINITY;
+                if (ok && unf) {
+                    z = (mode == CIC_SAMPLE_GUMBEL_ST) ? (x[r][e] + gumbel_from_u(urow[c])) * inv_t : x[r][e] * inv_t;
+                }
+                y[r][e] = z;
+                zm = fmaxf(zm, z);
+            }
+    }
     float cdot = 0.f, ysum = 1.f;
     if (unf) {
         zm = block_max4(zm, sh);
@@ -112,17 +157,19 @@ __global__ __launch_bounds__(SNW * 64) void sampler_bwd_kernel(const float* __re
         cdot = block_sum4(c, sh);
     }
 #pragma unroll
-    for (int r = 0; r < RV; ++r)
+    for (int r = 0; r < RV; ++r) {
+        f32x4 o4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int c = 4 * (tid + NT * r) + e;
-            if ((tid + NT * r) < nq && c < V1) {
-                float v = 0.f;
-                if (unf) v = y[r][e] * (gg[r][e] - cdot) * inv_t;
-                if (ds != 0.f) v += ds * ((c == it ? 1.f : 0.f) - __expf(x[r][e]));
-                out[c] = v;
-            }
+            float v = 0.f;
+            if (unf) v = y[r][e] * (gg[r][e] - cdot) * inv_t;
+            if (ds != 0.f) v += ds * ((c == it ? 1.f : 0.f) - __expf(x[r][e]));
+            o4[e] = v;
+            if (!fast && (tid + NT * r) < nq && c < V1) out[c] = v;
         }
+        if (fast && (tid + NT * r) < nq) reinterpret_cast<f32x4*>(out)[tid + NT * r] = o4;
+    }
 }
 
 
