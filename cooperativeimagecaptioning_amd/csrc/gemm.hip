@@ -225,22 +225,56 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(cic_gemm_args g, int 
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * (BN / WN) + j * 32 + r;
-            if (n >= g.N) continue;
-            const float bv = (g.bias && slice == 0) ? g.bias[n] : 0.f;
+            const bool nok = n < g.N;
+            const int nc = nok ? n : g.N - 1;
+            const float bv = (g.bias && slice == 0) ? g.bias[nc] : 0.f;
+            if (nslice > 1) {                    // block-uniform
+                // (values finished on the straight-line path, see below: an add of the loaded bias inside the
+                // bounds-checked blocks made every atomic wait for the completion of the previous one)
+                float va[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = acc[i][j][e] + bv;
+                    asm volatile("" : "+v"(v));
+                    va[e] = v;
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    // no-return global_atomic_add_f32, executed at the memory side
+                    if (m < g.M && nok) atomicAdd(g.C + (size_t)m * g.ldc + n, va[e]);
+                }
+                continue;
+            }
+            // C += ...: the 16 old values of this 32x32 block are fetched in ONE batch of unconditional loads (rows and
+            // columns beyond the matrix re-read its last ones); a load under the bounds check of each element compiled
+            // to load + full wait + store per element, 64 serial memory round trips per thread in a 128x128 tile
+            float cold[16];
+            if (g.accumulate) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    cold[e] = g.C[(size_t)(m < g.M ? m : g.M - 1) * g.ldc + nc];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) cold[e] = 0.f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the sums are finished on the straight-line path (the empty asm keeps them there): computed inside the
+            // bounds-checked store blocks, every block would wait for ALL earlier memory operations, stores included
+            float vv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[i][j][e] + bv + cold[e];
+                if (g.relu) v = fmaxf(v, 0.f);
+                asm volatile("" : "+v"(v));
+                vv[e] = v;
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (m < g.M) {
-                    float* c = g.C + (size_t)m * g.ldc + n;
-                    float v = acc[i][j][e] + bv;
-                    if (nslice > 1) {
-                        atomicAdd(c, v);         // no-return global_atomic_add_f32, executed at the memory side
-                    } else {
-                        if (g.accumulate) v += *c;
-                        if (g.relu) v = fmaxf(v, 0.f);
-                        *c = v;
-                    }
-                }
+                if (m < g.M && nok) g.C[(size_t)m * g.ldc + n] = vv[e];
             }
         }
 }
