@@ -21,6 +21,37 @@ __global__ void add_vec_kernel(const float* a, const float* b, float* o, int n) 
     if (i < n) o[i] = a[i] + b[i];
 }
 
+// Start-of-decode state of up to two decodes in ONE launch (was: three memsets, two fills and a vector add per decode,
+// ~5 us each): zero (h_0, c_0) (init_hidden, AttModel.py:311), clear the any-unfinished flags, unfinished = 1,
+// first token = <bos> (= vocab_size + 1, :324-326) or the caller's column (AttModel.forward: seq[:, 0], :131), and the
+// summed bias of the i2h / h2h products.
+struct DecodeInit {
+    float* h;                  // [B,H] or null
+    float* c;                  // [B,H] or null
+    int32_t* any_unf;          // [T+1]
+    int32_t* unfinished;       // [B]
+    int32_t* it;               // [B]
+    const int64_t* first_token;   // [B] or null
+    float* bias_ih;            // [5H]
+};
+__global__ __launch_bounds__(256) void decode_init_kernel(DecodeInit a, DecodeInit b, const float* __restrict__ i2h_b,
+                                                          const float* __restrict__ h2h_b, int BH4, int B, int T1, int H5,
+                                                          int bos) {
+    const DecodeInit d = blockIdx.y ? b : a;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    if (i < BH4) {
+        if (d.h) reinterpret_cast<f32x4*>(d.h)[i] = z4;
+        if (d.c) reinterpret_cast<f32x4*>(d.c)[i] = z4;
+    }
+    if (i < T1) d.any_unf[i] = 0;
+    if (i < B) {
+        d.unfinished[i] = 1;
+        d.it[i] = d.first_token ? (int32_t)d.first_token[i] : bos;
+    }
+    if (i < H5) d.bias_ih[i] = i2h_b[i] + h2h_b[i];
+}
+
 }  // namespace
 
 int cic_fill_i32(int32_t* p, int n, int32_t v, hipStream_t st) {
@@ -160,29 +191,36 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         w[q] = spk_carve(d, wss[q]);
         CIC_REQUIRE(ws_bytes[q] >= w[q].bytes);
         CIC_REQUIRE((fc || io[q]->att_pre) && io[q]->seq && io[q]->slp && io[q]->L && !(fc && psq));
-        RUN(cic_add_vec(p->i2h_b, p->h2h_b, w[q].bias_ih, 5 * H, st));
+    }
+    {
+        DecodeInit di[2] = {};
+        for (int q = 0; q < nb; ++q) {
+            // fc: the image step below produces (h_0, c_0) from a zero state held in `zeros`
+            di[q].h = fc ? w[q].zeros : w[q].h_all;
+            di[q].c = fc ? nullptr : w[q].c_all;
+            di[q].any_unf = w[q].any_unf; di[q].unfinished = w[q].unfinished; di[q].it = w[q].it_all;
+            di[q].first_token = io[q]->first_token; di[q].bias_ih = w[q].bias_ih;
+        }
+        const int BH4 = B * H / 4;
+        int span = BH4 > 5 * H ? BH4 : 5 * H;
+        if (span < T + 1) span = T + 1;
+        if (span < B) span = B;
+        hipLaunchKernelGGL(decode_init_kernel, dim3(cic_cdiv(span, 256), nb), dim3(256), 0, st, di[0], di[1], p->i2h_b, p->h2h_b,
+                           BH4, B, T + 1, 5 * H, d.V + 1);
+        CIC_LAUNCH_CHECK();
+    }
+    for (int q = 0; q < nb; ++q) {
         if (!fc) {
             // att = dropout(relu(att_embed(att_raw)));  p_att = ctx2att(att)      (AttModel.py:315,319)
             RUN(cic_apply_keep(io[q]->att_pre, io[q]->att_keep, io[q]->att_keep ? p_drop : 0.f, w[q].att, (int64_t)B * K * H, s));
             RUN(gemm_nt(w[q].att, H, p->ctx2att_w, H, w[q].p_att, A, B * K, A, H, p->ctx2att_b, false, false, st));
-            CIC_HIP(hipMemsetAsync(w[q].h_all, 0, sizeof(float) * B * H, st));          // init_hidden (:311)
-            CIC_HIP(hipMemsetAsync(w[q].c_all, 0, sizeof(float) * B * H, st));
         } else {
             // image step: (h0, c0) = LSTMCore(img_embed(fc_feats), zero state)          (FCModel.py:97-99,121,274-276,315)
             // h = 0, so h2h contributes its bias only (already in bias_ih)
-            CIC_HIP(hipMemsetAsync(w[q].zeros, 0, sizeof(float) * B * H, st));
             RUN(gemm_nt(io[q]->x0, E, p->i2h_w, E, w[q].pre_img, 5 * H, B, 5 * H, E, w[q].bias_ih, false, false, st));
             RUN(cic_cell_fwd2(dual1((const float*)w[q].pre_img), dual1((const float*)w[q].zeros), dual1(io[q]->out_keep),
                               io[q]->out_keep ? p_drop : 0.f, dual1(w[q].h_all), dual1(w[q].c_all), dual1(w[q].out_all), B, 1,
                               H, st, 1));
-        }
-        CIC_HIP(hipMemsetAsync(w[q].any_unf, 0, sizeof(int32_t) * (T + 1), st));
-        RUN(cic_fill_i32(w[q].unfinished, B, 1, st));
-        if (io[q]->first_token) {                                                    // AttModel.forward: seq[:, 0]  (:131)
-            hipLaunchKernelGGL(i64_to_i32_kernel, dim3(cic_cdiv(B, 256)), dim3(256), 0, st, io[q]->first_token, w[q].it_all, B);
-            CIC_LAUNCH_CHECK();
-        } else {
-            RUN(cic_fill_i32(w[q].it_all, B, d.V + 1, st));                          // <bos> = vocab_size + 1 (:324-326)
         }
     }
     if (nb == 1) w[1] = SpkWs{};                      // all-null second set
