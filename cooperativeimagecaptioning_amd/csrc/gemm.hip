@@ -26,6 +26,7 @@ int g_force_tile = 0;   // bits 8..15: 1 = 128x128, 2 = 64x64 tiles forced
 int g_walk = 1;         // bit 16 set: strip walkers off
 int g_walk16 = 1;       // bit 21 set: 16-wide strip walkers off
 int g_ldsb = 1;         // bit 22 set: LDS-staged column walker (K = 512 logit product) off
+int g_split_rows = 1;   // bit 23 set: 129..256-row products are not handed to the register-streaming kernels as two row blocks
 
 constexpr int BK = 32;
 constexpr int KCS = BK + 4;  // row stride of a K-contiguous LDS image (floats)
@@ -1225,6 +1226,7 @@ extern "C" int cic_debug_gemm_tail_split(int on) {
     g_walk = ((on >> 16) & 1) ? 0 : 1;
     g_walk16 = ((on >> 21) & 1) ? 0 : 1;
     g_ldsb = ((on >> 22) & 1) ? 0 : 1;
+    g_split_rows = ((on >> 23) & 1) ? 0 : 1;
     return 0;
 }
 
@@ -1251,6 +1253,19 @@ extern "C" int cic_gemm_f32(const cic_gemm_args* a, cic_stream_t s) {
             if (int rc = cic_colsum_f32(g.A, g.K, g.M, g.lda, g.colsum_A, 1, s)) return rc;
             if (g.colsum_A2) { if (int rc = cic_colsum_f32(g.A, g.K, g.M, g.lda, g.colsum_A2, 1, s)) return rc; }
             return cic_gemm_f32(&g2, s);
+        }
+    }
+    if (g.rows_blk == 0 && g_split_rows && g.a_kc && g.M > 128 && g.M <= 256 && !g.colsum_A) {
+        // 129..256 rows of K-contiguous activations (a per-timestep product of a B = 256 decode): the register-streaming
+        // kernels address two row blocks, so hand them the matrix as two halves (same arithmetic per row)
+        cic_gemm_args h2 = g;
+        h2.rows_blk = 128;
+        h2.A_b = g.A + (size_t)128 * g.lda;
+        h2.C_b = g.C + (size_t)128 * g.ldc;
+        if (g.K2 > 0) h2.A2_b = g.A2 + (size_t)128 * g.lda2;
+        if (rega_ok(h2)) {
+            if (g_ldsb && ldsb_walk_ok(h2)) return launch_ldsb_walk(h2, cic_s(s));
+            return launch_rega(h2, cic_s(s));
         }
     }
     if (g.rows_blk > 0) {

@@ -47,6 +47,9 @@ def run(name, steps, turns, **kw):
 
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    if os.environ.get('CIC_GEMM_FLAGS') is not None:       # A/B measurement of the GEMM dispatch switches
+        from cooperativeimagecaptioning_amd import engine
+        engine.lib.cic_debug_gemm_tail_split(int(os.environ['CIC_GEMM_FLAGS'], 0))
     run('C3 joint gumbel + CIDEr-D', steps, ['speaker'], batch_size=128)
     run('C2 att2in2 MLE', steps, [None], batch_size=64, is_alternating=0, phase=2, caption_loss_weight=1.0,
         retrieval_reward_weight=0.0, cider_optimization=0, alternating_turn=None)
