@@ -26,6 +26,7 @@ int g_force_tile = 0;   // bits 8..15: 1 = 128x128, 2 = 64x64 tiles forced
 int g_walk = 1;         // bit 16 set: strip walkers off
 int g_walk16 = 1;       // bit 21 set: 16-wide strip walkers off
 int g_ldsb = 1;         // bit 22 set: LDS-staged column walker (K = 512 logit product) off
+int g_rega2 = 1;        // bit 24 set: two-strip dX kernel (gemm_rega2_kernel) off
 int g_split_rows = 1;   // bit 23 set: 129..256-row products are not handed to the register-streaming kernels as two row blocks
 
 constexpr int BK = 32;
@@ -538,6 +539,110 @@ __global__ __launch_bounds__(KS * 64) void gemm_rega_kernel(cic_gemm_args g, int
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         o[5] = xcc;
+    }
+}
+
+
+// Two-strip variant for the BPTT dX products (dX = dY W, W stored [K, N]: the K-strided B operand is the expensive
+// one, four row-coalesced dword loads per group): a workgroup owns 64 rows x 32 columns, every B fragment feeds the
+// MFMA chains of BOTH 32-row strips.  These launches are bound by the bytes a CU has to pull in (~15 B/clk per CU with
+// every CU loading): per unit of output a workgroup reads (64 + 32) k-columns instead of 2 x (32 + 32), 25 % fewer
+// bytes and 40 % fewer load instructions, at twice the K split over workgroups (float atomics, gradient products
+// only).  K slices of CH groups, register double buffer as in gemm_rega_kernel; the 16 x 32 partial accumulator
+// registers of a tile meet in 128 KB of LDS and every wave finishes two of them.
+template <int KS, int CH>
+__global__ __launch_bounds__(KS * 64) void gemm_rega2_kernel(cic_gemm_args g, int gps) {
+    static_assert(KS == 16, "32 accumulator registers dealt two per wave");
+    extern __shared__ __attribute__((aligned(16))) float red2[];   // KS * 32 * 64 floats
+    const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
+    const int h = lane >> 5, r = lane & 31;
+    const int tiles_n = (g.N + 31) / 32;
+    int m0 = (blockIdx.x / tiles_n) * 64;
+    const int n0 = (blockIdx.x % tiles_n) * 32;
+    const bool blk2 = g.rows_blk > 0 && m0 >= g.rows_blk;   // row blocks (rows_blk % 64 == 0): see gemm_rega_kernel
+    const float* __restrict__ gA = blk2 ? g.A_b : g.A;
+    const float* __restrict__ gA2 = blk2 ? g.A2_b : g.A2;
+    float* __restrict__ gC = blk2 ? g.C_b : g.C;
+    const int Mloc = g.rows_blk > 0 ? (blk2 ? g.M - g.rows_blk : min(g.M, g.rows_blk)) : g.M;
+    if (blk2) m0 -= g.rows_blk;
+    const int n = n0 + r;
+    const int K1 = g.K, Kt = g.K + g.K2;
+    const bool nok = n < g.N;
+    const int nc = nok ? n : g.N - 1;
+    int mc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) mc[t] = (m0 + 32 * t + r) < Mloc ? (m0 + 32 * t + r) : Mloc - 1;
+    const float* zeros = g_zero16;
+    // unconditional loads, no select on loaded values (see gemm_rega_kernel)
+    auto load_chunk = [&](f32x4 (&af)[2][CH], f32x4 (&bf)[CH], int c) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int k = 8 * ((blockIdx.y * KS + ks) * gps + c * CH + i) + 4 * h;
+            const bool kok = k < Kt;
+            const bool second = kok && k >= K1;
+            const float* A = second ? gA2 : gA;
+            const float* B = second ? g.B2 : g.B;
+            const int lda = second ? g.lda2 : g.lda, ldb = second ? g.ldb2 : g.ldb;
+            const int kp = second ? g.K2 : K1;
+            int kk = second ? k - K1 : k;
+            kk = kk < kp - 4 ? kk : kp - 4;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float* pa = A + (size_t)mc[t] * lda + kk;
+                pa = kok ? pa : zeros;
+                af[t][i] = *reinterpret_cast<const f32x4*>(pa);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[i][j] = B[(size_t)(kk + j) * ldb + nc];
+        }
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    auto mma_chunk = [&](const f32x4 (&af)[2][CH], const f32x4 (&bf)[CH]) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][i][s], bf[i][s], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][i][s], bf[i][s], acc[1], 0, 0, 0);
+            }
+    };
+    const int nch = gps / CH;
+    f32x4 a0[2][CH], b0[CH], a1[2][CH], b1[CH];
+    load_chunk(a0, b0, 0);
+#pragma unroll 1
+    for (int c = 0; c < nch; c += 2) {
+        if (c + 1 < nch) load_chunk(a1, b1, c + 1);
+        mma_chunk(a0, b0);
+        if (c + 2 < nch) load_chunk(a0, b0, c + 2);
+        if (c + 1 < nch) mma_chunk(a1, b1);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red2[(ks * 32 + 16 * t + e) * 64 + lane] = acc[t][e];
+    __syncthreads();
+    // wave ks sums registers ks and ks + 16 of the 32 (strip 0 / strip 1, accumulator register ks) over the KS partial
+    // tiles in a fixed order; the K parts of different workgroups then meet in C through float atomics
+    float bias_v = 0.f;
+    if (g.bias && blockIdx.y == 0) bias_v = g.bias[nc];
+    float v2[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < KS; ++q) v += red2[(q * 32 + 16 * t + ks) * 64 + lane];
+        v += bias_v;
+        asm volatile("" : "+v"(v));          // finished outside the bounds-checked block (see the gemm_kernel epilogue)
+        v2[t] = v;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int mm = m0 + 32 * t + (ks & 3) + 8 * (ks >> 2) + 4 * h;
+        if (mm < Mloc && nok) atomicAdd(gC + (size_t)mm * g.ldc + n, v2[t]);
     }
 }
 
@@ -1126,6 +1231,33 @@ int launch_rega(const cic_gemm_args& g, hipStream_t st) {
     // which the caller allows for gradient products (sum_order_free) whose C accumulates or is already zero
     // (c_is_zero: the caller or the producing kernel cleared it).
     int ky = 1, gps_y = gps;
+    // dX products of the BPTT loops (K-strided weights, gradient sums): 64-row tiles, the B fragments shared by two strips
+    if (g_rega2 && g_tail_split && !g.b_kc && g.sum_order_free && !g.relu && (g.accumulate || g.c_is_zero) && groups >= 128 &&
+        (g.rows_blk % 64) == 0 && g.M >= 64) {
+        const int strips64 = g.rows_blk > 0 ? g.rows_blk / 64 + cic_cdiv(g.M - g.rows_blk, 64) : cic_cdiv(g.M, 64);
+        const int grid2 = strips64 * tiles_n;
+        int ky2 = 256 / grid2;
+        if (ky2 > groups / 32) ky2 = groups / 32;      // at least 2 groups (16 k) per wave
+        if (ky2 > 16) ky2 = 16;
+        if (grid2 <= 128 && ky2 >= 2) {
+            const int per = cic_cdiv(groups, 16 * ky2);          // groups per wave
+            const int ch = (per % 3 == 0 && per % 2 != 0) ? 3 : 2;
+            const int gps2 = cic_cdiv(per, ch) * ch;
+            constexpr size_t lds_bytes = 16 * 32 * 64 * sizeof(float);
+            static bool attr_set = false;
+            if (!attr_set) {
+                CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rega2_kernel<16, 2>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rega2_kernel<16, 3>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                attr_set = true;
+            }
+            if (ch == 3) hipLaunchKernelGGL((gemm_rega2_kernel<16, 3>), dim3(grid2, ky2), dim3(1024), lds_bytes, st, g, gps2);
+            else hipLaunchKernelGGL((gemm_rega2_kernel<16, 2>), dim3(grid2, ky2), dim3(1024), lds_bytes, st, g, gps2);
+            CIC_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (g_tail_split && g.sum_order_free && !g.relu && (g.accumulate || g.c_is_zero) && grid <= 128 && groups >= 128) {
         ky = 256 / grid;
         if (ky > groups / 64) ky = groups / 64;        // at least 4 groups (32 k) per wave
@@ -1227,6 +1359,7 @@ extern "C" int cic_debug_gemm_tail_split(int on) {
     g_walk16 = ((on >> 21) & 1) ? 0 : 1;
     g_ldsb = ((on >> 22) & 1) ? 0 : 1;
     g_split_rows = ((on >> 23) & 1) ? 0 : 1;
+    g_rega2 = ((on >> 24) & 1) ? 0 : 1;
     return 0;
 }
 
