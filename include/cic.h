@@ -59,7 +59,11 @@ int cic_debug_empty(int grid, int block, cic_stream_t s);
 /* diagnostics: per-workgroup phase stamps of the register-streaming GEMM (NULL = off) */
 int cic_debug_set_stamps(unsigned long long* buf);
 int cic_debug_set_attn_stamps(unsigned long long* buf);
-/* diagnostics: 0 turns the K-sliced tail tiles of the large GEMMs off (fixed summation order; A/B timing) */
+/* diagnostics: per-workgroup phase stamps of the per-timestep GEMMs (rega / LDS-staged walker) and of the row kernels
+ * (attention, sampler); NULL = off */
+/* diagnostics, A/B timing of the GEMM dispatch: bit 0 clear = K-sliced tail tiles and K split over workgroups off (fixed
+ * summation order); bits 8..15: 1 / 2 force 128x128 / 64x64 tiles; set bits turn a kernel family OFF: 16 strip walkers,
+ * 21 16-wide walkers, 22 LDS-staged logit walker, 23 row-block split of 129..256-row products, 24 two-strip dX kernel */
 int cic_debug_gemm_tail_split(int on);
 /* diagnostics: 1 runs the logit weight-gradient product on a side stream beside the BPTT loop (default 0: measured slower) */
 int cic_debug_side_stream(int on);
