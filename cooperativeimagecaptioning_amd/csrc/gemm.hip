@@ -998,21 +998,9 @@ __global__ __launch_bounds__(KS * 64) void gemm_walk16_kernel(cic_gemm_args g, i
 // its first use and hoists the waits for the staged loads above the MFMA chain.
 // Work units = row groups x column tiles (4 x 593 for the paired logit product) dealt round-robin to one workgroup
 // per CU: 9.3 tiles per workgroup, 4096 MFMA cycles each.
-// The A fragments are read ONCE per workgroup, 16 rows x 64 B per load instruction: rows 2 KB apart fall on few L2
-// channels, and every workgroup of an XCD would walk K in the same order at the same time, so the waves start their
-// walk at different K offsets (rotation by 64 floats per (wave, walker parity)).
+// The A fragments are read ONCE per workgroup (128 KB per CU: ~5 us at the rate a CU fills when all of them load).
 //   operand layout as in gemm_walk16_kernel: lane l -> (i = l & 15, q = l >> 4); A: row i, k = 16g + 4q + s;
 //   B: column i likewise; D: 4 registers v: row 4q + v, column i.
-template <int NG, int R>
-__device__ __forceinline__ void ldsb_load_a(f32x4 (&af)[NG], const float* __restrict__ row) {
-#pragma unroll
-    for (int i = 0; i < NG; ++i) {
-        constexpr int dummy = 0; (void)dummy;
-        const int ii = (i + R) % NG;
-        af[ii] = *reinterpret_cast<const f32x4*>(row + 16 * ii);
-    }
-}
-
 template <int NG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_ldsb_walk_kernel(
     cic_gemm_args g, int row_groups, int walkers) {
@@ -1067,23 +1055,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     load_tile(first);                                      // the first weight tile goes out before the A fragments
     f32x4 af[NG];
-    {
-        const float* row = gA + (size_t)mc * g.lda + 4 * lq;
-        switch ((2 * w + (first & 1)) & 7) {
-            case 0: ldsb_load_a<NG, 0>(af, row); break;
-            case 1: ldsb_load_a<NG, 4>(af, row); break;
-            case 2: ldsb_load_a<NG, 8>(af, row); break;
-            case 3: ldsb_load_a<NG, 12>(af, row); break;
-            case 4: ldsb_load_a<NG, 16>(af, row); break;
-            case 5: ldsb_load_a<NG, 20>(af, row); break;
-            case 6: ldsb_load_a<NG, 24>(af, row); break;
-            default: ldsb_load_a<NG, 28>(af, row); break;
-        }
-    }
+    // the first half of the A fragments goes out with the first tile; the second half after the first barrier, so
+    // that the first tile's MFMA chain starts after 24 of the 40 prologue loads and the rest arrives under it
+    // (hipcc waits for ALL outstanding loads before the first LDS write)
+    const float* arow = gA + (size_t)mc * g.lda + 4 * lq;
+#pragma unroll
+    for (int i = 0; i < NG / 2; ++i) af[i] = *reinterpret_cast<const f32x4*>(arow + 16 * i);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int e = 0; e < F4; ++e) store_piece(lds, e);
     __syncthreads();
+#pragma unroll
+    for (int i = NG / 2; i < NG; ++i) af[i] = *reinterpret_cast<const f32x4*>(arow + 16 * i);
+    __builtin_amdgcn_sched_barrier(0);
     stamp();
     if (stamps && lane == 0) { stamps[60] = __builtin_amdgcn_s_memrealtime(); stamps[61] = __builtin_amdgcn_s_memtime(); }
     int buf = 0;
