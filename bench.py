@@ -209,6 +209,8 @@ def main():
         engine.lib.cic_debug_gemm_tail_split(int(os.environ['CIC_GEMM_FLAGS'], 0))
     if os.environ.get('CIC_A2C_CELL_FUSED') is not None:   # A/B measurement of the fused a2c + cell kernel
         engine.lib.cic_debug_a2c_cell_fused(int(os.environ['CIC_A2C_CELL_FUSED']))
+    if os.environ.get('CIC_GATES_ATT_FUSED') is not None:  # A/B measurement of the gate + attention-query launch
+        engine.lib.cic_debug_gates_att_fused(int(os.environ['CIC_GATES_ATT_FUSED']))
     if os.environ.get('CIC_GRU_FUSED') is not None:        # A/B measurement of the fused listener GRU step
         engine.lib.cic_debug_gru_fused(int(os.environ['CIC_GRU_FUSED']))
     if os.environ.get('CIC_SIDE_STREAM') is not None:      # A/B measurement of the side-stream products

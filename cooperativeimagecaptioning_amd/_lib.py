@@ -41,7 +41,9 @@ class GemmArgs(C.Structure):
                 ('B2', c_ptr), ('ldb2', C.c_int),
                 ('C', c_ptr), ('ldc', C.c_int),
                 ('bias', c_ptr), ('accumulate', C.c_int), ('relu', C.c_int),
-                ('sum_order_free', C.c_int), ('c_is_zero', C.c_int), ('colsum_A', c_ptr), ('colsum_A2', c_ptr), ('rows_blk', C.c_int), ('A_b', c_ptr), ('A2_b', c_ptr), ('C_b', c_ptr)]
+                ('sum_order_free', C.c_int), ('c_is_zero', C.c_int), ('colsum_A', c_ptr), ('colsum_A2', c_ptr), ('rows_blk', C.c_int), ('A_b', c_ptr), ('A2_b', c_ptr), ('C_b', c_ptr),
+                ('n_split', C.c_int), ('B2_tail', c_ptr), ('ldb2_tail', C.c_int), ('bias_tail', c_ptr),
+                ('C_tail', c_ptr), ('C_tail_b', c_ptr), ('ldc_tail', C.c_int)]
 
 
 class SamplerArgs(C.Structure):

@@ -889,7 +889,7 @@ template <int GPS, int KS, bool DEEP>   // K slice per wave = 16*GPS; DEEP: B fr
 __global__ __launch_bounds__(KS * 64) void gemm_walk16_kernel(cic_gemm_args g, int strips) {
     static_assert(KS == 8, "8 accumulator registers (2 row tiles x 4) dealt one per wave");
     __shared__ float red[2 * KS * 8 * 64];
-    const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, ks = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
     const int li = lane & 15, lq = lane >> 4;
     const int tiles_n = (g.N + 15) / 16;
     const int step = gridDim.x / strips;                     // walkers per strip, a multiple of 8 (XCD sharing)
@@ -922,23 +922,30 @@ __global__ __launch_bounds__(KS * 64) void gemm_walk16_kernel(cic_gemm_args g, i
         }
     }
     f32x4 bf[GPS], bq[DEEP ? GPS : 1];
+    // column split (see cic.h): tiles at or beyond n_split take the second operand pair only, from B2_tail
+    const int split_t = g.n_split > 0 ? g.n_split / 16 : tiles_n;
     auto load_b = [&](f32x4 (&dst)[GPS], int t) {
         const int tt = t < tiles_n ? t : tiles_n - 1;
         const int n = tt * 16 + li;
         const bool nok = t < tiles_n && n < g.N;
         const int nc = n < g.N ? n : g.N - 1;
+        const bool tail = tt >= split_t;
 #pragma unroll
         for (int i = 0; i < GPS; ++i) {
-            const int k = 16 * (ks * GPS + i) + 4 * lq;
+            const int k0 = 16 * (ks * GPS + i);             // wave-uniform: the operand choice stays in scalar registers
+            const int k = k0 + 4 * lq;
             const bool kok = k < Kt;
-            const bool second = kok && k >= K1;
-            const float* B = second ? g.B2 : g.B;
-            const int ldb = second ? g.ldb2 : g.ldb;
+            const bool second = k0 >= K1;                   // K1 % 16 == 0 (rega_ok: K % 8, walk16: Kt == 1024, K1 = 512)
+            const float* B = second ? (tail ? g.B2_tail : g.B2) : g.B;
+            const int ldb = second ? (tail ? g.ldb2_tail : g.ldb2) : g.ldb;
             const int kp = second ? g.K2 : K1;
             int kk = second ? k - K1 : k;
             kk = kk < kp - 4 ? kk : kp - 4;
-            const f32x4 b = *reinterpret_cast<const f32x4*>(B + (size_t)nc * ldb + kk);
-            dst[i] = (kok && nok) ? b : z4;
+            const int row = tail ? nc - g.n_split : nc;
+            const bool use = kok && nok && (second || !tail);
+            // unused fragments (padding, and the first pair's K slices of tail tiles) read a block of zeros
+            const float* pb = use ? B + (size_t)row * ldb + kk : g_zero16;
+            dst[i] = *reinterpret_cast<const f32x4*>(pb);
         }
     };
     load_b(bf, first);
@@ -952,8 +959,10 @@ __global__ __launch_bounds__(KS * 64) void gemm_walk16_kernel(cic_gemm_args g, i
         const int n = t * 16 + li;
         const int ncl = n < g.N ? n : g.N - 1;
         float bias_v = 0.f, cold = 0.f;                 // epilogue operands fetched before the barrier
-        if (g.bias) bias_v = g.bias[ncl];
-        if (g.accumulate) cold = gC[(size_t)mcl * g.ldc + ncl];
+        const bool tail = t >= split_t;
+        if (tail) { if (g.bias_tail) bias_v = g.bias_tail[ncl - g.n_split]; }
+        else if (g.bias) bias_v = g.bias[ncl];
+        if (g.accumulate && !tail) cold = gC[(size_t)mcl * g.ldc + ncl];
         f32x4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < GPS; ++i)
@@ -981,7 +990,10 @@ __global__ __launch_bounds__(KS * 64) void gemm_walk16_kernel(cic_gemm_args g, i
         for (int w = 0; w < KS; ++w) v += rb[(w * 8 + ks) * 64 + lane];
         v += bias_v + cold;
         if (g.relu) v = fmaxf(v, 0.f);
-        if (mm < Mloc && n < g.N) gC[(size_t)mm * g.ldc + n] = v;
+        if (mm < Mloc && n < g.N) {
+            if (tail) (blk2 ? g.C_tail_b : g.C_tail)[(size_t)mm * g.ldc_tail + (n - g.n_split)] = v;
+            else gC[(size_t)mm * g.ldc + n] = v;
+        }
         buf ^= 1;
     }
 }
@@ -1179,7 +1191,7 @@ int launch_rega(const cic_gemm_args& g, hipStream_t st) {
     // 16-wide walkers (see gemm_walk16_kernel) for the K = 1024 products with many column tiles (measured,
     // tools/step_gemms.py: [256 x 2560 x 1024] 22.6 us vs 29.3 us with 32-wide tiles, [128 x 3072 x 1024] 16.6 vs 22.7;
     // at K = 512 the 16-wave persistent strips below stay faster: 35 vs 42-48 us for the logit product)
-    if (g_walk16 && g.b_kc && g.N >= 2048 && Kt == 1024) {
+    if (g_walk16 && g.b_kc && g.N >= 2048 && Kt == 1024 && (g.K % 16) == 0) {
         int nb = 256 / strips;                         // 8-wave workgroups, one per CU
         const int t16 = cic_cdiv(g.N, 16);
         if (nb > t16) nb = t16;
@@ -1352,9 +1364,21 @@ extern "C" int cic_debug_set_stamps(unsigned long long* buf) {
     return 0;
 }
 
+static bool gemm_split_supported(const cic_gemm_args& g) {
+    // the 16-wide strip walker (launch_rega): K-contiguous operands, x and h halves of 512, whole 16-column tiles
+    return g.n_split > 0 && g.a_kc && g.b_kc && g.K == 512 && g.K2 == 512 && (g.n_split % 16) == 0 && g.n_split >= 2048 &&
+           g.N > g.n_split && g.B2_tail && g.C_tail && (g.ldb2_tail & 3) == 0 && aligned16(g.B2_tail) && !g.accumulate &&
+           !g.relu && (g.rows_blk == 0 || g.C_tail_b) && g_walk16 && rega_ok(g);   // K = K2 = 512: the walker's shape
+}
+extern "C" int cic_gemm_split_ok(const cic_gemm_args* a) { return a && gemm_split_supported(*a) ? 1 : 0; }
+
 extern "C" int cic_gemm_f32(const cic_gemm_args* a, cic_stream_t s) {
     CIC_REQUIRE(a != nullptr);
     const cic_gemm_args& g = *a;
+    if (g.n_split > 0) {
+        CIC_REQUIRE(gemm_split_supported(g));
+        return launch_rega(g, cic_s(s));
+    }
     CIC_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.K2 >= 0);
     CIC_REQUIRE(g.A && g.B && g.C);
     CIC_REQUIRE(g.K2 == 0 || (g.A2 && g.B2));

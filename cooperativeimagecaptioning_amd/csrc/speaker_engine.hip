@@ -8,6 +8,8 @@
 
 namespace {
 
+int g_gates_att_fused = 1;   // cic_debug_gates_att_fused: 0 = separate h2att launch (A/B timing)
+
 __global__ void fill_i32_kernel(int32_t* p, int n, int32_t v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -53,6 +55,8 @@ __global__ __launch_bounds__(256) void decode_init_kernel(DecodeInit a, DecodeIn
 }
 
 }  // namespace
+
+extern "C" int cic_debug_gates_att_fused(int on) { g_gates_att_fused = on; return 0; }
 
 int cic_fill_i32(int32_t* p, int n, int32_t v, hipStream_t st) {
     hipLaunchKernelGGL(fill_i32_kernel, dim3(cic_cdiv(n, 256)), dim3(256), 0, st, p, n, v);
@@ -261,8 +265,24 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
                                fc ? Dual<const uint8_t>{nullptr, nullptr} : xk, (xk.a && !fc) ? p_drop : 0.f, x, B, nb, E, st,
                                fc ? 1 : 0));
         }
-        // attention                                                        (:465-489)
+        // all_input_sums = i2h(xt) + h2h(h)  (:514) and the attention query att_h = h2att(h)  (:470) read the same
+        // (x_t, h_{t-1}): one launch where the GEMM implements the column split (flagship widths), else two
+        bool gates_done = false;
         if (!fc) {
+            cic_gemm_args g = {};
+            g.M = M; g.N = 5 * H + A; g.K = E; g.A = x.a; g.lda = E; g.a_kc = 1; g.B = p->i2h_w; g.ldb = E; g.b_kc = 1;
+            g.K2 = H; g.A2 = h.a; g.lda2 = H; g.B2 = p->h2h_w; g.ldb2 = H;
+            g.C = pre.a; g.ldc = 5 * H; g.bias = w[0].bias_ih;
+            g.n_split = 5 * H; g.B2_tail = p->h2att_w; g.ldb2_tail = H; g.bias_tail = p->h2att_b;
+            g.C_tail = att_h.a; g.C_tail_b = att_h.b; g.ldc_tail = A;
+            if (nb == 2) { g.rows_blk = B; g.A_b = x.b; g.A2_b = h.b; g.C_b = pre.b; }
+            if (g_gates_att_fused && cic_gemm_split_ok(&g)) {
+                RUN(cic_gemm_f32(&g, st));
+                gates_done = true;
+            }
+        }
+        // attention                                                        (:465-489)
+        if (!fc && !gates_done) {
             cic_gemm_args g = {};
             g.M = M; g.N = A; g.K = H; g.A = h.a; g.lda = H; g.a_kc = 1; g.B = p->h2att_w; g.ldb = H; g.b_kc = 1;
             g.C = att_h.a; g.ldc = A; g.bias = p->h2att_b;
@@ -278,7 +298,7 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
             if (rc) return rc;
         }
         // all_input_sums = i2h(xt) + h2h(h);  in_transform += a2c(att_res)   (:514,521-522)
-        {
+        if (!gates_done) {
             cic_gemm_args g = {};
             g.M = M; g.N = 5 * H; g.K = E; g.A = x.a; g.lda = E; g.a_kc = 1; g.B = p->i2h_w; g.ldb = E; g.b_kc = 1;
             g.K2 = H; g.A2 = h.a; g.lda2 = H; g.B2 = p->h2h_w; g.ldb2 = H;

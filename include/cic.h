@@ -65,6 +65,8 @@ int cic_debug_set_attn_stamps(unsigned long long* buf);
  * summation order); bits 8..15: 1 / 2 force 128x128 / 64x64 tiles; set bits turn a kernel family OFF: 16 strip walkers,
  * 21 16-wide walkers, 22 LDS-staged logit walker, 23 row-block split of 129..256-row products, 24 two-strip dX kernel */
 int cic_debug_gemm_tail_split(int on);
+/* diagnostics: 0 = the decode engines launch the attention query product on its own (A/B timing of the column split) */
+int cic_debug_gates_att_fused(int on);
 /* diagnostics: 1 runs the logit weight-gradient product on a side stream beside the BPTT loop (default 0: measured slower) */
 int cic_debug_side_stream(int on);
 /* diagnostics: 0 runs every listener GRU step as a GEMM launch + a cell launch instead of the fused step kernel */
@@ -117,8 +119,19 @@ typedef struct {
     const float* A_b;
     const float* A2_b;
     float* C_b;
+    /* Column split (optional; two products of one decode step that read the same state in ONE launch:
+     * [i2h(x) + h2h(h) | h2att(h)], AttModel.py:470,514): when n_split > 0, columns [n_split, N) are the product of the
+     * SECOND operand pair only, with weight rows B2_tail[(n - n_split)*ldb2_tail + k], bias bias_tail[n - n_split], and
+     * go to C_tail[m*ldc_tail + (n - n_split)] (rows at or beyond rows_blk: C_tail_b).  Supported where
+     * cic_gemm_split_ok() says so (K-contiguous operands, K = K2 = 512, n_split % 16 == 0); else leave n_split = 0. */
+    int n_split;
+    const float* B2_tail; int ldb2_tail;
+    const float* bias_tail;
+    float* C_tail; float* C_tail_b; int ldc_tail;
 } cic_gemm_args;
 int cic_gemm_f32(const cic_gemm_args* a, cic_stream_t s);
+/* 1 if cic_gemm_f32 implements the column split for these arguments, 0 if not */
+int cic_gemm_split_ok(const cic_gemm_args* a);
 /* measurement helper: average duration (us) of `iters` back-to-back launches of the product, HIP events on s */
 int cic_gemm_f32_timed(const cic_gemm_args* a, int iters, double* avg_us, cic_stream_t s);
 /* out[n] (+)= sum_m X[m*ldx + n]   — bias gradients. */
