@@ -26,6 +26,7 @@ int g_force_tile = 0;   // bits 8..15: 1 = 128x128, 2 = 64x64 tiles forced
 int g_walk = 1;         // bit 16 set: strip walkers off
 int g_walk16 = 1;       // bit 21 set: 16-wide strip walkers off
 int g_ldsb = 1;         // bit 22 set: LDS-staged column walker (K = 512 logit product) off
+int g_ldsb2 = 2;        // K parts per row tile of the logit walker: 2 or 4 (bits 25..26 of the debug word: 1 -> 4-wave form, 2 -> 4 parts)
 int g_rega2 = 1;        // bit 24 set: two-strip dX kernel (gemm_rega2_kernel) off
 int g_split_rows = 1;   // bit 23 set: 129..256-row products are not handed to the register-streaming kernels as two row blocks
 
@@ -1138,6 +1139,124 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (stamps && lane == 0) { stamps[62] = __builtin_amdgcn_s_memrealtime(); stamps[63] = __builtin_amdgcn_s_memtime(); }
 }
 
+// Eight-wave form of the walker above: the same 64 rows x 16-column tiles, but every 16-row tile is shared by TWO waves
+// that each take one half of K (A fragments: 64 VGPRs per lane), so a SIMD holds two waves and one wave's LDS reads,
+// staging writes, stores and waits run under the other's MFMAs (with one wave per SIMD they all sit inside the chain:
+// 2.9 us per tile for 1.9 us of MFMAs).  The two K halves of a tile meet through 4 KB of LDS: the upper-half wave
+// parks its four sums there before the tile's barrier, the lower-half wave adds them (lower + upper: a fixed order)
+// while it stores the tile under the next tile's MFMAs.
+template <int NG, int KH>   // KH K parts per row tile: 4 * KH waves, KH per SIMD
+__global__ __launch_bounds__(256 * KH) __attribute__((amdgpu_waves_per_eu(KH, KH))) void gemm_ldsb2_walk_kernel(
+    cic_gemm_args g, int row_groups, int walkers) {
+    constexpr int K = 16 * NG, LDB = K + 4, TILE = 16 * LDB, NH = NG / KH, NT = 256 * KH;
+    constexpr int CH = 8, NC = NH / CH;
+    constexpr int F4 = 16 * (K / 4) / NT;                  // float4 per thread and staged tile
+    static_assert(F4 <= CH && NC >= 1, "the staged float4 ride behind the MFMA groups of the last chunk");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* pairbuf = lds + 2 * TILE;                       // [2 parities][4 row tiles][KH - 1 upper parts][4 registers][64 lanes]
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
+    const int rt = w & 3, kh = w >> 2;                     // row tile, K half
+    const int li = lane & 15, lq = lane >> 4;
+    const int per_xcd = gridDim.x / 8;
+    const int wg = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * per_xcd + blockIdx.x / 8 : blockIdx.x;
+    const int rg = wg % row_groups, first = wg / row_groups;
+    if (first >= walkers) return;                          // whole workgroup: no barrier is skipped by a part of it
+    const int tiles_n = (g.N + 15) / 16;
+    const int rg_a = g.rows_blk > 0 ? (g.rows_blk + 63) / 64 : row_groups;
+    const bool blk2 = rg >= rg_a;
+    const int m0 = (blk2 ? rg - rg_a : rg) * 64;
+    const float* __restrict__ gA = blk2 ? g.A_b : g.A;
+    float* __restrict__ gC = blk2 ? g.C_b : g.C;
+    const int Mloc = g.rows_blk > 0 ? (blk2 ? g.M - g.rows_blk : min(g.M, g.rows_blk)) : g.M;
+    const int m = m0 + 16 * rt + li;
+    const int mc = m < Mloc ? m : Mloc - 1;                // rows beyond M re-read row M-1: never stored
+    f32x4 stg[F4];
+    auto load_tile = [&](int t) {
+        const int tt = t < tiles_n ? t : tiles_n - 1;
+#pragma unroll
+        for (int e = 0; e < F4; ++e) {
+            const int j = tid + NT * e;
+            const int r = j / (K / 4), c4 = j % (K / 4);
+            const int n = tt * 16 + r;
+            const int nc = n < g.N ? n : g.N - 1;
+            stg[e] = *reinterpret_cast<const f32x4*>(g.B + (size_t)nc * g.ldb + 4 * c4);
+        }
+    };
+    auto store_piece = [&](float* dst, int e) {
+        const int j = tid + NT * e;
+        const int r = j / (K / 4), c4 = j % (K / 4);
+        *reinterpret_cast<f32x4*>(dst + r * LDB + 4 * c4) = stg[e];
+    };
+    load_tile(first);
+    f32x4 af[NH];
+    const float* arow = gA + (size_t)mc * g.lda + 16 * NH * kh + 4 * lq;
+#pragma unroll
+    for (int i = 0; i < NH; ++i) af[i] = *reinterpret_cast<const f32x4*>(arow + 16 * i);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < F4; ++e) store_piece(lds, e);
+    __syncthreads();
+    int buf = 0;
+    float prev[4];                                         // the previous tile's sums of this wave's K half
+    int prev_n = -1;
+    float prev_bias = 0.f;
+    auto store_row = [&](int v) {                          // lower-half waves: output register v of the previous tile
+        const int mm = m0 + 16 * rt + 4 * lq + v;
+        if (kh == 0 && prev_n >= 0) {
+            float x = prev[v];
+#pragma unroll
+            for (int u = 0; u < KH - 1; ++u) x += pairbuf[((((buf ^ 1) * 4 + rt) * (KH - 1) + u) * 4 + v) * 64 + lane];
+            x += prev_bias;
+            if (mm < Mloc && prev_n < g.N) gC[(size_t)mm * g.ldc + prev_n] = x;
+        }
+    };
+#pragma unroll 1
+    for (int t = first; t < tiles_n; t += walkers) {
+        load_tile(t + walkers);                            // next tile's rows in flight under this tile's MFMAs
+        const int n = t * 16 + li;
+        const int ncl = n < g.N ? n : g.N - 1;
+        float bias_v = 0.f;
+        if (g.bias) bias_v = g.bias[ncl];
+        const float* bt = lds + buf * TILE + li * LDB + 16 * NH * kh + 4 * lq;
+        float* nxt = lds + (buf ^ 1) * TILE;               // every wave left this buffer before the last barrier
+        f32x4acc acc[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[s] = f32x4acc{0.f, 0.f, 0.f, 0.f};
+        f32x4 bq[2][CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) bq[0][i] = *reinterpret_cast<const f32x4*>(bt + 16 * i);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (c + 1 < NC) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) bq[(c + 1) & 1][i] = *reinterpret_cast<const f32x4*>(bt + 16 * ((c + 1) * CH + i));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c * CH + i][s], bq[c & 1][i][s], acc[s], 0, 0, 0);
+                if (c == 0 && i < 4) { store_row(i); __builtin_amdgcn_sched_barrier(0); }
+                if (c == NC - 1 && i < F4) { store_piece(nxt, i); __builtin_amdgcn_sched_barrier(0); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) prev[v] = (acc[0][v] + acc[1][v]) + (acc[2][v] + acc[3][v]);
+        if (kh >= 1) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) pairbuf[(((buf * 4 + rt) * (KH - 1) + (kh - 1)) * 4 + v) * 64 + lane] = prev[v];
+        }
+        prev_n = n;
+        prev_bias = bias_v;
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) store_row(v);
+}
+
 bool ldsb_walk_ok(const cic_gemm_args& g) {
     return g.a_kc && g.b_kc && g.K2 == 0 && g.K == 512 && g.N >= 2048 && !g.accumulate && !g.relu &&
            (g.lda & 3) == 0 && (g.ldb & 3) == 0 && aligned16(g.A) && aligned16(g.B) && (g.rows_blk == 0 || aligned16(g.A_b));
@@ -1162,6 +1281,23 @@ int launch_ldsb_walk(const cic_gemm_args& g, hipStream_t st) {
     if (walkers < 1) walkers = 1;
     if (walkers > tiles_n) walkers = tiles_n;
     int grid = row_groups * walkers;
+    if (g_ldsb2 == 2 || g_ldsb2 == 4) {
+        const size_t lds2_bytes = lds_bytes + 2 * 4 * (g_ldsb2 - 1) * 4 * 64 * sizeof(float);
+        static bool attr2_set = false;
+        if (!attr2_set) {
+            CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2_walk_kernel<NG, 2>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bytes + 2 * 4 * 1 * 4 * 64 * 4)));
+            CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2_walk_kernel<NG, 4>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bytes + 2 * 4 * 3 * 4 * 64 * 4)));
+            attr2_set = true;
+        }
+        if (g_ldsb2 == 2)
+            hipLaunchKernelGGL((gemm_ldsb2_walk_kernel<NG, 2>), dim3(grid), dim3(512), lds2_bytes, st, g, row_groups, walkers);
+        else
+            hipLaunchKernelGGL((gemm_ldsb2_walk_kernel<NG, 4>), dim3(grid), dim3(1024), lds2_bytes, st, g, row_groups, walkers);
+        CIC_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL((gemm_ldsb_walk_kernel<NG>), dim3(grid), dim3(256), lds_bytes, st, g, row_groups, walkers);
     CIC_LAUNCH_CHECK();
     return 0;
@@ -1356,6 +1492,7 @@ extern "C" int cic_debug_gemm_tail_split(int on) {
     g_ldsb = ((on >> 22) & 1) ? 0 : 1;
     g_split_rows = ((on >> 23) & 1) ? 0 : 1;
     g_rega2 = ((on >> 24) & 1) ? 0 : 1;
+    g_ldsb2 = ((on >> 25) & 3) == 1 ? 0 : (((on >> 25) & 3) == 2 ? 4 : 2);
     return 0;
 }
 

@@ -67,8 +67,10 @@ def main():
         u2, e2 = run(*sh, flag=1 | (1 << 21) | (1 << 22))
         u3, e3 = run(*sh, flag=1 | (1 << 22))
         u4, e4 = run(*sh, flag=1 | (1 << 24))
+        u5, e5 = run(*sh, flag=1 | (1 << 25))
+        u6, e6 = run(*sh, flag=1 | (2 << 25))
         print(f'{name:14s} M{M:4d} N{N:5d} K{K + K2:5d}  auto {u1:7.2f} us ({fl / u1 / 1e6:6.1f} TF/s, err {e1:.1e})   '
-              f'no-rega2 {u4:7.2f} us   no-ldsb {u3:7.2f} us   walk32 {u2:7.2f} us   no-walk {u0:7.2f} us (err {e0:.1e})   '
+              f'4-wave ldsb {u5:7.2f} us   16-wave ldsb {u6:7.2f} us (err {e6:.1e})   no-rega2 {u4:7.2f} us   no-ldsb {u3:7.2f} us   walk32 {u2:7.2f} us   no-walk {u0:7.2f} us (err {e0:.1e})   '
               f'mfma floor {fl / 157e6:5.2f} us')
 
 
