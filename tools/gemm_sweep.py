@@ -40,7 +40,7 @@ def main():
         ref = (A if akc else A.t()).double() @ (B.t() if bkc else B).double()
         row = []
         free = not name.endswith('fwd') and name != 'lst gi' and name != 'lst img fc'
-        for tile in (1, 2):
+        for tile in (1, 2, 3, 4):
             for split in (0, 1):
                 _lib.lib.cic_debug_gemm_tail_split(split | (tile << 8))
                 C.zero_()
@@ -54,6 +54,7 @@ def main():
         tot['auto'] = tot.get('auto', 0.0) + us_auto
         fl = 2.0 * M * N * K
         print(f'{name:16s} M{M:5d} N{N:5d} K{K:5d}  128:{row[0][0]:7.1f} 128+tail:{row[1][0]:7.1f}  64:{row[2][0]:7.1f} 64+tail:{row[3][0]:7.1f}'
+              f'  128/8w(2x4):{row[4][0]:7.1f} +tail:{row[5][0]:7.1f}  128/8w(4x2):{row[6][0]:7.1f} +tail:{row[7][0]:7.1f}'
               f'  auto:{us_auto:7.1f} us = {fl / us_auto / 1e6:6.1f} TF/s  (peak-time {fl / 157e6:6.1f} us)  maxrelerr {max(r[1] for r in row):.1e}')
     print('totals', {str(k): round(v, 1) for k, v in tot.items()})
 
