@@ -180,7 +180,9 @@ def main():
     rewards.init_scorer('corpus')
     model = models.AlternatingJointModel(opt).to(dev).train()
     model.caption_generator.noise.manual_seed(1000 + rank)
-    optimizer_dict = optim.load_optimizer(model, opt)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):        # the reference-style progress prints stay off stdout: ONE JSON line there
+        optimizer_dict = optim.load_optimizer(model, opt)
     if world > 1:
         optim.overlap_gradient_exchange(model, optimizer_dict)   # listener all-reduce under the speaker backward
     batch = synthetic.make_batch(opt, seed=1234 + rank, device=dev)    # per-rank shard of the global batch
