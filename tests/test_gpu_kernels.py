@@ -386,3 +386,58 @@ def test_gemm_row_blocks_equal_two_products(ops, N, K, K2, b_kc):
     torch.cuda.synchronize()
     for i in range(2):
         assert torch.equal(sep[i], both[i])
+
+
+@pytest.mark.parametrize('M', [37, 100, 200, 256])
+def test_gemm_logit_walker_ragged_rows(ops, M):
+    """The LDS-staged logit walker (K = 512, N = 9488) with row counts that are no multiple of its 16-row tiles /
+    64-row groups: rows beyond M are clamped loads and never stored."""
+    g = torch.Generator().manual_seed(M)
+    A, W, bias = torch.randn(M, 512, generator=g), torch.randn(9488, 512, generator=g) * 0.05, torch.randn(9488, generator=g)
+    guard = 7.0
+    Cd = dev(torch.full((M + 3, 9488), guard))
+    ops.gemm(dev(A), dev(W), Cd[:M], True, True, bias=dev(bias))
+    torch.cuda.synchronize()
+    ref = A.double() @ W.double().t() + bias.double()
+    np.testing.assert_allclose(Cd[:M].cpu().double().numpy(), ref.numpy(), rtol=1e-5, atol=2e-4)
+    assert float((Cd[M:] - guard).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('pair', [False, True])
+def test_gemm_column_split(ops, pair):
+    """cic_gemm_args.n_split: [i2h(x) + h2h(h) | h2att(h)] in one launch.  The first 2560 columns equal the unsplit
+    product bit for bit (same kernel, same per-row arithmetic); the tail columns are h W_h2att^T + b."""
+    import ctypes as C
+    from cooperativeimagecaptioning_amd import _lib
+    g = torch.Generator().manual_seed(11)
+    Bh, E, H, A_ = 128, 512, 512, 512
+    nb = 2 if pair else 1
+    x = [dev(torch.randn(Bh, E, generator=g)) for _ in range(nb)]
+    h = [dev(torch.randn(Bh, H, generator=g)) for _ in range(nb)]
+    W1, W2 = dev(torch.randn(5 * H, E, generator=g) * .05), dev(torch.randn(5 * H, H, generator=g) * .05)
+    Wt, b1, bt = dev(torch.randn(A_, H, generator=g) * .05), dev(torch.randn(5 * H, generator=g)), dev(torch.randn(A_, generator=g))
+    pre = [dev(torch.zeros(Bh, 5 * H)) for _ in range(nb)]
+    att_h = [dev(torch.zeros(Bh, A_)) for _ in range(nb)]
+    ga = _lib.GemmArgs()
+    ga.M, ga.N, ga.K, ga.K2 = nb * Bh, 5 * H + A_, E, H
+    ga.A, ga.lda, ga.a_kc = x[0].data_ptr(), E, 1
+    ga.B, ga.ldb, ga.b_kc = W1.data_ptr(), E, 1
+    ga.A2, ga.lda2, ga.B2, ga.ldb2 = h[0].data_ptr(), H, W2.data_ptr(), H
+    ga.C, ga.ldc, ga.bias = pre[0].data_ptr(), 5 * H, b1.data_ptr()
+    ga.n_split, ga.B2_tail, ga.ldb2_tail, ga.bias_tail = 5 * H, Wt.data_ptr(), H, bt.data_ptr()
+    ga.C_tail, ga.ldc_tail = att_h[0].data_ptr(), A_
+    if pair:
+        ga.rows_blk, ga.A_b, ga.A2_b, ga.C_b = Bh, x[1].data_ptr(), h[1].data_ptr(), pre[1].data_ptr()
+        ga.C_tail_b = att_h[1].data_ptr()
+    assert _lib.lib.cic_gemm_split_ok(C.byref(ga)) == 1
+    _lib.check(_lib.lib.cic_gemm_f32(C.byref(ga), None), 'cic_gemm_f32')
+    torch.cuda.synchronize()
+    for i in range(nb):
+        plain = dev(torch.zeros(Bh, 5 * H))
+        ops.gemm(x[i], W1, plain, True, True, bias=b1, A2=h[i], B2=W2)
+        assert torch.equal(plain, pre[i])
+        ref = h[i].double().cpu() @ Wt.double().cpu().t() + bt.double().cpu()
+        np.testing.assert_allclose(att_h[i].cpu().double().numpy(), ref.numpy(), rtol=1e-5, atol=1e-4)
+    # unsupported forms are refused, not mis-computed
+    ga.K2 = 0
+    assert _lib.lib.cic_gemm_split_ok(C.byref(ga)) == 0
