@@ -172,3 +172,38 @@ def test_synthetic_batch_contract():
     nnz = (b['labels'] > 0).sum(1)
     assert (b['masks'].sum(1) == nnz + 2).all() and len(b['gts']) == 4 and b['gts'][0].shape == (5, 16)
     assert b['labels'].max() <= 9487 and b['att_feats'].min() >= 0
+
+
+def test_build_module_needs_no_library():
+    """A fresh checkout has no libcic_hip.so: importing the build module (what __graft_entry__.build() and
+    `python -m cooperativeimagecaptioning_amd.build` do first) must not try to load it."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; import cooperativeimagecaptioning_amd.build as b; "
+            "assert 'cooperativeimagecaptioning_amd._lib' not in sys.modules; print(len(b.sources()))")
+    out = subprocess.run([sys.executable, '-c', code], cwd=root, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert int(out.stdout.strip()) >= 8
+
+
+def test_compute_modules_fail_loudly_without_the_library(tmp_path):
+    """No fallback path: with the shared object out of reach, importing the model classes raises CicError."""
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # a copy of the Python package without the built library
+    dst = tmp_path / 'cooperativeimagecaptioning_amd'
+    shutil.copytree(os.path.join(root, 'cooperativeimagecaptioning_amd'), dst,
+                    ignore=shutil.ignore_patterns('*.so', '*.o', 'csrc', '__pycache__'))
+    os.makedirs(tmp_path / 'include')
+    shutil.copy(os.path.join(root, 'include', 'cic.h'), tmp_path / 'include' / 'cic.h')
+    code = ("import sys\n"
+            "try:\n"
+            "    import cooperativeimagecaptioning_amd.models\n"
+            "except Exception as e:\n"
+            "    print(type(e).__name__); sys.exit(0)\n"
+            "print('imported'); sys.exit(1)\n")
+    out = subprocess.run([sys.executable, '-c', code], cwd=str(tmp_path), capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0 and out.stdout.strip() == 'CicError', (out.stdout, out.stderr)
