@@ -11,6 +11,10 @@ for p in (ROOT, os.path.join(ROOT, 'tests')):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # a checkout without the built library (it is git-ignored): build it once, in-tree (no-op when up to date)
+    from cooperativeimagecaptioning_amd import build as _build
+    if _build.needs_build():
+        _build.build(force=False, verbose=False)
 
 
 def pytest_collection_modifyitems(config, items):
