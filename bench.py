@@ -17,6 +17,7 @@ oracle (oracle/, a restatement of the reference pinned by golden vectors) timed 
 for a bounded number of steps of the same workload.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -172,6 +173,13 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device('cuda', local_rank)
 
+    from cooperativeimagecaptioning_amd import build as _build
+    if _build.needs_build():                   # a checkout without the (git-ignored) library: compile it in-tree first
+        if local_rank == 0:
+            with contextlib.redirect_stdout(sys.stderr):
+                _build.build(force=False)
+        if world > 1:
+            dist.barrier()
     from cooperativeimagecaptioning_amd import models, optimizer as optim, synthetic, engine
     from cooperativeimagecaptioning_amd.misc import rewards
 
@@ -180,7 +188,6 @@ def main():
     rewards.init_scorer('corpus')
     model = models.AlternatingJointModel(opt).to(dev).train()
     model.caption_generator.noise.manual_seed(1000 + rank)
-    import contextlib
     with contextlib.redirect_stdout(sys.stderr):        # the reference-style progress prints stay off stdout: ONE JSON line there
         optimizer_dict = optim.load_optimizer(model, opt)
     if world > 1:
