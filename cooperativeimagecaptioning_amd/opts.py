@@ -62,6 +62,8 @@ def build_parser():
     p.add_argument('--continue_from_existing_models', action='store_false')     # opts.py:88-89 (store_false!)
     # additions of this implementation (absent from the reference)
     p.add_argument('--synthetic', type=int, default=0, help='1: COCO-shaped synthetic batches (no dataset needed)')
+    p.add_argument('--synthetic_pool', type=int, default=8,
+                   help='distinct synthetic batches served round robin (0: draw a fresh batch on every call)')
     p.add_argument('--max_iterations', type=int, default=-1, help='stop after this many iterations (-1: never)')
     p.add_argument('--seed', type=int, default=0)
     p.add_argument('--prefetch', type=int, default=1, help='1: upload the next batch on a copy stream while the '

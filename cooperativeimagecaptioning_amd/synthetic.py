@@ -53,15 +53,31 @@ def make_batch(opt, K=36, seed=1234, ncap=5, device='cpu'):
 
 class SyntheticLoader:
     """get_batch('train') with the reference loader's output contract (dataloader.py:171-245): numpy
-    arrays on the host, a fresh random batch per call, `bounds.wrapped` every `iters_per_epoch` calls."""
+    arrays on the host, `bounds.wrapped` every `iters_per_epoch` calls.  The synthetic "dataset" is a pool of `pool`
+    distinct random batches generated on first use and served round robin (a real dataset also repeats every epoch;
+    drawing 9.4 M normals per call costs 50-150 ms of host time, an order of magnitude more than the step);
+    pool = 0 draws a fresh batch on every call."""
 
-    def __init__(self, opt, seed=1234, K=36, iters_per_epoch=100):
+    def __init__(self, opt, seed=1234, K=36, iters_per_epoch=100, pool=8):
         self.opt, self.seed, self.K, self.n, self.ipe = opt, seed, K, 0, iters_per_epoch
         self.vocab_size, self.seq_length = opt.vocab_size, opt.seq_length
+        self.pool = int(pool)
+        self._cache = {}
+
+    def _make(self, idx):
+        b = make_batch(self.opt, K=self.K, seed=self.seed + idx)
+        return dict(fc_feats=b['fc_feats'].numpy(), att_feats=b['att_feats'].numpy(), att_masks=None,
+                    labels=b['labels'].numpy(), masks=b['masks'].numpy(), gts=b['gts'])
 
     def get_batch(self, split):
-        b = make_batch(self.opt, K=self.K, seed=self.seed + self.n)
+        if self.pool > 0:
+            idx = self.n % self.pool
+            if idx not in self._cache:
+                self._cache[idx] = self._make(idx)
+            b = dict(self._cache[idx])          # shallow copy: per-call keys (bounds, loader attachments) stay per call
+        else:
+            b = self._make(self.n)
         self.n += 1
-        return dict(fc_feats=b['fc_feats'].numpy(), att_feats=b['att_feats'].numpy(), att_masks=None,
-                    labels=b['labels'].numpy(), masks=b['masks'].numpy(), gts=b['gts'],
-                    bounds=dict(it_pos_now=self.n, it_max=self.ipe, wrapped=(self.n % self.ipe == 0)), infos=[])
+        b['bounds'] = dict(it_pos_now=self.n, it_max=self.ipe, wrapped=(self.n % self.ipe == 0))
+        b['infos'] = []
+        return b

@@ -112,7 +112,7 @@ def train(opt, loader=None):
                                       'path: pass a loader object with get_batch("train") or use --synthetic 1')
         opt.vocab_size = getattr(opt, 'vocab_size', None) or 9487
         opt.seq_length = getattr(opt, 'seq_length', None) or 16
-        loader = synthetic.SyntheticLoader(opt, seed=1234 + rank)
+        loader = synthetic.SyntheticLoader(opt, seed=1234 + rank, pool=getattr(opt, 'synthetic_pool', 8))
     else:
         opt.vocab_size, opt.seq_length = loader.vocab_size, loader.seq_length
     if getattr(opt, 'prefetch', 1):
