@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64) void beam_final_kernel(const float* __restrict_
 }
 
 struct BeamWs {
-    float *p_att, *x, *h[2], *c[2], *att_h, *att_res, *alpha, *dot, *pre, *out, *logp, *bias_ih;
+    float *att_m, *p_att, *x, *h[2], *c[2], *att_h, *att_res, *alpha, *dot, *pre, *out, *logp, *bias_ih;
     float *ys, *lp[2], *beam_sum, *done_lp;
     int32_t *it, *ix, *parent, *seq[2], *done_seq, *done_order, *done_count;
     size_t bytes;
@@ -180,6 +180,7 @@ BeamWs beam_carve(const cic_speaker_dims& d, int beam, void* base) {
     BeamWs w;
     Carver c(base);
     const size_t B = d.B, K = d.K, H = d.H, E = d.E, A = d.A, T = d.T, V1 = d.V + 1, R = B * beam;
+    w.att_m = c.f32(B * K * H);      // embedded regions with the padded rows zeroed (att_masks only)
     w.p_att = c.f32(B * K * A);
     w.x = c.f32(R * E);
     for (int i = 0; i < 2; ++i) { w.h[i] = c.f32(R * H); w.c[i] = c.f32(R * H); }
@@ -233,6 +234,10 @@ extern "C" int cic_speaker_beam_search(const cic_speaker_dims* dp, const cic_spe
 #define RUN(x) if ((rc = (x)) != 0) return rc
     // evaluation mode: att = relu(att_embed(att_raw)) without dropout; p_att = ctx2att(att)      (:158-162)
     const float* att = io->att_pre;
+    if (io->att_masks) {          // ragged region counts: padded rows of the embedded regions are 0 (pack_wrapper :44-51)
+        RUN(cic_att_keep_rows(io->att_pre, nullptr, 0.f, io->att_masks, w.att_m, B, K, H, st));
+        att = w.att_m;
+    }
     RUN(gemm_nt(att, H, p->ctx2att_w, H, w.p_att, A, B * K, A, H, p->ctx2att_b, false, false, st));
     RUN(cic_add_vec(p->i2h_b, p->h2h_b, w.bias_ih, 5 * H, st));
     CIC_HIP(hipMemsetAsync(w.h[0], 0, sizeof(float) * R * H, st));

@@ -4,7 +4,9 @@
 //
 // MI355X design: a sentence has <= 16 tokens, hence <= 58 n-grams (16+15+14+13): exactly one
 // 64-lane wavefront per sentence, one n-gram per lane.
-//   1. ngram   : lane -> 64-bit key (order | 4 x 15-bit tokens); wave-wide bitonic sort with
+//   1. ngram   : lane -> 64-bit key (order | 4 x 15-bit tokens: the caller declares its vocabulary size, which must
+//                fit 15 bits, and a token outside [0, vocab_size + 1] turns every score into NaN instead of aliasing
+//                silently); wave-wide bitonic sort with
 //                shuffles; run-length -> unique keys + integer term frequencies   (precook :13-30)
 //   2. df      : reference n-grams go into an open-addressing hash table (atomicCAS on the key,
 //                atomicAdd on the count), once per image (binary search in the image's earlier
@@ -62,8 +64,9 @@ __device__ __forceinline__ const int32_t* sent_row(const Sents& s, int i, int& c
 }
 
 // 1. one wave per sentence
-__global__ __launch_bounds__(256) void ngram_kernel(Sents s, int S, uint64_t* __restrict__ keys, int32_t* __restrict__ cnt,
-                                                    int32_t* __restrict__ nuniq, int32_t* __restrict__ blen) {
+__global__ __launch_bounds__(256) void ngram_kernel(Sents s, int S, int max_token, uint64_t* __restrict__ keys,
+                                                    int32_t* __restrict__ cnt, int32_t* __restrict__ nuniq,
+                                                    int32_t* __restrict__ blen, int32_t* __restrict__ bad) {
     const int lane = threadIdx.x & 63;
     const int sid = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (sid >= S) return;
@@ -73,6 +76,8 @@ __global__ __launch_bounds__(256) void ngram_kernel(Sents s, int S, uint64_t* __
     int len = cols;
     for (int j = 0; j < cols; ++j)
         if (row[j] == 0) { len = j + 1; break; }
+    // a token id that does not fit the declared vocabulary would alias another n-gram key: poison the result instead
+    if (lane < len && (row[lane] < 0 || row[lane] > max_token)) atomicOr(bad, 1);
     // lane -> (order n, position p): unigrams 0..15, bigrams 16..30, trigrams 31..44, 4-grams 45..57
     int n, p;
     if (lane < 16) { n = 1; p = lane; }
@@ -194,7 +199,8 @@ __global__ __launch_bounds__(256) void vec_kernel(const uint64_t* __restrict__ k
 __global__ __launch_bounds__(256) void score_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ nuniq,
                                                     const int32_t* __restrict__ blen, const double* __restrict__ vec,
                                                     const double* __restrict__ norm, const int32_t* __restrict__ ref_off,
-                                                    int B, int spi, double sigma, double* __restrict__ scores) {
+                                                    int B, int spi, double sigma, const int32_t* __restrict__ bad,
+                                                    double* __restrict__ scores) {
     const int lane = threadIdx.x & 63;
     const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (h >= 2 * B) return;
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(256) void score_kernel(const uint64_t* __restrict__
     if (lane == 0) {
         double avg = (tot[0] + tot[1] + tot[2] + tot[3]) / (double)NMAX;   // np.mean over n  (:194)
         avg /= (double)(r1 - r0);
-        scores[h] = avg * 10.0;
+        scores[h] = *bad ? __longlong_as_double(0x7ff8000000000000ll) : avg * 10.0;   // out-of-vocabulary token: NaN
     }
 }
 
@@ -260,7 +266,7 @@ __global__ void ref_img_kernel(const int32_t* __restrict__ ref_off, int n_images
 
 struct CidWs {
     uint64_t *keys, *ht_keys;
-    int32_t *cnt, *nuniq, *blen, *ht_df, *ref_img, *df;
+    int32_t *cnt, *nuniq, *blen, *ht_df, *ref_img, *df, *bad;
     double *vec, *norm;
     uint32_t ht_size;
     size_t bytes;
@@ -282,6 +288,7 @@ CidWs cid_carve(int B, int R, void* base) {
     w.blen = c.i32(S);
     w.ht_df = c.i32(ht);
     w.ref_img = c.i32(R);
+    w.bad = c.i32(1);
     w.bytes = c.used();
     return w;
 }
@@ -294,6 +301,12 @@ extern "C" int cic_ciderd_reward(const cic_ciderd_args* a, void* ws, size_t ws_b
     CIC_REQUIRE(a && ws && a->gen && a->greedy && a->L_gen && a->L_greedy && a->refs && a->ref_off && a->scores);
     CIC_REQUIRE(a->B > 0 && a->R > 0 && a->n_images > 0 && a->spi > 0 && a->B == a->n_images * a->spi);
     CIC_REQUIRE(a->T > 0 && a->T <= MAXTOK && a->Tr > 0 && a->Tr <= MAXTOK);
+    // n-gram keys hold 15 bits per token: ids 0 .. vocab_size + 1 (<eos>, the words, <bos>) must fit
+    if (a->vocab_size <= 0 || a->vocab_size + 1 > 0x7fff) {
+        cic_set_error("cic_ciderd_reward: vocab_size %d is outside 1..%d (n-gram keys pack 15 bits per token)",
+                      a->vocab_size, 0x7fff - 1);
+        return 1;
+    }
     CidWs w = cid_carve(a->B, a->R, ws);
     CIC_REQUIRE(ws_bytes >= w.bytes);
     hipStream_t st = cic_s(s);
@@ -301,9 +314,11 @@ extern "C" int cic_ciderd_reward(const cic_ciderd_args* a, void* ws, size_t ws_b
     Sents sn = {a->gen, a->greedy, a->refs, a->L_gen, a->L_greedy, B, a->T, R, a->Tr};
     CIC_HIP(hipMemsetAsync(w.ht_keys, 0xFF, sizeof(uint64_t) * w.ht_size, st));
     CIC_HIP(hipMemsetAsync(w.ht_df, 0, sizeof(int32_t) * w.ht_size, st));
+    CIC_HIP(hipMemsetAsync(w.bad, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(ref_img_kernel, dim3(cic_cdiv(a->n_images, 256)), dim3(256), 0, st, a->ref_off, a->n_images,
                        w.ref_img);
-    hipLaunchKernelGGL(ngram_kernel, dim3(cic_cdiv(S, 4)), dim3(256), 0, st, sn, S, w.keys, w.cnt, w.nuniq, w.blen);
+    hipLaunchKernelGGL(ngram_kernel, dim3(cic_cdiv(S, 4)), dim3(256), 0, st, sn, S, a->vocab_size + 1, w.keys, w.cnt, w.nuniq,
+                       w.blen, w.bad);
     // every image's reference set is seen by 2*spi hypothesis entries (sampled + greedy halves, rewards.py:53-56)
     hipLaunchKernelGGL(df_kernel, dim3(cic_cdiv(R, 4)), dim3(256), 0, st, w.keys, w.nuniq, w.ref_img, a->ref_off, 2 * B,
                        R, 2 * a->spi, w.ht_keys, w.ht_df, w.ht_size - 1);
@@ -311,7 +326,7 @@ extern "C" int cic_ciderd_reward(const cic_ciderd_args* a, void* ws, size_t ws_b
     hipLaunchKernelGGL(vec_kernel, dim3(cic_cdiv(S, 4)), dim3(256), 0, st, w.keys, w.cnt, w.nuniq, S, ref_len, w.ht_keys,
                        w.ht_df, w.ht_size - 1, w.vec, w.norm, w.df);
     hipLaunchKernelGGL(score_kernel, dim3(cic_cdiv(2 * B, 4)), dim3(256), 0, st, w.keys, w.nuniq, w.blen, w.vec, w.norm,
-                       a->ref_off, B, a->spi, 6.0, a->scores);
+                       a->ref_off, B, a->spi, 6.0, w.bad, a->scores);
     if (a->reward) hipLaunchKernelGGL(reward_kernel, dim3(1), dim3(256), 0, st, a->scores, B, a->reward, a->stats);
     CIC_LAUNCH_CHECK();
     if (a->dbg_keys) {   // exact-integer tables for the parity tests

@@ -49,6 +49,9 @@ int cic_a2c_cell_fused(Dual<const float> att_res, const float* Wa, const float* 
                        Dual<const uint8_t> keep, float p_drop, Dual<float> h_new, Dual<float> c_new, Dual<float> out, int B,
                        int nb, int H, hipStream_t st);
 int cic_logsoftmax_sample2(const cic_sampler_args* a, const cic_sampler_args* b, hipStream_t st);
+// dropout of the embedded regions with ragged region counts: rows beyond an image's own regions become 0
+int cic_att_keep_rows(const float* x, const uint8_t* keep, float p_drop, const float* masks, float* y, int B, int K, int H,
+                      hipStream_t st);
 int cic_relu_keep_fwd(const float* xpre, const uint8_t* keep, float p_drop, float* x, int64_t n, hipStream_t st);
 int cic_soft_mask(const float* soft_raw, const int32_t* seq, const int32_t* L, float* soft_out, int T, int B, int V1,
                   hipStream_t st);

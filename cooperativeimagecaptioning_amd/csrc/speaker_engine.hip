@@ -216,7 +216,13 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     for (int q = 0; q < nb; ++q) {
         if (!fc) {
             // att = dropout(relu(att_embed(att_raw)));  p_att = ctx2att(att)      (AttModel.py:315,319)
-            RUN(cic_apply_keep(io[q]->att_pre, io[q]->att_keep, io[q]->att_keep ? p_drop : 0.f, w[q].att, (int64_t)B * K * H, s));
+            // with att_masks: only an image's own region rows are embedded, the padded rows are 0   (:44-51)
+            if (io[q]->att_masks) {
+                RUN(cic_att_keep_rows(io[q]->att_pre, io[q]->att_keep, io[q]->att_keep ? p_drop : 0.f, io[q]->att_masks, w[q].att,
+                                      B, K, H, st));
+            } else {
+                RUN(cic_apply_keep(io[q]->att_pre, io[q]->att_keep, io[q]->att_keep ? p_drop : 0.f, w[q].att, (int64_t)B * K * H, s));
+            }
             RUN(gemm_nt(w[q].att, H, p->ctx2att_w, H, w[q].p_att, A, B * K, A, H, p->ctx2att_b, false, false, st));
         } else {
             // image step: (h0, c0) = LSTMCore(img_embed(fc_feats), zero state)          (FCModel.py:97-99,121,274-276,315)

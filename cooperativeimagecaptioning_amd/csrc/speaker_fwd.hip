@@ -444,6 +444,30 @@ __global__ __launch_bounds__(256) void apply_keep_kernel(const float* __restrict
     reinterpret_cast<f32x4*>(y)[idx] = v;
 }
 
+// Ragged region counts (att_masks != None): pack_wrapper (models/AttModel.py:30-51) embeds only the first
+// len_b = sum_k att_masks[b,k] region rows of image b and pads the rest back with ZEROS, so rows k >= len_b of the
+// embedded features are 0 (not relu(bias)):  y[b,k,:] = k < len_b ? x * keep * scale : 0
+__global__ __launch_bounds__(256) void att_keep_rows_kernel(const float* __restrict__ x, const uint8_t* __restrict__ keep,
+                                                            float scale, const float* __restrict__ masks,
+                                                            float* __restrict__ y, int B, int K, int H4) {
+    const int row = blockIdx.x;                       // one (image, region) row per workgroup
+    const int b = row / K, k = row % K;
+    float len = 0.f;
+    for (int j = 0; j < K; ++j) len += (float)(int)masks[(size_t)b * K + j];    // att_masks.data.long().sum(1)
+    const bool valid = (float)k < len;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    for (int c = threadIdx.x; c < H4; c += 256) {
+        const size_t idx = (size_t)row * H4 + c;
+        f32x4 v = reinterpret_cast<const f32x4*>(x)[idx];
+        if (keep) {
+            const uint32_t kp = *reinterpret_cast<const uint32_t*>(keep + idx * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] * ((float)((kp >> (8 * e)) & 0xffu) * scale);
+        }
+        reinterpret_cast<f32x4*>(y)[idx] = valid ? v : z4;
+    }
+}
+
 // x = dropout(relu(xpre))  — self.relu_dropout on soft_vec @ embed (models/AttModel.py:77-78,396-397)
 __global__ __launch_bounds__(256) void relu_keep_fwd_kernel(const float* __restrict__ xpre, const uint8_t* __restrict__ keep,
                                                             float scale, float* __restrict__ x, int64_t n4) {
@@ -1013,6 +1037,15 @@ extern "C" int cic_apply_keep(const float* x, const uint8_t* keep, float p_drop,
     CIC_REQUIRE(x && y && n > 0 && (n & 3) == 0);
     hipLaunchKernelGGL(apply_keep_kernel, dim3(cic_cdiv(n / 4, 256)), dim3(256), 0, cic_s(s), x, keep,
                        1.0f / (1.0f - p_drop), y, n / 4);
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+
+int cic_att_keep_rows(const float* x, const uint8_t* keep, float p_drop, const float* masks, float* y, int B, int K, int H,
+                      hipStream_t st) {
+    CIC_REQUIRE(x && y && masks && B > 0 && K > 0 && H > 0 && (H & 3) == 0);
+    hipLaunchKernelGGL(att_keep_rows_kernel, dim3(B * K), dim3(256), 0, st, x, keep, 1.0f / (1.0f - p_drop), masks, y, B, K,
+                       H / 4);
     CIC_LAUNCH_CHECK();
     return 0;
 }

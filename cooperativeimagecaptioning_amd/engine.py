@@ -246,9 +246,15 @@ def pack_refs(gts, device):
             torch.from_numpy(off).to(device))
 
 
-def ciderd_reward(gen, L_gen, greedy, L_greedy, refs, ref_off, spi=None, debug=False, ws=None):
+CIDERD_MAX_VOCAB = 32766      # n-gram keys pack 15 bits per token (ids 0 .. V+1)
+
+
+def ciderd_reward(gen, L_gen, greedy, L_greedy, refs, ref_off, spi=None, debug=False, ws=None,
+                  vocab_size=CIDERD_MAX_VOCAB):
     """get_self_critical_reward on the GPU.  gen/greedy: i32[B,T]; refs/ref_off from pack_refs.
-    -> dict(scores f64[2B], reward f32[B], stats f64[2] = (mean sampled score, cider_greedy))."""
+    -> dict(scores f64[2B], reward f32[B], stats f64[2] = (mean sampled score, cider_greedy)).
+    vocab_size: the captions' vocabulary (token ids 0 .. V+1); the call is refused (CicError) for V > 32766 and a
+    token outside the declared range turns the scores into NaN instead of aliasing another word."""
     dev = gen.device
     B, T = gen.shape
     n_images = ref_off.numel() - 1
@@ -264,6 +270,7 @@ def ciderd_reward(gen, L_gen, greedy, L_greedy, refs, ref_off, spi=None, debug=F
     a.gen, a.L_gen, a.greedy, a.L_greedy = _p(gen), _p(L_gen), _p(greedy), _p(L_greedy)
     a.refs, a.ref_off = _p(refs), _p(ref_off)
     a.scores, a.reward, a.stats = _p(out['scores']), _p(out['reward']), _p(out['stats'])
+    a.vocab_size = int(vocab_size)
     if debug:
         S = 2 * B + R
         out['dbg_keys'] = torch.zeros(S, 64, dtype=torch.int64, device=dev)

@@ -21,7 +21,8 @@ def init_scorer(cached_tokens):
 
 def get_self_critical_reward_device(refs, ref_off, sample, greedy, ws=None):
     """Device-resident form used by the joint model: DecodeResults in, device tensors out, no sync."""
-    return engine.ciderd_reward(sample.seq, sample.L, greedy.seq, greedy.L, refs, ref_off, ws=ws)
+    return engine.ciderd_reward(sample.seq, sample.L, greedy.seq, greedy.L, refs, ref_off, ws=ws,
+                                vocab_size=sample.dims.V)
 
 
 def _as_dev_i32(x, T=16):

@@ -53,6 +53,7 @@ class AlternatingJointModel(nn.Module):
         self.cider_optimization = getattr(opt, 'cider_optimization', 0)
         self.use_gen_cider_scores = getattr(opt, 'use_gen_cider_scores', 0)
         self._loss = {}
+        self.last_decodes = {}
         # MI355X: the greedy (baseline) decode and the sampled decode of a step read the same images and weights
         # and are independent until the reward, so they advance in lock step through shared launches
         # (cic_speaker_decode_fwd_pair: every per-timestep kernel once over 2B rows; bit-identical results).
@@ -246,6 +247,8 @@ class AlternatingJointModel(nn.Module):
             self._loss['avg_reward'] = coef.mean().detach()
             self._loss['cider_greedy'] = rw['stats'][1].detach()
             self._loss['loss_cider'] = lc.detach()[0]
+        # the decodes of this step (DecodeResult or None), for callers that want the generated tokens (evaluation, tests)
+        self.last_decodes = {'sample': sample, 'greedy': greedy}
         if sample is not None and sample.soft is not None:
             sample = None            # a partial-sampling decode without a CIDEr term: already queued above
         if sample is not None and spk_grad and (dslp is not None or getattr(sample, 'd_onehot', None) is not None):
@@ -287,6 +290,7 @@ class AlternatingJointModel(nn.Module):
                 self.setLossFlages(VSEWeight=oldVSE, MLEWeight=0, ciderFlag=0, DISCWeight=0)
                 cg = self.caption_generator
                 gen = cg.decode(att_feats, att_masks, 'multinomial', 1.0, grad=False)
+                self.last_decodes = {'sample': gen, 'greedy': None}
                 return self._listener_on_generated(fc_feats, gen)
             raise ValueError(f'unknown alternating_turn {alternating_turn!r}')
         finally:

@@ -435,6 +435,10 @@ typedef struct {
     double* stats;            /* out [2] mean sampled score, mean greedy score, or NULL */
     /* optional dumps of the exact integer tables (tests): sentence-major, 64 slots each */
     uint64_t* dbg_keys; int32_t* dbg_cnt; int32_t* dbg_df; int32_t* dbg_nuniq;
+    /* REQUIRED: the vocabulary size V of the captions (token ids 0 .. V+1).  n-gram keys pack 15 bits per token, so
+     * the call is refused unless 1 <= V <= 32766; a token outside [0, V+1] met on the device turns every score into
+     * NaN (the reference's string n-grams have no such limit: refusing beats aliasing two words silently). */
+    int vocab_size;
 } cic_ciderd_args;
 size_t cic_ciderd_ws_bytes(int B, int R);
 int cic_ciderd_reward(const cic_ciderd_args* a, void* ws, size_t ws_bytes, cic_stream_t s);

@@ -30,10 +30,20 @@ def dropout(x, keep, p):
     return x * (keep / (1.0 - p))
 
 
-def att_embed(P, att_raw, keep, p):
-    """AttModel.py:82-85,110,315 (use_bn=0, att_masks=None path of pack_wrapper :44-51)."""
+def att_embed(P, att_raw, keep, p, att_masks=None):
+    """AttModel.py:82-85,110,315 (use_bn=0) through pack_wrapper :44-51.  With att_masks the reference packs the first
+    len_b = sum_k att_masks[b, k] region rows of every image (sort_pack_padded_sequence :30-36), applies the
+    module to the packed rows only and pads back with zeros (pad_unsort_packed_sequence :38-41): rows k >= len_b
+    of the embedded features are exactly 0 (not relu(bias)), and the keep mask covers the packed rows only."""
     y = F.linear(att_raw, P['att_embed.0.weight'], P['att_embed.0.bias'])
-    return dropout(torch.relu(y), keep, p)
+    y = dropout(torch.relu(y), keep, p)
+    if att_masks is not None:
+        lens = att_masks.long().sum(1)
+        K = att_raw.shape[1]
+        assert int(lens.max()) == K, 'pad_packed_sequence pads to the longest image: one image must use all K rows'
+        valid = (torch.arange(K).unsqueeze(0) < lens.unsqueeze(1)).to(y.dtype)
+        y = y * valid.unsqueeze(2)
+    return y
 
 
 def ctx2att(P, att):
@@ -177,7 +187,7 @@ def sample(P, cfg, fc_feats, att_raw, att_masks, opt=None, noise=None, retrieval
     H = P['core.h2h.weight'].shape[1]
     h = torch.zeros(B, H)
     c = torch.zeros(B, H)
-    att = att_embed(P, att_raw, _n(noise, 'att_keep'), p)             # :315
+    att = att_embed(P, att_raw, _n(noise, 'att_keep'), p, att_masks)  # :315
     p_att = ctx2att(P, att)                                           # :319
     eos_one_hot = torch.zeros(1, V + 2)
     eos_one_hot[0, 0] = 1.0                                           # :297-304
@@ -295,7 +305,7 @@ def mle_forward(P, cfg, fc_feats, att_raw, att_masks, seq, masks, noise=None, ss
     H = P['core.h2h.weight'].shape[1]
     h = torch.zeros(B, H)
     c = torch.zeros(B, H)
-    att = att_embed(P, att_raw, _n(noise, 'att_keep'), p)
+    att = att_embed(P, att_raw, _n(noise, 'att_keep'), p, att_masks)
     p_att = ctx2att(P, att)
     outputs = []
     for i in range(seq.shape[1] - 1):                                 # :116
@@ -338,7 +348,7 @@ def sample_beam(P, cfg, fc_feats, att_raw, att_masks, opt=None):
     V, T = cfg['vocab_size'], cfg['seq_length']
     B = att_raw.shape[0]
     H = P['core.h2h.weight'].shape[1]
-    att_all = att_embed(P, att_raw, None, 0.0)
+    att_all = att_embed(P, att_raw, None, 0.0, att_masks)
     p_att_all = ctx2att(P, att_all)
     seq = torch.zeros(B, T, dtype=torch.long)
     logps = torch.zeros(B, T)

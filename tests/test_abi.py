@@ -29,3 +29,22 @@ def test_product_does_not_import_oracle():
             if f.endswith('.py'):
                 s = open(os.path.join(dp, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', s, re.M), f
+
+
+def test_ciderd_refuses_a_vocabulary_that_does_not_fit_its_ngram_keys():
+    """n-gram keys pack 15 bits per token (csrc/cider.hip): cic_ciderd_reward must refuse a vocabulary it cannot
+    represent instead of aliasing token ids silently.  The refusal happens on the host, before any launch."""
+    import ctypes as C
+    from cooperativeimagecaptioning_amd import _lib
+    fn = _lib.lib.cic_ciderd_reward
+    fn.argtypes = [C.POINTER(_lib.CiderdArgs), C.c_void_p, C.c_size_t, C.c_void_p]
+    fn.restype = C.c_int
+    dummy = (C.c_char * 64)()                     # never dereferenced: the call fails its argument checks first
+    a = _lib.CiderdArgs()
+    a.B, a.T, a.n_images, a.spi, a.R, a.Tr = 4, 16, 4, 1, 4, 16
+    for f in ('gen', 'L_gen', 'greedy', 'L_greedy', 'refs', 'ref_off', 'scores'):
+        setattr(a, f, C.addressof(dummy))
+    for bad in (0, 32767, 40000):
+        a.vocab_size = bad
+        assert fn(C.byref(a), C.addressof(dummy), 64, None) != 0
+        assert b'vocab_size' in _lib.lib.cic_last_error()

@@ -45,7 +45,8 @@ def run_decode(z, mode_name):
     ps = mode_name.endswith('_ps')
     ps_u = T_(nz['ps_u']).cuda().contiguous() if ps and 'ps_u' in nz else None
     ps_prob = cfg['prob_gumbel_softmax'] if mode_name == 'gumbel_ps' else cfg['prob_multinomial_soft']
-    out = engine.speaker_decode_fwd(dims, params, att_pre, mode, temp, None, keep('att_keep'), keep('x_keep'),
+    att_masks = T_(z['att_masks']).cuda().contiguous() if 'att_masks' in z else None     # masked_*: ragged regions
+    out = engine.speaker_decode_fwd(dims, params, att_pre, mode, temp, att_masks, keep('att_keep'), keep('x_keep'),
                                     keep('out_keep'), U, pick, cfg['decoding_constraint'],
                                     want_stv=mode_name.endswith('_st'), ps_u=ps_u, ps_prob=ps_prob if ps else 0.0)
     torch.cuda.synchronize()
@@ -57,7 +58,9 @@ CASES = [('sample_greedy_full', 'greedy'), ('sample_greedy_early', 'greedy'), ('
          ('sample_multinomial_temp', 'multinomial'), ('sample_gumbel_st', 'gumbel_st'),
          ('sample_gumbel_st_tau', 'gumbel_st'), ('sample_multinomial_st', 'multinomial_st'),
          ('sample_gumbel_ps', 'gumbel_ps'), ('sample_multinomial_ps', 'multinomial_ps'),
-         ('sample_multinomial_ps_tau', 'multinomial_ps')]
+         ('sample_multinomial_ps_tau', 'multinomial_ps'),
+         # ragged region counts + att_masks (pack_wrapper AttModel.py:44-51, masked attention :481-483)
+         ('masked_sample_greedy', 'greedy'), ('masked_sample_gumbel_st', 'gumbel_st')]
 
 
 @pytest.mark.parametrize('name,mode', CASES)

@@ -25,7 +25,7 @@ def _compare(grads, P, rtol=5e-4):
         np.testing.assert_allclose(got, ref, rtol=rtol, atol=rtol * scale + 1e-5 * glob, err_msg=k)
 
 
-def _run(W, cfg, att_raw, noise, mode_name, seed):
+def _run(W, cfg, att_raw, noise, mode_name, seed, att_masks=None):
     from cooperativeimagecaptioning_amd import engine, _lib
     from oracle import speaker as S
     B, K, D = att_raw.shape
@@ -40,7 +40,7 @@ def _run(W, cfg, att_raw, noise, mode_name, seed):
     # ---- oracle with autograd
     P = {k: v.clone().requires_grad_(True) for k, v in W.items()}
     opt = {'sample_max': 0, 'temperature': 1, 'use_one_hot': 0 if rr == 'reinforce' else 1}
-    res = S.sample(P, cfg, att_raw.mean(1), att_raw, None, opt, noise, rr)
+    res = S.sample(P, cfg, att_raw.mean(1), att_raw, att_masks, opt, noise, rr)
     g = torch.Generator().manual_seed(seed)
     if rr == 'reinforce':
         seq, slp = res
@@ -72,7 +72,8 @@ def _run(W, cfg, att_raw, noise, mode_name, seed):
     temp = (cfg['gumbel_temp'] if mode_name.startswith('gumbel') else
             cfg['multinomial_temp'] if mode_name in ('multinomial_st', 'multinomial_ps') else 1.0)
     ps_prob = cfg['prob_gumbel_softmax'] if mode_name == 'gumbel_ps' else cfg['prob_multinomial_soft']
-    f = engine.speaker_decode_fwd(dims, params, att_pre, mode, temp, None, nz('att_keep', torch.uint8),
+    am_d = att_masks.cuda().contiguous() if att_masks is not None else None
+    f = engine.speaker_decode_fwd(dims, params, att_pre, mode, temp, am_d, nz('att_keep', torch.uint8),
                                   nz('x_keep', torch.uint8), nz('out_keep', torch.uint8), nz('gumbel_u'), nz('pick'),
                                   0, want_stv=(oh is not None), ps_u=nz('ps_u') if ps else None,
                                   ps_prob=ps_prob if ps else 0.0)
@@ -92,17 +93,20 @@ def _run(W, cfg, att_raw, noise, mode_name, seed):
                                        ('sample_multinomial_st', 'multinomial_st'),
                                        ('sample_multinomial_plain', 'multinomial'),
                                        ('sample_gumbel_ps', 'gumbel_ps'), ('sample_multinomial_ps', 'multinomial_ps'),
-                                       ('sample_multinomial_ps_tau', 'multinomial_ps')])
+                                       ('sample_multinomial_ps_tau', 'multinomial_ps'),
+                                       ('masked_sample_gumbel_st', 'gumbel_st')])
 def test_decode_bwd_golden_inputs(name, mode):
     z = GU.load_case(name)
     cfg = GU.cfg_dict(z)
     W = {k: T_(v) for k, v in z['weights'].items()}
     noise = {k: T_(v) for k, v in GU.noise_dict(z, 'noise').items()}
-    _run(W, cfg, T_(z['att_raw']), noise, mode, 3)
+    _run(W, cfg, T_(z['att_raw']), noise, mode, 3, T_(z['att_masks']) if 'att_masks' in z else None)
 
 
-def test_decode_bwd_flagship_dims():
-    """H=E=A=512, K=36, V=9487 (the shapes the fast kernel paths are built for), small batch."""
+@pytest.mark.parametrize('masked', [False, True])
+def test_decode_bwd_flagship_dims(masked):
+    """H=E=A=512, K=36, V=9487 (the shapes the fast kernel paths are built for), small batch; `masked`: ragged region
+    counts (10..36 regions per image, zero-padded features, att_masks as dataloader.py:224-229 builds them)."""
     g = torch.Generator().manual_seed(21)
     B, K, D, H, V, T = 8, 36, 256, 512, 9487, 16
 
@@ -122,7 +126,12 @@ def test_decode_bwd_flagship_dims():
                  x_keep=(torch.rand(T + 1, B, H, generator=g) >= 0.5).float(),
                  out_keep=(torch.rand(T + 1, B, H, generator=g) >= 0.5).float(),
                  gumbel_u=torch.rand(T + 1, B, V + 1, generator=g))
-    _run(W, cfg, att_raw, noise, 'gumbel_st', 4)
+    am = None
+    if masked:
+        lens = torch.tensor([36, 10, 25, 36, 17, 30, 12, 33])
+        am = (torch.arange(K).unsqueeze(0) < lens.unsqueeze(1)).float()
+        att_raw = att_raw * am.unsqueeze(2)
+    _run(W, cfg, att_raw, noise, 'gumbel_st', 4, am)
 
 
 def test_decode_bwd_partial_sampling_flagship_dims():

@@ -38,7 +38,7 @@ def decode_tags(cfg, turn, n):
 
 CASES = ['joint_gumbel', 'joint_gumbel_dropout', 'joint_gumbel_tau', 'joint_multinomial', 'joint_reinforce_gt',
          'joint_reinforce_greedy', 'joint_reinforce_no', 'joint_reinforce_listener', 'joint_gumbel_mle',
-         'joint_plain_all', 'joint_gumbel_ps', 'joint_multinomial_ps']
+         'joint_plain_all', 'joint_gumbel_ps', 'joint_multinomial_ps', 'masked_joint_gumbel']
 
 
 @pytest.mark.parametrize('name', CASES)
@@ -60,11 +60,12 @@ def test_joint_step_matches_reference(name):
     fc, att = T_(z['fc']).cuda(), T_(z['att_raw']).cuda()
     labels, masks = T_(z['labels']).cuda(), T_(z['masks']).cuda()
     data = {'gts': GU.gts_list(z)}
+    att_masks = T_(z['att_masks']).cuda() if 'att_masks' in z else None      # masked_*: ragged region counts
     model.zero_grad()
     if turn == 'None':
-        loss = model(fc, labels, masks, data, att, None)
+        loss = model(fc, labels, masks, data, att, att_masks)
     else:
-        loss = model(fc, labels, masks, data, att, None, is_alternating=True, alternating_turn=turn)
+        loss = model(fc, labels, masks, data, att, att_masks, is_alternating=True, alternating_turn=turn)
     loss.backward()
     torch.cuda.synchronize()
     np.testing.assert_allclose(float(loss.detach()), float(np.asarray(z['loss']).reshape(-1)[0]), rtol=5e-5, atol=1e-6)
@@ -105,7 +106,7 @@ def test_cpu_input_fails_loudly():
               is_alternating=True, alternating_turn='speaker')
 
 
-@pytest.mark.parametrize('name', ['mle_plain', 'mle_dropout', 'mle_ss'])
+@pytest.mark.parametrize('name', ['mle_plain', 'mle_dropout', 'mle_ss', 'masked_mle'])
 def test_mle_forward_backward_matches_reference(name):
     """Att2in2Model.forward (teacher-forced MLE, models/AttModel.py:103-148) vs the reference."""
     from cooperativeimagecaptioning_amd import models
@@ -119,7 +120,8 @@ def test_mle_forward_backward_matches_reference(name):
     cg.noise.override = {'mle': GU.noise_dict(z, 'noise')}
     cg.ss_prob = float(z['ss_prob'])       # scheduled sampling (AttModel.py:118-129): recorded uniforms and draws
     cg.zero_grad()
-    loss = cg(T_(z['fc']).cuda(), T_(z['att_raw']).cuda(), None, T_(z['labels']).cuda(), T_(z['masks']).cuda())
+    att_masks = T_(z['att_masks']).cuda() if 'att_masks' in z else None
+    loss = cg(T_(z['fc']).cuda(), T_(z['att_raw']).cuda(), att_masks, T_(z['labels']).cuda(), T_(z['masks']).cuda())
     loss.backward()
     np.testing.assert_allclose(loss.item(), float(z['loss']), rtol=5e-5)
     grads = {k: p.grad for k, p in cg.named_parameters()}
@@ -229,6 +231,17 @@ def _full_size_step(opt, turn, decodes, logged_exact=(), logged_close=()):
     loss = model(*args) if turn is None else model(*args, is_alternating=True, alternating_turn=turn)
     loss.backward()
     torch.cuda.synchronize()
+    # every decoded token id of the step equals the oracle's, directly (north_star: bit-exact greedy arg-max indices;
+    # at V = 9487 near-ties between logits are likeliest)
+    for tag, key in (('sample', 'gen_result'), ('greedy', 'greedy_res')):
+        ref_tok = aux.get(key)
+        if ref_tok is None or tag not in decodes:
+            continue
+        got = model.last_decodes[tag]
+        L = int(got.L)
+        assert L == ref_tok.shape[1], (tag, L, ref_tok.shape)
+        np.testing.assert_array_equal(got.seq[:, :L].cpu().numpy(), ref_tok.numpy(), err_msg=tag + ' tokens')
+        assert int((ref_tok > 0).sum()) > B, tag                  # real captions, not all-EOS
     np.testing.assert_allclose(float(loss.detach()), float(ref_loss.detach()), rtol=1e-4, atol=1e-6)
     logged = model.loss()
     for k in logged_exact:

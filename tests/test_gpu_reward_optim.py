@@ -64,6 +64,26 @@ def test_ciderd_golden(name):
             assert int(dfg[s, i]) == int(df.get(ng, 0)), (s, ng)
 
 
+def test_ciderd_out_of_vocabulary_token_poisons_the_scores():
+    """A token id beyond the declared vocabulary would alias another word's 15-bit key field: the scores become NaN
+    (and a vocabulary that cannot be represented at all is refused, tests/test_abi.py)."""
+    from cooperativeimagecaptioning_amd import engine, _lib
+    z = GU.load_case('ciderd')
+    gts = GU.gts_list(z)
+    refs, off = engine.pack_refs(gts, 'cuda')
+    gen, greedy = _pad(z['gen']), _pad(z['greedy'])
+    Lg = torch.tensor([z['gen'].shape[1]], dtype=torch.int32).cuda()
+    Lr = torch.tensor([z['greedy'].shape[1]], dtype=torch.int32).cuda()
+    ok = engine.ciderd_reward(T_(gen).cuda(), Lg, T_(greedy).cuda(), Lr, refs, off, vocab_size=23)
+    assert torch.isfinite(ok['scores']).all()
+    bad = gen.copy()
+    bad[1, 0] = 40000                                     # row 1 has no <eos>: the token is inside the caption
+    out = engine.ciderd_reward(T_(bad).cuda(), Lg, T_(greedy).cuda(), Lr, refs, off, vocab_size=23)
+    assert torch.isnan(out['scores']).all()
+    with pytest.raises(_lib.CicError):
+        engine.ciderd_reward(T_(gen).cuda(), Lg, T_(greedy).cuda(), Lr, refs, off, vocab_size=40000)
+
+
 def test_ciderd_random_full_size():
     """B=128, 5 refs each, vocabulary 9487, ragged lengths, L < 16 for the greedy half."""
     from oracle import ciderd

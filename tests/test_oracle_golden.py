@@ -27,6 +27,11 @@ def params(z, prefix='', grad=False):
     return out
 
 
+def masks_t(z):
+    """att_masks of a ragged-region fixture (masked_*), else None."""
+    return T(z['att_masks']) if 'att_masks' in z else None
+
+
 def noise_t(z, prefix):
     nd = GU.noise_dict(z, prefix)
     return {k: T(v) for k, v in nd.items()} or None
@@ -73,7 +78,8 @@ def test_kernels_speaker():
 SAMPLE_CASES = ['sample_greedy_full', 'sample_greedy_early', 'sample_greedy_dropout',
                 'sample_multinomial_plain', 'sample_multinomial_temp', 'sample_gumbel_st',
                 'sample_gumbel_st_tau', 'sample_multinomial_st', 'sample_gumbel_ps',
-                'sample_multinomial_ps', 'sample_multinomial_ps_tau', 'sample_constraint']
+                'sample_multinomial_ps', 'sample_multinomial_ps_tau', 'sample_constraint',
+                'masked_sample_greedy', 'masked_sample_gumbel_st']
 
 
 @pytest.mark.parametrize('name', SAMPLE_CASES)
@@ -83,7 +89,7 @@ def test_sample(name):
     cfg = GU.cfg_dict(z)
     opt = {k[4:]: (int(v) if k[4:] != 'temperature' else float(v)) for k, v in z.items()
            if k.startswith('opt.')}
-    res = S.sample(P, cfg, T(z['fc']), T(z['att_raw']), None, opt, noise_t(z, 'noise'),
+    res = S.sample(P, cfg, T(z['fc']), T(z['att_raw']), masks_t(z), opt, noise_t(z, 'noise'),
                    cfg['retrieval_reward'])
     assert res[0].shape == z['res0'].shape, 'L differs'
     np.testing.assert_array_equal(res[0].numpy(), z['res0'])          # token ids: exact
@@ -91,12 +97,12 @@ def test_sample(name):
         close(res[i], z[f'res{i}'], rtol=5e-5, atol=5e-6)
 
 
-@pytest.mark.parametrize('name', ['mle_plain', 'mle_dropout', 'mle_ss'])
+@pytest.mark.parametrize('name', ['mle_plain', 'mle_dropout', 'mle_ss', 'masked_mle'])
 def test_mle(name):
     z = GU.load_case(name)
     P = params(z, grad=True)
     cfg = GU.cfg_dict(z)
-    loss = S.mle_forward(P, cfg, T(z['fc']), T(z['att_raw']), None, T(z['labels']), T(z['masks']),
+    loss = S.mle_forward(P, cfg, T(z['fc']), T(z['att_raw']), masks_t(z), T(z['labels']), T(z['masks']),
                          noise_t(z, 'noise'), float(z['ss_prob']))
     close(loss, z['loss'])
     loss.backward()
@@ -159,7 +165,7 @@ def test_ciderd_counts_quirks():
 JOINT_CASES = ['joint_gumbel', 'joint_gumbel_dropout', 'joint_gumbel_tau', 'joint_multinomial',
                'joint_gumbel_ps', 'joint_multinomial_ps', 'joint_reinforce_gt',
                'joint_reinforce_greedy', 'joint_reinforce_no', 'joint_reinforce_listener',
-               'joint_gumbel_mle', 'joint_plain_all']
+               'joint_gumbel_mle', 'joint_plain_all', 'masked_joint_gumbel']
 
 
 def joint_noise(z, cfg, turn):
@@ -196,7 +202,7 @@ def test_joint(name):
     Ps = params(z, 'caption_generator.', grad=True)
     Pl = params(z, 'vse.', grad=True)
     turn = str(z['turn'])
-    batch = dict(fc_feats=T(z['fc']), att_feats=T(z['att_raw']), att_masks=None, labels=T(z['labels']),
+    batch = dict(fc_feats=T(z['fc']), att_feats=T(z['att_raw']), att_masks=masks_t(z), labels=T(z['labels']),
                  masks=T(z['masks']), gts=GU.gts_list(z))
     noise = joint_noise(z, cfg, turn)
     if turn == 'None':
@@ -257,13 +263,13 @@ def test_fc_sample_matches_reference(name):
 
 
 # ---- AttModel.sample_beam (the evaluation decode) -------------------------------------------
-@pytest.mark.parametrize('name', ['beam2', 'beam3_early', 'beam5_constraint'])
+@pytest.mark.parametrize('name', ['beam2', 'beam3_early', 'beam5_constraint', 'masked_beam3'])
 def test_sample_beam_matches_reference(name):
     z = GU.load_case(name)
     cfg = GU.cfg_dict(z)
     P = params(z)
     with torch.no_grad():
-        seq, lps, score = S.sample_beam(P, cfg, T(z['fc']), T(z['att_raw']), None,
+        seq, lps, score = S.sample_beam(P, cfg, T(z['fc']), T(z['att_raw']), masks_t(z),
                                         {'beam_size': int(z['beam']), 'decoding_constraint': cfg['decoding_constraint']})
     np.testing.assert_array_equal(seq.numpy(), z['res0'])
     close(lps, z['res1'])

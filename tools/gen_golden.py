@@ -9,6 +9,7 @@ partial-sampling row uniforms) and writes inputs + weights + noise + outputs as 
 fixtures are data only.  tests/test_oracle_golden.py replays them against oracle/.
 
 Usage:  python tools/gen_golden.py            (rewrites tests/golden/*.npz)
+        python tools/gen_golden.py --only-masks   (the att_masks cases only)
 """
 import argparse
 import os
@@ -122,14 +123,37 @@ class Recorder:
         return ev
 
 
-def split_decodes(events, T, B, E, H, Vp1):
+def unpack_rows(torch, packed, att_masks):
+    """[N, H] rows in pack_padded_sequence order (AttModel.py:30-36: images sorted by region count, descending,
+    then region-major) -> [B, K, H] with ones at the padded rows."""
+    lens = att_masks.long().sum(1)
+    sorted_lengths, indices = torch.sort(lens, descending=True)
+    B, K = att_masks.shape
+    out = np.ones((B, K, packed.shape[1]), np.float32)
+    n = 0
+    for k in range(int(sorted_lengths[0])):
+        for i in range(B):
+            if int(sorted_lengths[i]) > k:
+                out[int(indices[i]), k] = packed[n].numpy()
+                n += 1
+    assert n == packed.shape[0]
+    return out
+
+
+def split_decodes(events, T, B, E, H, Vp1, att_masks=None):
     """Split a flat event list into per-decode noise dicts (see oracle/speaker.py).
     A 3-D dropout event (att_embed) opens a new decode; 2-D dropout events then
     alternate x_keep[t], out_keep[t]; rand / multinomial / uniform events belong to
-    the step whose x_keep comes next."""
+    the step whose x_keep comes next.  With att_masks the att_embed dropout runs on the packed
+    valid region rows (pack_wrapper, AttModel.py:44-51): a 2-D event of sum(att_masks) rows."""
     decs = []
     cur = None
+    n_packed = int(att_masks.sum()) if att_masks is not None else -1
+    assert n_packed != B
     for kind, t in events:
+        if kind == 'dropout' and t.dim() == 2 and t.shape[0] == n_packed:
+            import torch as _torch
+            kind, t = 'dropout', _torch.from_numpy(unpack_rows(_torch, t, att_masks))
         if kind == 'dropout' and t.dim() == 3:
             cur = dict(att_keep=t.numpy(), x_keep=np.ones((T, B, E), np.float32),
                        out_keep=np.ones((T, B, H), np.float32),
@@ -210,6 +234,23 @@ def make_batch(torch, opt, K=7, seed=0, ncap=5):
                 masks=torch.from_numpy(masks), gts=gts)
 
 
+MASK_LENS = (7, 3, 5, 4, 7, 6, 3, 5)
+
+
+def mask_batch(torch, batch):
+    """Ragged region counts as dataloader.get_batch builds them (dataloader.py:218-229): features zero-padded to
+    the longest image, att_masks = 1 on an image's own rows."""
+    B, K, _ = batch['att_feats'].shape
+    am = torch.zeros(B, K)
+    for i in range(B):
+        am[i, :MASK_LENS[i % len(MASK_LENS)]] = 1
+    assert int(am.sum(1).max()) == K
+    batch['att_feats'] = batch['att_feats'] * am.unsqueeze(2)
+    batch['fc_feats'] = batch['att_feats'].sum(1) / am.sum(1, keepdim=True)
+    batch['att_masks'] = am
+    return batch
+
+
 def widen(cg, batch):
     for w in (cg.core.i2h.weight, cg.core.h2h.weight, cg.core.a2c.weight, cg.embed[0].weight,
               cg.core.attention.h2att.weight, cg.core.attention.alpha_net.weight):
@@ -219,7 +260,10 @@ def widen(cg, batch):
     sc = (0.3 + 0.5 * np.arange(B)).astype(np.float32)
     import torch
     batch['att_feats'] = batch['att_feats'] * torch.from_numpy(sc).view(B, 1, 1)
-    batch['fc_feats'] = batch['att_feats'].mean(1)
+    if batch.get('att_masks') is not None:
+        batch['fc_feats'] = batch['att_feats'].sum(1) / batch['att_masks'].sum(1, keepdim=True)
+    else:
+        batch['fc_feats'] = batch['att_feats'].mean(1)
 
 
 def sd_np(module, prefix=''):
@@ -240,7 +284,12 @@ def base_weights(seed, module):
     if key not in _BASES:
         _BASES[key] = sd
         os.makedirs(OUT, exist_ok=True)
-        np.savez_compressed(os.path.join(OUT, key + '.npz'), **sd)
+        path = os.path.join(OUT, key + '.npz')
+        if os.path.exists(path):            # same seed, same draws: leave an identical file alone
+            old = np.load(path, allow_pickle=False)
+            if sorted(old.files) == sorted(sd) and all(np.array_equal(old[k], sd[k]) for k in sd):
+                return key
+        np.savez_compressed(path, **sd)
         print('wrote', key, sum(a.nbytes for a in sd.values()) // 1024, 'KiB')
     return key
 
@@ -349,28 +398,33 @@ def gen_fc(torch, models, rec):
              **fc_noise(ev, opt.seq_length + 2, opt.batch_size, opt.rnn_size))
 
 
-BEAM_CASES = (('beam2', 2, 0, 2.0, 22), ('beam3_early', 3, 0, 1.8, 22), ('beam5_constraint', 5, 1, 1.86, 22))
+BEAM_CASES = (('beam2', 2, 0, 2.0, 22, False), ('beam3_early', 3, 0, 1.8, 22, False),
+              ('beam5_constraint', 5, 1, 1.86, 22, False))
+BEAM_CASES_MASKED = (('masked_beam3', 3, 0, 1.8, 22, True),)
 
 
-def gen_beam(torch, models, rec):
+def gen_beam(torch, models, rec, cases=BEAM_CASES):
     """AttModel.sample_beam (evaluation decode, AttModel.py:150-289): beam 2 (eval.py's setting), 3 and 5 with the
-    decoding constraint."""
-    for name, beam, dc, bias0, seed in BEAM_CASES:
+    decoding constraint; `masked`: ragged region counts + att_masks."""
+    for name, beam, dc, bias0, seed, masked in cases:
         opt = make_opt(batch_size=5, decoding_constraint=dc)
         torch.manual_seed(seed)
         m = models.AlternatingJointModel(opt)
         cg = m.caption_generator
         batch = make_batch(torch, opt, K=7, seed=seed)
+        if masked:
+            mask_batch(torch, batch)
         widen(cg, batch)
         cg.logit.bias.data[0] = bias0
         cg.eval()
         with torch.no_grad():
-            seq, lps = cg.sample(batch['fc_feats'], batch['att_feats'], None, {'beam_size': beam, 'decoding_constraint': dc})
+            seq, lps = cg.sample(batch['fc_feats'], batch['att_feats'], batch['att_masks'],
+                                 {'beam_size': beam, 'decoding_constraint': dc})
         score = np.array([float(cg.done_beams[k][0]['p']) for k in range(opt.batch_size)], np.float32)
         nd = np.array([len(cg.done_beams[k]) for k in range(opt.batch_size)])
         print(name, 'lens', (seq > 0).sum(1).tolist(), 'done beams per image', nd.tolist())
         save(name, **{'w.' + k: v for k, v in sd_np(cg).items()}, **opt_np(opt), att_raw=batch['att_feats'], fc=batch['fc_feats'],
-             res0=seq, res1=lps, score=score, beam=np.int64(beam))
+             res0=seq, res1=lps, score=score, beam=np.int64(beam), att_masks=batch['att_masks'])
 
 
 def gen_retrieval(torch):
@@ -398,6 +452,7 @@ def main():
     torch, models, rewards = install_harness()
     rec = Recorder(torch)
     torch.set_num_threads(4)
+    only_masks = '--only-masks' in sys.argv     # the att_masks cases only (other fixtures untouched)
     if '--only-retrieval' in sys.argv:
         gen_retrieval(torch)
         return
@@ -414,32 +469,75 @@ def main():
         m._wkey = base_weights(seed, m)
         if eos_bias is not None:
             m.caption_generator.logit.bias.data[0] = eos_bias
-        # make biases non-trivial so a dropped bias shows
         return m
+    rewards.init_scorer('corpus')
 
     # ------------------------------------------------------------------ S3 / S4 / S5 kernels
-    opt = make_opt()
-    m = build(opt, 1)
-    cg = m.caption_generator
-    batch = make_batch(torch, opt, K=7, seed=1)
-    B, H = opt.batch_size, opt.rnn_size
-    g = torch.Generator().manual_seed(7)
-    h = torch.randn(B, H, generator=g) * 0.5
-    c = torch.randn(B, H, generator=g) * 0.5
-    att = cg.att_embed(batch['att_feats'])
-    p_att = cg.ctx2att(att)
-    att_res = cg.core.attention(h, att, p_att, None)
-    am = (torch.rand(B, 7, generator=g) > 0.3).float()
-    am[:, 0] = 1
-    att_res_m = cg.core.attention(h, att, p_att, am)
-    xt = torch.randn(B, opt.input_encoding_size, generator=g)
-    out, st = cg.core(xt, None, att, p_att, None, (h.unsqueeze(0), c.unsqueeze(0)))
-    logp = torch.nn.functional.log_softmax(cg.logit(out), dim=1)
-    save('kernels_speaker', **weights_of(m._wkey, cg, 'caption_generator.'), **opt_np(opt), att_raw=batch['att_feats'], h=h, c=c, xt=xt,
-         att=att, p_att=p_att, att_res=att_res, att_masks=am, att_res_masked=att_res_m,
-         out=out, h2=st[0][0], c2=st[1][0], logp=logp)
+    def kernel_cases():
+        opt = make_opt()
+        m = build(opt, 1)
+        cg = m.caption_generator
+        batch = make_batch(torch, opt, K=7, seed=1)
+        B, H = opt.batch_size, opt.rnn_size
+        g = torch.Generator().manual_seed(7)
+        h = torch.randn(B, H, generator=g) * 0.5
+        c = torch.randn(B, H, generator=g) * 0.5
+        att = cg.att_embed(batch['att_feats'])
+        p_att = cg.ctx2att(att)
+        att_res = cg.core.attention(h, att, p_att, None)
+        am = (torch.rand(B, 7, generator=g) > 0.3).float()
+        am[:, 0] = 1
+        att_res_m = cg.core.attention(h, att, p_att, am)
+        xt = torch.randn(B, opt.input_encoding_size, generator=g)
+        out, st = cg.core(xt, None, att, p_att, None, (h.unsqueeze(0), c.unsqueeze(0)))
+        logp = torch.nn.functional.log_softmax(cg.logit(out), dim=1)
+        save('kernels_speaker', **weights_of(m._wkey, cg, 'caption_generator.'), **opt_np(opt), att_raw=batch['att_feats'], h=h, c=c, xt=xt,
+             att=att, p_att=p_att, att_res=att_res, att_masks=am, att_res_masked=att_res_m,
+             out=out, h2=st[0][0], c2=st[1][0], logp=logp)
 
     # ------------------------------------------------------------------ S1 decodes
+    def sample_case(name, rr, kw, opts_, eos, masked=False):
+        opt = make_opt(retrieval_reward=rr, **kw)
+        m = build(opt, 2, None if eos == 'search' else eos)
+        cg = m.caption_generator
+        cg.train()
+        batch = make_batch(torch, opt, K=7, seed=2)
+        if masked:
+            mask_batch(torch, batch)
+        am = batch['att_masks']
+        if eos == 'search':
+            # greedy decodes finish all-at-once for a large EOS bias and never for a small
+            # one (SURVEY.md Appendix A.16): widen the logits, then scan for mixed lengths
+            cg.logit.weight.data.mul_(4.0)
+            found = None
+            for bias in np.linspace(0.0, 3.0, 61):
+                cg.logit.bias.data[0] = float(bias)
+                torch.manual_seed(11)
+                try:
+                    r = cg.sample(batch['fc_feats'], batch['att_feats'], am, dict(opts_))
+                except ValueError:
+                    break
+                lens = (r[0] > 0).sum(1)
+                if 2 <= r[0].shape[1] < opt.seq_length and len(set(lens.tolist())) >= 3:
+                    found = float(bias)
+            assert found is not None, name
+            cg.logit.bias.data[0] = found
+        torch.manual_seed(11)
+        rec.start()
+        res = cg.sample(batch['fc_feats'], batch['att_feats'], am, dict(opts_))
+        ev = rec.stop()
+        T = opt.seq_length + 1
+        nd = split_decodes(ev, T, opt.batch_size, opt.input_encoding_size, opt.rnn_size, opt.vocab_size + 1, am)
+        nz = flat_noise('noise', nd[0]) if nd else {}
+        outs = {f'res{i}': r for i, r in enumerate(res)}
+        print(name, 'L =', res[0].shape[1])
+        save(name, **weights_of(m._wkey, cg, 'caption_generator.'), **opt_np(opt), **nz, **outs, att_raw=batch['att_feats'],
+             fc=batch['fc_feats'], att_masks=am, **{'opt.' + k: np.float64(v) for k, v in opts_.items()})
+
+    SAMPLE_MASKED = [
+        ('masked_sample_greedy', 'gumbel', {'drop_prob_lm': 0.5}, {'sample_max': 1}, 'search'),
+        ('masked_sample_gumbel_st', 'gumbel', {'drop_prob_lm': 0.5}, {'sample_max': 0, 'temperature': 1, 'use_one_hot': 1}, 2.5),
+    ]
     for name, rr, kw, opts_, eos in [
         ('sample_greedy_full', 'gumbel', {}, {'sample_max': 1}, None),
         ('sample_greedy_early', 'gumbel', {}, {'sample_max': 1}, 'search'),
@@ -454,128 +552,106 @@ def main():
         ('sample_multinomial_ps_tau', 'multinomial_soft', {'multinomial_temp': 2.0}, {'sample_max': 0, 'temperature': 1, 'use_one_hot': 1}, 2.5),
         ('sample_constraint', 'reinforce', {'decoding_constraint': 1}, {'sample_max': 1}, None),
     ]:
-        opt = make_opt(retrieval_reward=rr, **kw)
-        m = build(opt, 2, None if eos == 'search' else eos)
-        cg = m.caption_generator
-        cg.train()
-        batch = make_batch(torch, opt, K=7, seed=2)
-        if eos == 'search':
-            # greedy decodes finish all-at-once for a large EOS bias and never for a small
-            # one (SURVEY.md Appendix A.16): widen the logits, then scan for mixed lengths
-            cg.logit.weight.data.mul_(4.0)
-            found = None
-            for bias in np.linspace(0.0, 3.0, 61):
-                cg.logit.bias.data[0] = float(bias)
-                torch.manual_seed(11)
-                try:
-                    r = cg.sample(batch['fc_feats'], batch['att_feats'], None, dict(opts_))
-                except ValueError:
-                    break
-                lens = (r[0] > 0).sum(1)
-                if 2 <= r[0].shape[1] < opt.seq_length and len(set(lens.tolist())) >= 3:
-                    found = float(bias)
-            assert found is not None, name
-            cg.logit.bias.data[0] = found
-        torch.manual_seed(11)
-        rec.start()
-        res = cg.sample(batch['fc_feats'], batch['att_feats'], None, dict(opts_))
-        ev = rec.stop()
-        T = opt.seq_length + 1
-        nd = split_decodes(ev, T, opt.batch_size, opt.input_encoding_size, opt.rnn_size, opt.vocab_size + 1)
-        nz = flat_noise('noise', nd[0]) if nd else {}
-        outs = {f'res{i}': r for i, r in enumerate(res)}
-        print(name, 'L =', res[0].shape[1])
-        save(name, **weights_of(m._wkey, cg, 'caption_generator.'), **opt_np(opt), **nz, **outs, att_raw=batch['att_feats'],
-             fc=batch['fc_feats'], **{'opt.' + k: np.float64(v) for k, v in opts_.items()})
+        if not only_masks:
+            sample_case(name, rr, kw, opts_, eos)
 
     # ------------------------------------------------------------------ S2 MLE
-    for name, kw, ss in [('mle_plain', {}, 0.0), ('mle_dropout', {'drop_prob_lm': 0.5}, 0.0),
-                         ('mle_ss', {'drop_prob_lm': 0.5}, 0.25)]:
+    def mle_case(name, kw, ss, masked=False):
         opt = make_opt(**kw)
         m = build(opt, 3)
         cg = m.caption_generator
         cg.train()
         cg.ss_prob = ss
         batch = make_batch(torch, opt, K=7, seed=3)
+        if masked:
+            mask_batch(torch, batch)
+        am = batch['att_masks']
         torch.manual_seed(12)
         rec.start()
-        loss = cg(batch['fc_feats'], batch['att_feats'], None, batch['labels'], batch['masks'])
+        loss = cg(batch['fc_feats'], batch['att_feats'], am, batch['labels'], batch['masks'])
         ev = rec.stop()
         loss.backward()
         T = opt.seq_length + 1
         # scheduled sampling draws: uniform_ [B] then (maybe) multinomial per step i>=1
-        nd = split_decodes(ev, T, opt.batch_size, opt.input_encoding_size, opt.rnn_size, opt.vocab_size + 1)[0]
+        nd = split_decodes(ev, T, opt.batch_size, opt.input_encoding_size, opt.rnn_size, opt.vocab_size + 1, am)[0]
         if 'ps_u' in nd:
             nd['ss_u'] = nd.pop('ps_u')
         grads = digests((k, p.grad) for k, p in cg.named_parameters() if p.grad is not None)
         save(name, **weights_of(m._wkey, cg, 'caption_generator.'), **opt_np(opt), **flat_noise('noise', nd), **grads, loss=loss,
-             ss_prob=np.float64(ss), att_raw=batch['att_feats'], fc=batch['fc_feats'],
+             ss_prob=np.float64(ss), att_raw=batch['att_feats'], fc=batch['fc_feats'], att_masks=am,
              labels=batch['labels'], masks=batch['masks'])
 
+    for name, kw, ss in [('mle_plain', {}, 0.0), ('mle_dropout', {'drop_prob_lm': 0.5}, 0.0),
+                         ('mle_ss', {'drop_prob_lm': 0.5}, 0.25)]:
+        if not only_masks:
+            mle_case(name, kw, ss)
+
     # ------------------------------------------------------------------ V1-V4 listener
-    opt = make_opt()
-    m = build(opt, 4)
-    vse = m.vse
-    batch = make_batch(torch, opt, K=7, seed=4)
-    B, V = opt.batch_size, opt.vocab_size
-    img = vse.img_enc(batch['fc_feats'])
-    cap = vse.txt_enc(batch['labels'], batch['masks'])
-    onehot = torch.zeros(B, batch['labels'].shape[1], V + 2)
-    onehot.scatter_(2, batch['labels'].unsqueeze(2), 1.0)
-    g = torch.Generator().manual_seed(5)
-    soft = torch.softmax(torch.randn(B, batch['labels'].shape[1], V + 2, generator=g), 2)
-    soft.requires_grad_(True)
-    cap_oh = vse.txt_enc(onehot, batch['masks'])
-    res = {}
-    for wb in (False, True):
-        for oor in ('off', 'image', 'caption'):
-            res[f'loss_wb{int(wb)}_{oor}'] = vse(batch['fc_feats'], None, batch['labels'], batch['masks'], wb, oor)
-    vse.zero_grad()
-    loss_soft = vse(batch['fc_feats'], None, soft, batch['masks'])
-    loss_soft.backward()
-    grads = digests((k, p.grad) for k, p in vse.named_parameters())
-    save('listener', **weights_of(m._wkey, vse, 'vse.'), **opt_np(opt), fc=batch['fc_feats'], labels=batch['labels'],
-         masks=batch['masks'], img_emb=img, cap_emb=cap, cap_emb_onehot=cap_oh, soft=soft,
-         loss_soft=loss_soft, grad_soft=soft.grad, **grads, **res)
-    for name, kw in [('listener_mean', dict(vse_pool_type='mean', vse_max_violation=0)),
-                     ('listener_max', dict(vse_pool_type='max', vse_use_abs=1, vse_no_imgnorm=1))]:
-        opt2 = make_opt(**kw)
-        m2 = build(opt2, 4)
-        l = m2.vse(batch['fc_feats'], None, batch['labels'], batch['masks'])
-        save(name, **weights_of(m2._wkey, m2.vse, 'vse.'), **opt_np(opt2), fc=batch['fc_feats'], labels=batch['labels'],
-             masks=batch['masks'], loss=l)
+    def listener_cases():
+        opt = make_opt()
+        m = build(opt, 4)
+        vse = m.vse
+        batch = make_batch(torch, opt, K=7, seed=4)
+        B, V = opt.batch_size, opt.vocab_size
+        img = vse.img_enc(batch['fc_feats'])
+        cap = vse.txt_enc(batch['labels'], batch['masks'])
+        onehot = torch.zeros(B, batch['labels'].shape[1], V + 2)
+        onehot.scatter_(2, batch['labels'].unsqueeze(2), 1.0)
+        g = torch.Generator().manual_seed(5)
+        soft = torch.softmax(torch.randn(B, batch['labels'].shape[1], V + 2, generator=g), 2)
+        soft.requires_grad_(True)
+        cap_oh = vse.txt_enc(onehot, batch['masks'])
+        res = {}
+        for wb in (False, True):
+            for oor in ('off', 'image', 'caption'):
+                res[f'loss_wb{int(wb)}_{oor}'] = vse(batch['fc_feats'], None, batch['labels'], batch['masks'], wb, oor)
+        vse.zero_grad()
+        loss_soft = vse(batch['fc_feats'], None, soft, batch['masks'])
+        loss_soft.backward()
+        grads = digests((k, p.grad) for k, p in vse.named_parameters())
+        save('listener', **weights_of(m._wkey, vse, 'vse.'), **opt_np(opt), fc=batch['fc_feats'], labels=batch['labels'],
+             masks=batch['masks'], img_emb=img, cap_emb=cap, cap_emb_onehot=cap_oh, soft=soft,
+             loss_soft=loss_soft, grad_soft=soft.grad, **grads, **res)
+        for name, kw in [('listener_mean', dict(vse_pool_type='mean', vse_max_violation=0)),
+                         ('listener_max', dict(vse_pool_type='max', vse_use_abs=1, vse_no_imgnorm=1))]:
+            opt2 = make_opt(**kw)
+            m2 = build(opt2, 4)
+            l = m2.vse(batch['fc_feats'], None, batch['labels'], batch['masks'])
+            save(name, **weights_of(m2._wkey, m2.vse, 'vse.'), **opt_np(opt2), fc=batch['fc_feats'], labels=batch['labels'],
+                 masks=batch['masks'], loss=l)
 
     # ------------------------------------------------------------------ R1-R4 CIDEr-D
-    rewards.init_scorer('corpus')
-    rs = np.random.RandomState(9)
-    B, L = 12, 16
-    V = 23
+    def cider_cases():
+        rewards.init_scorer('corpus')
+        rs = np.random.RandomState(9)
+        B, L = 12, 16
+        V = 23
 
-    def rnd_rows(n, Lr, p0):
-        a = rs.randint(1, V, size=(n, Lr))
-        for i in range(n):
-            if rs.rand() < p0:
-                a[i, rs.randint(0, Lr):] = 0
-        return a
-    gen = rnd_rows(B, L, 0.7)
-    gen[0, :] = 0            # EOS first
-    gen[1] = 3               # repeated token, no EOS
-    gen[2, :5] = [4, 5, 4, 5, 4]
-    greedy = rnd_rows(B, 11, 0.7)
-    gts = [rnd_rows(rs.randint(1, 6), 16, 0.9) for _ in range(B)]
-    gts[3][0] = gen[3]       # exact match
-    sc, cg_ = rewards.get_self_critical_reward({'gts': gts}, torch.from_numpy(gen), torch.from_numpy(greedy))
-    cgen, sc2, cg2 = rewards.get_self_critical_reward({'gts': gts}, torch.from_numpy(gen),
-                                                      torch.from_numpy(greedy), True)
-    ngts = np.array([len(x) for x in gts])
-    gts_flat = np.concatenate(gts, 0)
-    save('ciderd', gen=gen, greedy=greedy, gts_flat=gts_flat, gts_count=ngts, reward=sc,
-         cider_greedy=np.float64(cg_), cider_gen=cgen)
-    # seq_per_img = 2 variant
-    gts2 = gts[:6]
-    sc3, cg3 = rewards.get_self_critical_reward({'gts': gts2}, torch.from_numpy(gen), torch.from_numpy(greedy))
-    save('ciderd_spi2', gen=gen, greedy=greedy, gts_flat=np.concatenate(gts2, 0),
-         gts_count=np.array([len(x) for x in gts2]), reward=sc3, cider_greedy=np.float64(cg3))
+        def rnd_rows(n, Lr, p0):
+            a = rs.randint(1, V, size=(n, Lr))
+            for i in range(n):
+                if rs.rand() < p0:
+                    a[i, rs.randint(0, Lr):] = 0
+            return a
+        gen = rnd_rows(B, L, 0.7)
+        gen[0, :] = 0            # EOS first
+        gen[1] = 3               # repeated token, no EOS
+        gen[2, :5] = [4, 5, 4, 5, 4]
+        greedy = rnd_rows(B, 11, 0.7)
+        gts = [rnd_rows(rs.randint(1, 6), 16, 0.9) for _ in range(B)]
+        gts[3][0] = gen[3]       # exact match
+        sc, cg_ = rewards.get_self_critical_reward({'gts': gts}, torch.from_numpy(gen), torch.from_numpy(greedy))
+        cgen, sc2, cg2 = rewards.get_self_critical_reward({'gts': gts}, torch.from_numpy(gen),
+                                                          torch.from_numpy(greedy), True)
+        ngts = np.array([len(x) for x in gts])
+        gts_flat = np.concatenate(gts, 0)
+        save('ciderd', gen=gen, greedy=greedy, gts_flat=gts_flat, gts_count=ngts, reward=sc,
+             cider_greedy=np.float64(cg_), cider_gen=cgen)
+        # seq_per_img = 2 variant
+        gts2 = gts[:6]
+        sc3, cg3 = rewards.get_self_critical_reward({'gts': gts2}, torch.from_numpy(gen), torch.from_numpy(greedy))
+        save('ciderd_spi2', gen=gen, greedy=greedy, gts_flat=np.concatenate(gts2, 0),
+             gts_count=np.array([len(x) for x in gts2]), reward=sc3, cider_greedy=np.float64(cg3))
 
     # ------------------------------------------------------------------ A1 full joint steps
     cases = [
@@ -592,11 +668,14 @@ def main():
         ('joint_gumbel_mle', dict(retrieval_reward='gumbel', caption_loss_weight=0.5, use_gen_cider_scores=1), 'speaker', 2.5),
         ('joint_plain_all', dict(retrieval_reward='gumbel', caption_loss_weight=1.0, vse_loss_weight=1.0), None, 2.5),
     ]
-    for name, kw, turn, eos in cases:
+    def joint_case(name, kw, turn, eos, masked=False):
         opt = make_opt(**kw)
         m = build(opt, 5, None)
         m.train()
         batch = make_batch(torch, opt, K=7, seed=5)
+        if masked:
+            mask_batch(torch, batch)
+        am = batch['att_masks']
         cg = m.caption_generator
         # random-init greedy decodes are knife-edge (never EOS / all EOS at t=1, SURVEY.md
         # Appendix A.16): widen the dynamics so the state, and with it EOS, varies per row
@@ -613,9 +692,9 @@ def main():
         def run():
             if turn is None:
                 return m(batch['fc_feats'], batch['labels'], batch['masks'], {'gts': batch['gts']},
-                         batch['att_feats'], None)
+                         batch['att_feats'], am)
             return m(batch['fc_feats'], batch['labels'], batch['masks'], {'gts': batch['gts']},
-                     batch['att_feats'], None, is_alternating=True, alternating_turn=turn)
+                     batch['att_feats'], am, is_alternating=True, alternating_turn=turn)
         # scan the EOS bias for a run whose decodes have mixed lengths and (if any
         # greedy decode happens) at least one decode that stops early (L < 16)
         found = None
@@ -648,7 +727,7 @@ def main():
         m.zero_grad()
         loss.backward()
         T = opt.seq_length + 1
-        decs = split_decodes(ev, T, opt.batch_size, opt.input_encoding_size, opt.rnn_size, opt.vocab_size + 1)
+        decs = split_decodes(ev, T, opt.batch_size, opt.input_encoding_size, opt.rnn_size, opt.vocab_size + 1, am)
         nz = {}
         for i, d in enumerate(decs):
             nz.update(flat_noise(f'noise{i}', d))
@@ -663,31 +742,49 @@ def main():
                 pass
         print(name, 'loss', float(loss), 'ndecodes', len(decs), 'ngrads', len(grads))
         save(name, **sd, **opt_np(opt), **nz, **grads, **aux, loss=loss, n_decodes=np.int64(len(decs)),
-             turn=np.array(str(turn)), fc=batch['fc_feats'], att_raw=batch['att_feats'],
+             turn=np.array(str(turn)), fc=batch['fc_feats'], att_raw=batch['att_feats'], att_masks=am,
              labels=batch['labels'], masks=batch['masks'],
              gts_flat=np.concatenate(batch['gts'], 0), gts_count=np.array([len(x) for x in batch['gts']]))
 
+    for name, kw, turn, eos in cases:
+        if not only_masks:
+            joint_case(name, kw, turn, eos)
+
     # ------------------------------------------------------------------ O1 clamp + Adam
-    import misc.utils as rutils
-    torch.manual_seed(3)
-    p0 = torch.randn(37, 5)
-    p = torch.nn.Parameter(p0.clone())
-    optim = torch.optim.Adam([p], lr=5e-4, weight_decay=0)
-    traj = []
-    gs = []
-    for it in range(3):
-        gr = torch.randn(37, 5) * (0.3 if it != 1 else 0.01)
-        gs.append(gr.clone())
-        optim.zero_grad()
-        p.grad = gr.clone()
-        rutils.clip_gradient(optim, 0.1)
-        optim.step()
-        traj.append(p.detach().clone())
-    save('clamp_adam', p0=p0, grads=torch.stack(gs), traj=torch.stack(traj), lr=np.float64(5e-4),
-         grad_clip=np.float64(0.1))
-    gen_fc(torch, models, rec)
-    gen_beam(torch, models, rec)
-    gen_retrieval(torch)
+    def clamp_adam_case():
+        import misc.utils as rutils
+        torch.manual_seed(3)
+        p0 = torch.randn(37, 5)
+        p = torch.nn.Parameter(p0.clone())
+        optim = torch.optim.Adam([p], lr=5e-4, weight_decay=0)
+        traj = []
+        gs = []
+        for it in range(3):
+            gr = torch.randn(37, 5) * (0.3 if it != 1 else 0.01)
+            gs.append(gr.clone())
+            optim.zero_grad()
+            p.grad = gr.clone()
+            rutils.clip_gradient(optim, 0.1)
+            optim.step()
+            traj.append(p.detach().clone())
+        save('clamp_adam', p0=p0, grads=torch.stack(gs), traj=torch.stack(traj), lr=np.float64(5e-4),
+             grad_clip=np.float64(0.1))
+    JOINT_MASKED = [('masked_joint_gumbel', dict(retrieval_reward='gumbel', drop_prob_lm=0.5), 'speaker', 2.5)]
+    if not only_masks:
+        kernel_cases()
+        listener_cases()
+        cider_cases()
+        clamp_adam_case()
+        gen_fc(torch, models, rec)
+        gen_beam(torch, models, rec)
+        gen_retrieval(torch)
+    # ------------------------------------------------------------------ att_masks (ragged region counts)
+    for name, rr, kw, opts_, eos in SAMPLE_MASKED:
+        sample_case(name, rr, kw, opts_, eos, masked=True)
+    mle_case('masked_mle', {'drop_prob_lm': 0.5}, 0.0, masked=True)
+    for name, kw, turn, eos in JOINT_MASKED:
+        joint_case(name, kw, turn, eos, masked=True)
+    gen_beam(torch, models, rec, BEAM_CASES_MASKED)
 
 
 if __name__ == '__main__':
