@@ -147,6 +147,7 @@ def main():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=128)
+    ap.add_argument('--batches', type=int, default=4, help='distinct synthetic batches resident in HBM, served round robin')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N > 1: 'nccl' (= RCCL over xGMI, the "
@@ -174,12 +175,13 @@ def main():
     dev = torch.device('cuda', local_rank)
 
     from cooperativeimagecaptioning_amd import build as _build
-    if _build.needs_build():                   # a checkout without the (git-ignored) library: compile it in-tree first
-        if local_rank == 0:
-            with contextlib.redirect_stdout(sys.stderr):
-                _build.build(force=False)
-        if world > 1:
-            dist.barrier()
+    # a checkout without the (git-ignored) library: rank 0 compiles it in-tree (build() links to a temporary name and
+    # renames it into place); EVERY rank then passes the same barrier, whatever it saw on disk, before it loads it
+    if rank == 0 and _build.needs_build():
+        with contextlib.redirect_stdout(sys.stderr):
+            _build.build(force=False)
+    if world > 1:
+        dist.barrier()
     from cooperativeimagecaptioning_amd import models, optimizer as optim, synthetic, engine
     from cooperativeimagecaptioning_amd.misc import rewards
 
@@ -192,13 +194,20 @@ def main():
         optimizer_dict = optim.load_optimizer(model, opt)
     if world > 1:
         optim.overlap_gradient_exchange(model, optimizer_dict)   # listener all-reduce under the speaker backward
-    batch = synthetic.make_batch(opt, seed=1234 + rank, device=dev)    # per-rank shard of the global batch
+    # per-rank shard of the global batch; `--batches` distinct batches stay resident in HBM and are served round robin
+    # (their reference captions are packed for the CIDEr-D kernels on first use: host work outside the metric, like
+    # the loader's; the n-gram / document-frequency / score kernels run in every step)
+    batches = [synthetic.make_batch(opt, seed=1234 + rank + 1000 * i, device=dev) for i in range(max(1, args.batches))]
+    batch = batches[0]
     turn = opt.alternating_turn[0]
     optimizer = optimizer_dict[turn]
+    counter = [0]
 
     def step():
+        b = batches[counter[0] % len(batches)]
+        counter[0] += 1
         optim.zeroing_optimizer(opt, optimizer_dict, optimizer)
-        loss = model(batch['fc_feats'], batch['labels'], batch['masks'], batch, batch['att_feats'], batch['att_masks'],
+        loss = model(b['fc_feats'], b['labels'], b['masks'], b, b['att_feats'], b['att_masks'],
                      is_alternating=True, alternating_turn=turn)
         loss.backward()
         optim.update_optimizer(optimizer_dict, optimizer, opt)

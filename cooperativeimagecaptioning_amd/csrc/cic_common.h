@@ -168,3 +168,61 @@ __host__ __device__ __forceinline__ Philox4 philox4x32_10(uint64_t counter, uint
 __host__ __device__ __forceinline__ float u32_to_unit(uint32_t r) {
     return (float)(r >> 8) * (1.0f / 16777216.0f);   // [0,1), 24 bits like torch.rand
 }
+
+// ---- Gumbel noise and vocabulary row partials (cic.h: "Row partials of the vocabulary") ------------------------------
+__device__ __forceinline__ float gumbel_from_u(float u) {
+    // -log(-log(U + eps) + eps), eps = 1e-20, in f32 exactly as models/gumbel.py:6-11
+    return -logf(-logf(u + 1e-20f) + 1e-20f);
+}
+// uniform `lane` (0..3) of Philox call `q` of the stream cic_uniform_f32(seed, offset 0) writes
+__device__ __forceinline__ f32x4 philox_uniform4(uint64_t seed, uint64_t q) {
+    const Philox4 r = philox4x32_10(q, seed);
+    return f32x4{u32_to_unit(r.v[0]), u32_to_unit(r.v[1]), u32_to_unit(r.v[2]), u32_to_unit(r.v[3])};
+}
+
+// Running reduction of one row over a subset of its columns.
+struct RowPart {
+    float m1, s1;        // max x, sum exp(x - m1)
+    float kbest, xbest;  // best key, logit there
+    int kidx;            // its column (lowest among equal keys)
+    float s2;            // see cic.h
+    __device__ __forceinline__ void init() { m1 = -INFINITY; s1 = 0.f; kbest = -INFINITY; xbest = -INFINITY; kidx = 0x7fffffff; s2 = 0.f; }
+};
+// online softmax step: (m, s) absorbs one value; one exp per value
+__device__ __forceinline__ void osm_add(float& m, float& s, float x) {
+    if (x == -INFINITY) return;                  // exp(-inf - m) = 0; also keeps (-inf) - (-inf) out of the arithmetic
+    const float e = __expf(-fabsf(x - m));       // m = -inf: e = 0
+    s = x > m ? s * e + 1.0f : s + e;
+    m = fmaxf(m, x);
+}
+// merge of two (m, s) pairs
+__device__ __forceinline__ void osm_merge(float& m, float& s, float m2, float s2) {
+    const float M = fmaxf(m, m2);
+    const float a = m == -INFINITY ? 0.f : s * __expf(m - M);
+    const float b = m2 == -INFINITY ? 0.f : s2 * __expf(m2 - M);
+    s = a + b;
+    m = M;
+}
+// mode: CIC_SAMPLE_*; x: logit (already -inf at the constrained column); g: Gumbel noise or 0; col: its column
+__device__ __forceinline__ void rowpart_add(RowPart& p, int mode, float inv_t, float x, float g, int col) {
+    osm_add(p.m1, p.s1, x);
+    if (mode == CIC_SAMPLE_NONE) return;
+    const bool gum = mode == CIC_SAMPLE_GUMBEL_ST;
+    const float k = mode == CIC_SAMPLE_GREEDY ? x : (gum ? (x + g) * inv_t : x * inv_t + g);
+    if (gum) {
+        // s2 = sum exp(k - kbest): the same online form, with the running best key as the maximum
+        float kb = p.kbest, s = p.s2;
+        osm_add(kb, s, k);
+        p.s2 = s;
+    }
+    if (k > p.kbest || (k == p.kbest && col < p.kidx)) { p.kbest = k; p.xbest = x; p.kidx = col; }
+}
+__device__ __forceinline__ void rowpart_merge(RowPart& p, int mode, const RowPart& q) {
+    if (mode == CIC_SAMPLE_GUMBEL_ST) {
+        float kb = p.kbest, s = p.s2;
+        osm_merge(kb, s, q.kbest, q.s2);
+        p.s2 = s;
+    }
+    osm_merge(p.m1, p.s1, q.m1, q.s1);
+    if (q.kbest > p.kbest || (q.kbest == p.kbest && q.kidx < p.kidx)) { p.kbest = q.kbest; p.xbest = q.xbest; p.kidx = q.kidx; }
+}

@@ -11,7 +11,6 @@
 
 namespace {
 
-__device__ __forceinline__ float gumbel_from_u(float u) { return -logf(-logf(u + 1e-20f) + 1e-20f); }
 
 constexpr int SNW = 16;   // waves per row workgroup of sampler_bwd_kernel
 __device__ __forceinline__ float block_sum4(float v, float* sh) {
@@ -671,6 +670,7 @@ extern "C" int cic_speaker_decode_bwd(const cic_speaker_dims* dp, const cic_spea
     key = cic_hash_bytes(&bio->dslp, sizeof(void*), key);
     key = cic_hash_bytes(bio->grads, sizeof(*bio->grads), key);
     key = cic_hash_bytes(&bio->att_raw, sizeof(void*), key);
+    key = cic_hash_bytes(&bio->phase, sizeof(int), key);
     key = cic_hash_bytes(&ws_fwd, sizeof(ws_fwd), key);
     key = cic_hash_bytes(&ws_bwd, sizeof(ws_bwd), key);
     CicGraphScope gs(cic_s(s), key);
@@ -693,6 +693,9 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     CIC_REQUIRE(!(bio->d_onehot && io->mode == CIC_SAMPLE_GUMBEL_ST) || io->U);
     CIC_REQUIRE(!bio->d_onehot || io->seq);
     CIC_REQUIRE(!ps || (io->soft_raw && io->xpre && io->seq && (io->mode != CIC_SAMPLE_GUMBEL_PS || io->U)));
+    const int phase = bio->phase;
+    CIC_REQUIRE(phase == CIC_BWD_ALL || ((phase == CIC_BWD_LOGIT || phase == CIC_BWD_REST) && !ps));
+    const bool do_logit = phase != CIC_BWD_REST, do_rest = phase != CIC_BWD_LOGIT;
     hipStream_t st = cic_s(s);
     const int B = d.B, K = d.K, H = d.H, E = d.E, A = d.A, T = d.T, V1 = d.V + 1, D = d.D;
     const float scale = 1.0f / (1.0f - d.p_drop);
@@ -702,7 +705,7 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
 
     // 1. d logits for every step at once (rows are independent of the recurrence; not so for partial sampling,
     //    whose soft row is the next step's input: there steps 1-2 run inside the time loop)
-    if (!ps) {
+    if (!ps && do_logit) {
         dim3 grid(T * B), blk(1024);
         const int64_t* tgt = io->mode == CIC_SAMPLE_TEACHER ? io->pick : nullptr;
 #define GO(RV) hipLaunchKernelGGL((sampler_bwd_kernel<RV>), grid, blk, 0, st, w.logp_all, io->U, bio->d_onehot, w.it_all, \
@@ -713,17 +716,18 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         CIC_LAUNCH_CHECK();
     }
     // 2. logit layer, batched over time: d_out = dlogits W,  dW += dlogits^T out,  db += colsum
-    if (!ps) RUN(gemm_nn(g.dlogits, V1, p->logit_w, H, g.d_out_all, H, T * B, H, V1, false, st));
+    if (!ps && do_logit) RUN(gemm_nn(g.dlogits, V1, p->logit_w, H, g.d_out_all, H, T * B, H, V1, false, st));
 
     // 2b. the logit layer's weight gradient needs only d logits and the saved outputs: it can run on a side stream
     //     beside the latency-bound BPTT loop (cic_debug_side_stream(1); measured slower than one stream, so the
     //     fork is a no-op by default and the product simply runs here; not for partial sampling, whose d logits
     //     are made inside the loop)
     hipStream_t side = st;
-    if (!ps) {
-        RUN(cic_side_fork(st, &side));
+    if (!ps && do_logit) {
+        if (phase == CIC_BWD_ALL) RUN(cic_side_fork(st, &side));
         RUN(gemm_tn(g.dlogits, V1, w.out_all, H, gr->logit_w, H, V1, H, T * B, true, side, gr->logit_b));
     }
+    if (!do_rest) return 0;        // CIC_BWD_LOGIT: the logit layer's gradient is final; d out waits in ws_bwd
     // 3. BPTT over the cell + attention (only dh, dc are carried)
     float* dh_in = g.dh_a;
     float* dh_out = g.dh_b;

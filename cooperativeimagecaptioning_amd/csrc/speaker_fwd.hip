@@ -569,10 +569,6 @@ __device__ __forceinline__ ArgMax block_argmax(ArgMax a, float* shv, int* shi) {
     return r;
 }
 
-__device__ __forceinline__ float gumbel_from_u(float u) {
-    // -log(-log(U + eps) + eps), eps = 1e-20, in f32 exactly as models/gumbel.py:6-11
-    return -logf(-logf(u + 1e-20f) + 1e-20f);
-}
 
 template <int RV>   // RV float4 per thread: rows up to RV*4096 floats
 __global__ __launch_bounds__(SNW * 64) void logsoftmax_sample_kernel(cic_sampler_args a0, cic_sampler_args a1) {

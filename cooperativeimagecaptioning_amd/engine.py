@@ -142,7 +142,7 @@ def speaker_decode_io(dims, params, att_pre, mode, temp=1.0, att_masks=None, att
 
 
 def speaker_decode_bwd(dims, params, fwd, grads, att_raw, d_onehot=None, dslp=None, ws_bwd=None, grad_params=None,
-                       d_x0=None):
+                       d_x0=None, phase=0):
     """Accumulates parameter gradients of one decode into `grads` (dict of tensors keyed like
     the parameters).  fwd: the dict returned by speaker_decode_fwd."""
     nbytes = lib.cic_speaker_decode_bwd_ws_bytes(C.byref(dims))
@@ -152,6 +152,7 @@ def speaker_decode_bwd(dims, params, fwd, grads, att_raw, d_onehot=None, dslp=No
     gp = grad_params if grad_params is not None else speaker_params(grads)
     bio.d_onehot, bio.dslp, bio.att_raw, bio.d_x0 = _p(d_onehot), _p(dslp), _p(att_raw), _p(d_x0)
     bio.grads = C.pointer(gp)
+    bio.phase = int(phase)
     ws = fwd['ws']
     check(lib.cic_speaker_decode_bwd(C.byref(dims), C.byref(params), C.byref(fwd['io']), C.byref(bio),
                                      ws.data_ptr(), ws.numel(), ws_bwd.data_ptr(), ws_bwd.numel(), stream()),

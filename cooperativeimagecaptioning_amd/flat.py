@@ -12,16 +12,26 @@ import torch
 class FlatAgent:
     ALIGN = 64  # floats: every parameter starts on a 256-byte boundary (float4 / MFMA tile loads)
 
-    def __init__(self, module):
+    def __init__(self, module, tail=()):
+        """tail: parameter names laid out LAST in the flat buffers, in that order (state-dict order is untouched).
+        The speaker puts its logit layer there: its gradient is final before the BPTT loop of the backward pass starts,
+        so [tail_offset, numel) is a contiguous bucket whose all-reduce can travel under the rest of backward."""
         self.module = module
         self.params = [p for p in module.parameters()]
         self.names = [n for n, _ in module.named_parameters()]
-        self.offsets = []
+        tail = [n for n in tail if n in self.names]
+        order = [i for i, n in enumerate(self.names) if n not in tail] + [self.names.index(n) for n in tail]
+        self.offsets = [0] * len(self.params)
         off = 0
-        for p in self.params:
-            self.offsets.append(off)
-            off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.tail_offset = None
+        for i in order:
+            if tail and self.names[i] == tail[0]:
+                self.tail_offset = off
+            self.offsets[i] = off
+            off += (self.params[i].numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         self.numel = off
+        if self.tail_offset is None:
+            self.tail_offset = off
         self.flat = None
         self.grad = None
         self.exp_avg = None

@@ -61,6 +61,9 @@ class AlternatingJointModel(nn.Module):
         # data-parallel runs: optimizer.overlap_gradient_exchange() sets this to the listener optimizer's
         # begin_all_reduce, called from backward() as soon as the listener's gradient is final
         self.listener_grads_ready = None
+        # ... and this to the speaker optimizer's begin_all_reduce('logit'): called inside the last speaker backward
+        # engine of a step, right after the logit layer's gradient is final (before the BPTT loop)
+        self.speaker_logit_grads_ready = None
         # Load model (:131-177)
         if opt.is_alternating:
             if getattr(opt, 'continue_from_existing_models', False):
@@ -160,7 +163,10 @@ class AlternatingJointModel(nn.Module):
             self._loss['loss_cap'] = l_mle.detach()[0]
             terms.append((cw, l_mle))
             if spk_grad:
-                bwd_steps.append(lambda go: cg.decode_backward(mle, dslp=d_mle * go))
+                def bwd_mle(go, logit_ready=None):
+                    cg.decode_backward(mle, dslp=d_mle * go, logit_grads_ready=logit_ready)
+                bwd_mle.is_speaker = True
+                bwd_steps.append(bwd_mle)
         # VSE on ground-truth captions (vse_loss :209-224)
         if vw > 0:
             gt = vse.run(fc_feats, labels=seq, masks=masks, only_one_retrieval=oor, slot=1)
@@ -227,7 +233,10 @@ class AlternatingJointModel(nn.Module):
                 if sample.soft is not None and spk_grad:
                     # partial sampling: the CIDEr term below draws its own captions (:378-389), so this decode's
                     # backward (listener gradient only) is queued here
-                    bwd_steps.append(lambda go, ps=sample, d=d_onehot: cg.decode_backward(ps, d_onehot=d))
+                    def bwd_ps(go, logit_ready=None, ps=sample, d=d_onehot):
+                        cg.decode_backward(ps, d_onehot=d, logit_grads_ready=logit_ready)
+                    bwd_ps.is_speaker = True
+                    bwd_steps.append(bwd_ps)
             else:
                 raise ValueError(f'unknown retrieval_reward {rr!r}')
         if ciw:                                                        # CIDEr loss :490-503
@@ -252,9 +261,10 @@ class AlternatingJointModel(nn.Module):
         if sample is not None and sample.soft is not None:
             sample = None            # a partial-sampling decode without a CIDEr term: already queued above
         if sample is not None and spk_grad and (dslp is not None or getattr(sample, 'd_onehot', None) is not None):
-            def bwd_speaker(go, sample=sample, dslp=dslp):
+            def bwd_speaker(go, logit_ready=None, sample=sample, dslp=dslp):
                 cg.decode_backward(sample, d_onehot=getattr(sample, 'd_onehot', None),
-                                   dslp=(dslp * go) if dslp is not None else None)
+                                   dslp=(dslp * go) if dslp is not None else None, logit_grads_ready=logit_ready)
+            bwd_speaker.is_speaker = True
             bwd_steps.append(bwd_speaker)
 
         if not terms:
@@ -266,10 +276,15 @@ class AlternatingJointModel(nn.Module):
 
         # the listener's gradient is final after the last step that runs a listener backward engine
         last_lst = max([i for i, st in enumerate(bwd_steps) if getattr(st, 'is_listener', False)], default=-1)
+        # ... and the speaker's logit-layer gradient inside the LAST speaker backward, before its BPTT loop
+        last_spk = max([i for i, st in enumerate(bwd_steps) if getattr(st, 'is_speaker', False)], default=-1)
 
         def backward(go):
             for i, step in enumerate(bwd_steps):
-                step(go)
+                if i == last_spk and self.speaker_logit_grads_ready is not None:
+                    step(go, logit_ready=self.speaker_logit_grads_ready)
+                else:
+                    step(go)
                 if i == last_lst and lst_grad and self.listener_grads_ready is not None:
                     self.listener_grads_ready()
         return EngineLoss.apply(loss, anchor, backward)

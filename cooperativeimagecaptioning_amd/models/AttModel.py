@@ -100,7 +100,8 @@ class AttModel(nn.Module):
     # ---- engine plumbing -----------------------------------------------------------------
     def flat(self):
         if self._flat is None:
-            self._flat = FlatAgent(self)
+            # the logit layer last: a contiguous early bucket of the data-parallel gradient exchange (flat.py)
+            self._flat = FlatAgent(self, tail=('logit.weight', 'logit.bias'))
         self._flat.ensure()
         return self._flat
 
@@ -205,13 +206,25 @@ class AttModel(nn.Module):
         self._ws[ws_key] = fwd['ws']
         return dims, params, fwd, (mode, att_raw, grad, ws_key)
 
-    def decode_backward(self, res, d_onehot=None, dslp=None):
+    def decode_backward(self, res, d_onehot=None, dslp=None, logit_grads_ready=None):
+        """logit_grads_ready: called between the logit layer's backward and the BPTT loop (data-parallel runs start the
+        all-reduce of the logit bucket there; only when this decode is the last one writing the logit gradient)."""
         fl = self.flat()
         if dslp is not None:   # stable address for the HIP-graph key
             dslp = self._buf.stage(('dslp_in', res.dims.T), dslp.contiguous(), torch.float32)
         key = ('bwd', res.dims.B, res.dims.K, res.dims.T)
+        kw = dict(d_onehot=d_onehot, dslp=dslp)
+        if logit_grads_ready is not None and res.soft is None:
+            self._ws[key] = engine.speaker_decode_bwd(res.dims, res.params, res.fwd, fl.grad_tensors(), res.att_raw,
+                                                      ws_bwd=self._ws.get(key), phase=_lib.BWD_LOGIT, **kw)
+            logit_grads_ready()
+            engine.speaker_decode_bwd(res.dims, res.params, res.fwd, fl.grad_tensors(), res.att_raw,
+                                      ws_bwd=self._ws[key], phase=_lib.BWD_REST, **kw)
+            return
         self._ws[key] = engine.speaker_decode_bwd(res.dims, res.params, res.fwd, fl.grad_tensors(), res.att_raw,
-                                                  d_onehot=d_onehot, dslp=dslp, ws_bwd=self._ws.get(key))
+                                                  ws_bwd=self._ws.get(key), **kw)
+        if logit_grads_ready is not None:
+            logit_grads_ready()
 
     # ---- reference API ---------------------------------------------------------------------
     def forward(self, fc_feats, att_feats, att_masks, seq, masks):

@@ -14,49 +14,94 @@ from .misc import utils
 
 
 class FlatAdam:
-    """torch.optim.Adam look-alike for one agent (a module owning a FlatAgent via .flat())."""
+    """torch.optim.Adam look-alike for one agent (a module owning a FlatAgent via .flat()).
+
+    Data-parallel exchange: the flat gradient buffer is cut into contiguous BUCKETS, each summed over the ranks by one
+    all-reduce before the clamp.  A bucket whose gradient is final early can be started from inside backward()
+    (begin_all_reduce) and travels under the rest of the backward pass; step() starts whatever has not been started,
+    waits for all of them and folds 1/world into the Adam kernel.  The speaker has two buckets — 'logit' (the logit
+    layer, 19.4 MB, final before the BPTT loop; laid out last in the flat buffer) and 'rest' —, the listener one."""
 
     def __init__(self, module, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8):
+        if weight_decay != 0:
+            # torch.optim.Adam (the reference, optimizer.py:25-27) skips parameters whose grad is None and keeps a step
+            # count per parameter; the flat update decays and bias-corrects every parameter alike.  The two agree at the
+            # reference's default weight_decay = 0 (a zero gradient leaves a zero-moment parameter where it is).
+            raise NotImplementedError('weight_decay != 0 is not on the MI355X path (FlatAdam updates the whole flat '
+                                      'buffer; parameters without gradient would decay, unlike torch.optim.Adam)')
         self.module = module
         self.param_groups = [dict(params=list(module.parameters()), lr=lr, weight_decay=weight_decay,
                                   betas=betas, eps=eps)]
         self._grad_clip = None
-        self._pending = None          # async all-reduce started by begin_all_reduce()
+        self.grad_scale = 1.0         # extra factor on the gradient (1/n after accumulating n micro-batches)
+        self._pending = {}            # bucket name -> async all-reduce handle of THIS step
+        self._done = set()            # buckets already summed over the ranks in this step
 
     @property
     def flat(self):
         return self.module.flat()
 
+    def buckets(self):
+        """{name: (start, end)} over the flat gradient buffer, covering it exactly once."""
+        fl = self.flat
+        if fl.tail_offset < fl.numel:
+            return {'rest': (0, fl.tail_offset), 'logit': (fl.tail_offset, fl.numel)}
+        return {'all': (0, fl.numel)}
+
+    def _drain(self):
+        for h in self._pending.values():
+            h.wait()
+        self._pending.clear()
+
     def zero_grad(self, set_to_none=False):
+        # an exchange still in flight belongs to a step that never reached step() (a skipped or failed update, an
+        # extra backward): it must land before the buffer is cleared, and must not be mistaken for the next step's
+        self._drain()
+        self._done.clear()
         self.flat.zero_grad()
 
     def set_grad_clip(self, grad_clip):
         """utils.clip_gradient() on a FlatAdam defers the clamp into the fused step kernel."""
         self._grad_clip = float(grad_clip)
 
-    def begin_all_reduce(self):
-        """Start this agent's gradient all-reduce as soon as its gradient is final, so that it runs under the rest of
-        the backward pass (the listener's gradient is complete before the speaker's BPTT starts: its 46.7 MB travel
-        over xGMI while the speaker backward computes).  step() then only waits for it.  One backward per step."""
-        if self._pending is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            self._pending = dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, async_op=True)
+    @staticmethod
+    def _distributed():
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def begin_all_reduce(self, bucket=None):
+        """Start the all-reduce of one bucket (default: every bucket not started yet) as soon as its gradient is final,
+        so that it runs under the rest of the backward pass (the listener's gradient is complete before the speaker's
+        backward starts, the speaker's logit layer before its BPTT loop).  At most once per bucket and step: a second
+        backward before step() (gradient accumulation) must not start the exchange early."""
+        if not self._distributed():
+            return
+        for name, (a, b) in self.buckets().items():
+            if bucket is not None and name != bucket:
+                continue
+            if name in self._pending or name in self._done:
+                raise RuntimeError(f'gradient bucket "{name}" was already exchanged in this step: begin_all_reduce() '
+                                   f'runs once per bucket between zero_grad() and step()')
+            self._pending[name] = dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, async_op=True)
 
     def all_reduce_grads(self):
-        """One collective per agent over the flat f32 gradient (sum); the 1/world scale is folded
+        """Every bucket summed over the ranks (one collective per bucket); returns the 1/world scale that is folded
         into the Adam kernel."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            if self._pending is not None:
-                self._pending.wait()          # stream-ordered on the GPU backends: the host does not block
-                self._pending = None
-            else:
-                dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM)
-            return 1.0 / dist.get_world_size()
-        return 1.0
+        if not self._distributed():
+            return 1.0
+        for name in self.buckets():
+            if name not in self._pending and name not in self._done:
+                self.begin_all_reduce(name)
+        for name, h in list(self._pending.items()):
+            h.wait()                  # stream-ordered on the GPU backends: the host does not block
+            self._done.add(name)
+        self._pending.clear()
+        return 1.0 / dist.get_world_size()
 
     def step(self):
         fl = self.flat
         g = self.param_groups[0]
-        scale = self.all_reduce_grads()
+        scale = self.all_reduce_grads() * self.grad_scale
+        self._done.clear()
         if not any(p.requires_grad for p in fl.params):
             return
         fl.step += 1
@@ -184,14 +229,21 @@ def save_optimizer(opt, optimizer_dict):
 def overlap_gradient_exchange(model, optimizer_dict):
     """Data-parallel runs: let the joint model start the listener's all-reduce from inside backward() (right after
     the listener's backward engines, before the speaker's), instead of after the whole backward pass."""
-    lst = None
+    lst = spk = None
     for v in optimizer_dict.values():
         for o in (v.values() if isinstance(v, dict) else [v]):
             if isinstance(o, FlatAdam) and o.module is getattr(model, 'vse', None):
                 lst = o
+            if isinstance(o, FlatAdam) and o.module is getattr(model, 'caption_generator', None):
+                spk = o
     if lst is not None:
         lst._started_early = True
     model.listener_grads_ready = lst.begin_all_reduce if lst is not None else None
+    # the speaker's logit bucket (final before the BPTT loop of its backward engine) leaves from inside backward() too
+    if spk is not None and 'logit' in spk.buckets():
+        model.speaker_logit_grads_ready = lambda: spk.begin_all_reduce('logit')
+    else:
+        model.speaker_logit_grads_ready = None
 
 
 def zeroing_optimizer(opt, optimizer_dict, optimizer):
@@ -208,8 +260,10 @@ def update_optimizer(optimizer_dict, optimizer, opt):
     if opt.retrieval_reward != 'reinforce' and opt.is_alternating:
         agents = list(optimizer_dict['speaker'].values())
         for o in agents:                       # data-parallel: every exchange in flight before the first update waits
-            if isinstance(o, FlatAdam):
-                o.begin_all_reduce()
+            if isinstance(o, FlatAdam) and o._distributed():
+                for name in o.buckets():
+                    if name not in o._pending and name not in o._done:
+                        o.begin_all_reduce(name)
         # the agent whose exchange started first (the listener's, from inside backward) is updated first
         for o in sorted(agents, key=lambda o: 0 if getattr(o, '_started_early', False) else 1):
             utils.clip_gradient(o, opt.grad_clip)

@@ -308,7 +308,14 @@ typedef struct {
     const cic_speaker_params* grads; /* accumulated into (+=) */
     const float* att_raw;    /* [B,K,D] the raw region features (for the att_embed weight gradient); NULL in fc_mode */
     float* d_x0;             /* fc_mode: out [B,E] gradient w.r.t. io->x0 (the caller back-propagates img_embed) */
+    /* 0: the whole backward pass.  Data-parallel callers split it in two calls on the same arguments so that the
+     * logit layer's gradient (19.4 MB of the speaker's 57.8 MB, final before the time loop starts) can travel
+     * under the BPTT loop:  CIC_BWD_LOGIT = d logits, d out and grads->logit_w / logit_b only;  CIC_BWD_REST =
+     * everything after that (reads the d out the first call left in ws_bwd).  Partial-sampling decodes make their
+     * d logits inside the time loop: phase 0 only. */
+    int phase;
 } cic_decode_bwd_io;
+enum { CIC_BWD_ALL = 0, CIC_BWD_LOGIT = 1, CIC_BWD_REST = 2 };
 size_t cic_speaker_decode_bwd_ws_bytes(const cic_speaker_dims* d);
 /* autograd of cic_speaker_decode_fwd: straight-through sampler, logit layer, BPTT through
  * Att2in2Core/Attention, embeddings, ctx2att, att_embed.  io must be the struct of the

@@ -46,16 +46,40 @@ def _worker(rank, world, port, out_dir):
         g = torch.Generator().manual_seed(100 + rank)
         local = torch.randn(fl.numel, generator=g)
         fl.grad.copy_(local)
+        optim.overlap_gradient_exchange(model, od)
         if agent == 'listener':
             # the overlapped form bench.py / train.py use for the listener: started from inside backward(),
             # awaited by step()
-            optim.overlap_gradient_exchange(model, od)
-            assert model.listener_grads_ready is not None
+            assert model.listener_grads_ready is not None and list(o.buckets()) == ['all']
             model.listener_grads_ready()
-            assert o._pending is not None
+            assert set(o._pending) == {'all'}
+        else:
+            # the speaker's logit bucket (laid out last in the flat buffer) leaves from inside its backward engine,
+            # the rest of the buffer at update time: two collectives that cover the buffer exactly once
+            bk = o.buckets()
+            assert set(bk) == {'rest', 'logit'} and bk['rest'][0] == 0 and bk['rest'][1] == bk['logit'][0] \
+                and bk['logit'][1] == fl.numel
+            names = dict(zip(fl.names, fl.offsets))
+            assert names['logit.weight'] == bk['logit'][0] and names['logit.bias'] > names['logit.weight']
+            assert all(off < bk['logit'][0] for n, off in names.items() if not n.startswith('logit.'))
+            model.speaker_logit_grads_ready()
+            assert set(o._pending) == {'logit'}
+            with pytest.raises(RuntimeError):          # a second backward before step() must not re-send a bucket
+                model.speaker_logit_grads_ready()
         scale = o.all_reduce_grads()
-        assert scale == 1.0 / world and o._pending is None
+        assert scale == 1.0 / world and not o._pending and o._done == set(o.buckets())
         res[agent] = (local.numpy(), fl.grad.numpy().copy())
+        # an exchange that never reached step() (skipped update): zero_grad() lands it and forgets it, so the next
+        # step exchanges afresh instead of waiting on a stale handle and applying un-reduced gradients
+        o._done.clear()
+        o.begin_all_reduce()
+        assert o._pending
+        o.zero_grad()
+        assert not o._pending and not o._done and float(fl.grad.abs().max()) == 0.0
+        fl.grad.copy_(local)
+        assert o.all_reduce_grads() == 1.0 / world
+        np.testing.assert_array_equal(fl.grad.numpy(), res[agent][1])
+        o._done.clear()
         # p.grad views alias the reduced buffer
         p0 = fl.params[0]
         assert p0.grad.data_ptr() == fl.grad.data_ptr() + 4 * fl.offsets[0]
