@@ -11,8 +11,9 @@ decode, CIDEr-D reward, loss) -> backward -> [RCCL all-reduce of the two flat gr
 
 Prints ONE JSON line (rank 0).  `roofline` is the per-timestep attention kernel (HBM-bound):
 algorithmic bytes per launch (151,696 B x the 2B images one launch of the paired decodes covers) /
-average launch duration (HIP events on the step's stream, launches interleaved with a kernel that
-reproduces the cache pollution of the step) / 8 TB/s.  `cpu_baseline` is the CPU
+average duration of the in-step launches (HIP events of a caller-owned cic_timer on the step's stream,
+collected over a few steps after the timed region) / 8 TB/s; `roofline_mfma` is the logit product
+(2 x 2B x 512 x 9488 flop per launch / in-step duration / 157.3 TF/s).  `cpu_baseline` is the CPU
 oracle (oracle/, a restatement of the reference pinned by golden vectors) timed on this host
 for a bounded number of steps of the same workload.
 """
@@ -31,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 ATTN_BYTES_PER_IMAGE = 151696          # p_att + att rows + att_h + att_res + alpha, f32
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+MFMA_F32_PEAK_TF = 157.3               # MI355X_MICROARCH.md: f32-input MFMA, 157.3 TFLOP/s (spec)
 
 
 def cpu_baseline(opt, steps_budget_s=20.0):
@@ -126,18 +128,33 @@ def attention_launch_time(model, batch, stream, iters=200):
     return {'attn_fwd': dict(ms=us.value * iters / 1e3, n=iters, warm_us=us_warm.value, images=B)}
 
 
+def _profile_doc(names):
+    for n in names:
+        try:
+            with open(os.path.join(ROOT, 'profiles', n)) as f:
+                return json.load(f)
+        except OSError:
+            continue
+    return None
+
+
 def pmc_traffic(images):
     """HBM-side bytes per attention launch from the committed PMC summary (profiles/, separate FETCH_SIZE and
     WRITE_SIZE passes of this same command, tools/pmc_summary.py), for the launch geometry of the step."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-    try:
-        with open(path) as f:
-            doc = json.load(f)
-    except OSError:
-        return None
-    for k in doc.get('kernels', []):
+    doc = _profile_doc(['r02_pmc_traffic.json', 'r01_pmc_traffic.json'])
+    for k in (doc or {}).get('kernels', []):
         if k['kernel'].startswith('attn_fwd_cols_kernel') and k['grid_threads'] == images * 1024:
             return k['total_bytes']
+    return None
+
+
+def pmc_mfma_util():
+    """Counter-derived MFMA utilisation of the logit walker from the committed PMC pass (profiles/r02_pmc_mfma.json,
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE ... of this same command), or None before that pass exists."""
+    doc = _profile_doc(['r02_pmc_mfma.json'])
+    for k in (doc or {}).get('kernels', []):
+        if k['kernel'].startswith('gemm_ldsb2_walk_kernel'):
+            return k.get('mfma_util')
     return None
 
 
@@ -148,14 +165,12 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=128)
     ap.add_argument('--batches', type=int, default=4, help='distinct synthetic batches resident in HBM, served round robin')
+    ap.add_argument('--profile-steps', type=int, default=5, help='extra steps after the timed region with in-step kernel timing')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N > 1: 'nccl' (= RCCL over xGMI, the "
                     "default) or 'gloo' (rehearsal of the multi-process path on a box with fewer GPUs than ranks)")
     ap.add_argument('--same-device', action='store_true', help='rehearsal: every rank uses cuda:0 (gloo backend only)')
-    ap.add_argument('--graphs', action='store_true',
-                    help='run on a side stream and replay the sequence engines as HIP graphs (measured SLOWER on '
-                         'this stack: 9.5 vs 8.2 ms/step; the default is direct launches on the default stream)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -219,32 +234,33 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # --graphs: the whole step runs on one non-default HIP stream and the sequence engines are captured
-    # into HIP graphs on their first call and replayed afterwards (one launch per decode / listener pass)
-    stream = torch.cuda.Stream(device=dev) if args.graphs else torch.cuda.current_stream(dev)
-    engine.graph_enable(args.graphs)
-    if os.environ.get('CIC_GEMM_FLAGS') is not None:       # A/B measurement of the GEMM dispatch switches
-        engine.lib.cic_debug_gemm_tail_split(int(os.environ['CIC_GEMM_FLAGS'], 0))
-    if os.environ.get('CIC_A2C_CELL_FUSED') is not None:   # A/B measurement of the fused a2c + cell kernel
-        engine.lib.cic_debug_a2c_cell_fused(int(os.environ['CIC_A2C_CELL_FUSED']))
-    if os.environ.get('CIC_GATES_ATT_FUSED') is not None:  # A/B measurement of the gate + attention-query launch
-        engine.lib.cic_debug_gates_att_fused(int(os.environ['CIC_GATES_ATT_FUSED']))
-    if os.environ.get('CIC_GRU_FUSED') is not None:        # A/B measurement of the fused listener GRU step
-        engine.lib.cic_debug_gru_fused(int(os.environ['CIC_GRU_FUSED']))
-    if os.environ.get('CIC_SIDE_STREAM') is not None:      # A/B measurement of the side-stream products
-        engine.lib.cic_debug_side_stream(int(os.environ['CIC_SIDE_STREAM']))
-    with torch.cuda.stream(stream):
-        for _ in range(args.warmup):
+    stream = torch.cuda.current_stream(dev)       # the engines launch on torch's current stream
+    for _ in range(args.warmup):
+        loss = step()
+    barrier()
+    # K timed steps; an event at every step boundary (same stream, no host sync) gives the per-step times for the median
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(args.steps):
+        loss = step()
+        marks[i + 1].record()
+    barrier()
+    dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2]
+    # roofline legs, AFTER the timed region: the same step a few more times with a cic_timer attached to the decodes, which
+    # brackets every in-step launch of the attention / logit / sampler kernels with HIP events on this stream
+    prof = {}
+    if rank == 0 and args.profile_steps > 0:
+        timer = engine.KernelTimer()
+        model.caption_generator.timer = timer
+        for _ in range(args.profile_steps):
             loss = step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = step()
-        barrier()
-        dt = time.perf_counter() - t0
-        # roofline leg: the attention kernel on the step's own tensors, timed with HIP events on this stream
-        prof = attention_launch_time(model, batch, stream)
-    gstats = engine.graph_stats()
+        torch.cuda.synchronize()
+        prof = timer.collect()
+        model.caption_generator.timer = None
+        prof['attn_microbench'] = attention_launch_time(model, batch, stream)['attn_fwd']
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -254,28 +270,52 @@ def main():
 
     if rank == 0:
         B = args.batch
+        n_img = 2 * B                                      # images per attention launch: the paired decodes of the step
         attn = prof.get('attn_fwd', dict(ms=0.0, n=0))
         attn_us = attn['ms'] * 1e3 / max(attn['n'], 1)
-        n_img = attn.get('images', B)                      # images per attention launch (2B: paired decodes)
         achieved = (ATTN_BYTES_PER_IMAGE * n_img) / (attn_us * 1e-6) / 1e9 if attn_us > 0 else 0.0
+        micro = prof.get('attn_microbench', {})
+        micro_us = micro.get('ms', 0.0) * 1e3 / max(micro.get('n', 1), 1)
+        lg = prof.get('logit_gemm', dict(ms=0.0, n=0))
+        lg_us = lg['ms'] * 1e3 / max(lg['n'], 1)
+        lg_flop = 2.0 * n_img * opt.rnn_size * (opt.vocab_size + 1)      # one launch: [2B, 512] x [512, 9488]
+        lg_tf = lg_flop / (lg_us * 1e-6) / 1e12 if lg_us > 0 else 0.0
         out = {
             'metric': 'joint-step images/sec (B=128, seq16)', 'value': B * world * args.steps / dt, 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'median_ms_per_step': median_ms,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'AlternatingJointModel joint step, att2in2 speaker + VSE-fc listener, ST-Gumbel '
                                    'tau=1 + self-critical CIDEr-D, 36x2048 att_feats, vocab 9487, seq_len 16, '
                                    'dropout 0.5, clamp 0.1 + Adam both agents (BASELINE configs[2])',
                        'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': f'dp{world}',
-                       'final_loss': final_loss, 'hip_graphs': gstats},
-            'roofline': {'bound': 'hbm', 'kernel': 'attn_fwd_kernel (per-timestep top-down attention)',
+                       'resident_batches': len(batches),
+                       'excluded': 'host packing + upload of the reference captions (once per resident batch, the loader\'s job)',
+                       'final_loss': final_loss,
+                       'world': world, 'backend': (args.backend if world > 1 else None),
+                       'rccl': ('.'.join(str(v) for v in torch.cuda.nccl.version())
+                                if world > 1 and args.backend == 'nccl' else None),
+                       'gradient_buckets': {a: list(o.buckets()) for a, o in optimizer_dict.get('speaker', {}).items()}
+                       if isinstance(optimizer_dict.get('speaker'), dict) else None},
+            # HBM-bound kernel of the path: the per-timestep attention.  achieved = algorithmic bytes of one launch / the
+            # average duration of the in-step launches (HIP events of a cic_timer on the step's stream)
+            'roofline': {'bound': 'hbm', 'kernel': 'attn_fwd_cols_kernel<5,1> (per-timestep top-down attention, 2B images per launch)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': pmc_traffic(n_img), 'avg_launch_us': attn_us, 'launches_timed': attn['n'],
-                         'avg_launch_us_l2_warm': attn.get('warm_us'), 'images_per_launch': n_img,
-                         'algorithmic_bytes_per_launch': ATTN_BYTES_PER_IMAGE * n_img,
-                         'traffic_source': 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)'},
+                         'timing': 'HIP events around every in-step launch (cic_timer), %d steps after the timed region' % args.profile_steps,
+                         'avg_launch_us_microbench': micro_us, 'avg_launch_us_l2_warm': micro.get('warm_us'),
+                         'images_per_launch': n_img, 'algorithmic_bytes_per_launch': ATTN_BYTES_PER_IMAGE * n_img,
+                         'traffic_source': 'profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_summary.py)'},
+            # MFMA-bound kernel of the path: the hidden -> vocabulary logit product (with its fused log-softmax / sampler
+            # partials), exact-f32 MFMA
+            'roofline_mfma': {'bound': 'mfma', 'kernel': 'gemm_ldsb2_walk_kernel<32,2,true> (logit product [2B,512]x[512,9488] + row partials)',
+                              'achieved': lg_tf, 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s', 'frac': lg_tf / MFMA_F32_PEAK_TF,
+                              'flop_per_launch': lg_flop, 'avg_launch_us': lg_us, 'launches_timed': lg['n'],
+                              'mfma_util_pmc': pmc_mfma_util()},
         }
-        for k, v in prof.items():
-            if k != 'attn_fwd' and v['n']:
+        for k in ('sampler', 'attn_bwd'):
+            v = prof.get(k)
+            if v and v['n']:
                 out.setdefault('kernel_us', {})[k] = v['ms'] * 1e3 / v['n']
         if world == 1 and not args.no_cpu_baseline:
             torch.cuda.synchronize()

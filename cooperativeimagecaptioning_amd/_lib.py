@@ -10,7 +10,8 @@ import re
 import torch  # noqa: F401  (loads the HIP runtime the library links against first)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, 'libcic_hip.so')
+# CIC_HIP_LIB: tools/ point this at the development build (libcic_hip_dev.so, tools/_devlib.py); unset = the product
+_LIB_PATH = os.environ.get('CIC_HIP_LIB') or os.path.join(_HERE, 'libcic_hip.so')
 _HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'cic.h')
 
 
@@ -43,7 +44,8 @@ class GemmArgs(C.Structure):
                 ('bias', c_ptr), ('accumulate', C.c_int), ('relu', C.c_int),
                 ('sum_order_free', C.c_int), ('c_is_zero', C.c_int), ('colsum_A', c_ptr), ('colsum_A2', c_ptr), ('rows_blk', C.c_int), ('A_b', c_ptr), ('A2_b', c_ptr), ('C_b', c_ptr),
                 ('n_split', C.c_int), ('B2_tail', c_ptr), ('ldb2_tail', C.c_int), ('bias_tail', c_ptr),
-                ('C_tail', c_ptr), ('C_tail_b', c_ptr), ('ldc_tail', C.c_int)]
+                ('C_tail', c_ptr), ('C_tail_b', c_ptr), ('ldc_tail', C.c_int),
+                ('epi', c_ptr)]        # fused vocabulary epilogue (the decode engine's logit product); NULL here
 
 
 class SamplerArgs(C.Structure):
@@ -88,7 +90,8 @@ class DecodeIO(C.Structure):
                 ('ps_u', c_ptr), ('ps_prob', C.c_float), ('soft_raw', c_ptr), ('xpre', c_ptr), ('soft_out', c_ptr),
                 ('ss_u', c_ptr), ('ss_prob', C.c_float),
                 ('ss_pick', c_ptr), ('fc_mode', C.c_int), ('x0', c_ptr), ('first_token', c_ptr),
-                ('seq', c_ptr), ('slp', c_ptr), ('stv', c_ptr), ('L', c_ptr)]
+                ('seq', c_ptr), ('slp', c_ptr), ('stv', c_ptr), ('L', c_ptr),
+                ('u_philox', C.c_int), ('u_seed', C.c_uint64), ('u_offset', C.c_uint64), ('timer', c_ptr)]
 
 
 class DecodeBwdIO(C.Structure):

@@ -1,14 +1,6 @@
-"""Persistent device buffers keyed by role and shape.
-
-The sequence engines are replayed as HIP graphs keyed on every pointer they receive, so the host keeps
-inputs, outputs and noise at stable addresses: a batch is copied into a staging buffer, outputs are
-written into the same tensors every step."""
+"""Persistent device buffers keyed by role and shape: outputs, noise and workspaces of the engines are written into
+the same tensors every step (no allocator traffic inside the step)."""
 import torch
-
-# Set by engine.graph_enable(): HIP-graph replay needs every pointer at a stable address, so inputs are copied into
-# persistent staging buffers.  With direct launches (the default) an input that is already a contiguous device tensor
-# of the right dtype is used in place: no copy, no extra launch.
-STABLE_ADDRESSES = False
 
 
 class BufCache:
@@ -26,9 +18,10 @@ class BufCache:
         return t
 
     def stage(self, key, src, dtype=None):
-        """Copy `src` into the persistent buffer of its role (same shape) and return that buffer."""
+        """`src` as a contiguous tensor of `dtype`: used in place when it already is one (no copy, no launch), else
+        converted into the persistent buffer of its role."""
         dtype = dtype or src.dtype
-        if not STABLE_ADDRESSES and src.dtype == dtype and src.is_contiguous():
+        if src.dtype == dtype and src.is_contiguous():
             return src
         t = self.get(key, src.shape, dtype, src.device)
         t.copy_(src)

@@ -30,32 +30,30 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// in-situ timing hooks (core.hip); no-ops unless cic_prof_enable(1)
-void* cic_prof_begin(int id, hipStream_t st);
-void cic_prof_end(void* h, hipStream_t st);
-#define CIC_PROF(id, st, stmt)                   \
-    do {                                         \
-        void* ph_ = cic_prof_begin((id), (st));  \
-        stmt;                                    \
-        cic_prof_end(ph_, (st));                 \
+// in-situ timing (core.hip): launches bracketed by HIP events of a caller-owned cic_timer; no-ops for a NULL timer
+void* cic_timer_begin(cic_timer* t, int id, hipStream_t st);
+void cic_timer_end(void* h, hipStream_t st);
+#define CIC_TIMED(timer, id, st, stmt)                      \
+    do {                                                    \
+        void* ph_ = cic_timer_begin((timer), (id), (st));   \
+        stmt;                                               \
+        cic_timer_end(ph_, (st));                           \
     } while (0)
 
-// ---- HIP graph capture/replay of an engine call (core.hip) ---------------------------------------
+// Dispatch switches and in-kernel stamp buffers exist only in the development build of the library
+// (-DCIC_DEVTOOLS -> libcic_hip_dev.so, setters declared in include/cic_dev.h; tools/ use it for A/B timing).  In the
+// product build (libcic_hip.so) they are compile-time constants: the library holds no mutable global state.
+#ifdef CIC_DEVTOOLS
+#define CIC_SWITCH(name, value) int name = value
+#define CIC_STAMP_BUF(sym) sym
+#else
+#define CIC_SWITCH(name, value) static constexpr int name = value
+#define CIC_STAMP_BUF(sym) nullptr
+#endif
+
 uint64_t cic_hash_bytes(const void* p, size_t n, uint64_t h);
-struct CicGraphScope {
-    hipStream_t st;
-    uint64_t key;
-    bool capturing = false;
-    bool replayed = false;
-    CicGraphScope(hipStream_t s, uint64_t k);   // replays a cached graph if there is one, else begins capture
-    int finish(int rc);                         // ends capture, instantiates, caches and launches
-};
 
 static inline hipStream_t cic_s(cic_stream_t s) { return (hipStream_t)s; }
-
-// side stream of an engine call (core.hip): *side = main when side streams are off or `main` is being captured
-int cic_side_fork(hipStream_t main, hipStream_t* side);
-int cic_side_join(hipStream_t main, hipStream_t side);
 
 // A pointer per decode of a PAIR of decodes that advance in lock step through the same launches
 // (rows [0,B) belong to decode a, rows [B,2B) to decode b; b is unused for a single decode).
@@ -147,22 +145,31 @@ __device__ __forceinline__ float fast_sigmoid(float x) {
 struct Philox4 {
     uint32_t v[4];
 };
-__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint64_t counter, uint64_t seed) {
-    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-    uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = 0u, c3 = 0u;
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
-        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        uint32_t n1 = (uint32_t)p1;
-        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-        uint32_t n3 = (uint32_t)p0;
+// one Philox4x32 call as a state machine, so that its ten rounds can be spread over the slots of a software pipeline
+struct PhiloxState {
+    uint32_t c0, c1, c2, c3, k0, k1;
+    __host__ __device__ __forceinline__ void init(uint64_t counter, uint64_t seed) {
+        c0 = (uint32_t)counter; c1 = (uint32_t)(counter >> 32); c2 = 0u; c3 = 0u;
+        k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32);
+    }
+    __host__ __device__ __forceinline__ void round() {
+        const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+        const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += W0; k1 += W1;
     }
+};
+__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint64_t counter, uint64_t seed) {
+    PhiloxState s;
+    s.init(counter, seed);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) s.round();
     Philox4 o;
-    o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+    o.v[0] = s.c0; o.v[1] = s.c1; o.v[2] = s.c2; o.v[3] = s.c3;
     return o;
 }
 __host__ __device__ __forceinline__ float u32_to_unit(uint32_t r) {
@@ -171,8 +178,10 @@ __host__ __device__ __forceinline__ float u32_to_unit(uint32_t r) {
 
 // ---- Gumbel noise and vocabulary row partials (cic.h: "Row partials of the vocabulary") ------------------------------
 __device__ __forceinline__ float gumbel_from_u(float u) {
-    // -log(-log(U + eps) + eps), eps = 1e-20, in f32 exactly as models/gumbel.py:6-11
-    return -logf(-logf(u + 1e-20f) + 1e-20f);
+    // -log(-log(U + eps) + eps), eps = 1e-20, in f32 as models/gumbel.py:6-11.  __logf = v_log_f32 * ln 2 (1 ulp, two
+    // instructions; the arguments are never denormal: u + eps >= 1e-20, -log(.) + eps in [1e-20, 46.1]): the library
+    // logf's range handling would cost ~10x the issue slots in the logit walker's epilogue, for the same last-bit noise
+    return -__logf(-__logf(u + 1e-20f) + 1e-20f);
 }
 // uniform `lane` (0..3) of Philox call `q` of the stream cic_uniform_f32(seed, offset 0) writes
 __device__ __forceinline__ f32x4 philox_uniform4(uint64_t seed, uint64_t q) {
@@ -180,49 +189,78 @@ __device__ __forceinline__ f32x4 philox_uniform4(uint64_t seed, uint64_t q) {
     return f32x4{u32_to_unit(r.v[0]), u32_to_unit(r.v[1]), u32_to_unit(r.v[2]), u32_to_unit(r.v[3])};
 }
 
-// Running reduction of one row over a subset of its columns.
+// Running reduction of one row over a subset of its columns.  "Empty" is -FLT_MAX, not -inf: every update and merge
+// below is then straight-line arithmetic (exp(-huge) = 0; no (-inf) - (-inf)), and a constrained column (x = -inf)
+// simply adds exp(-inf) = 0.
+constexpr float RP_EMPTY = -3.402823466e38f;
 struct RowPart {
     float m1, s1;        // max x, sum exp(x - m1)
     float kbest, xbest;  // best key, logit there
     int kidx;            // its column (lowest among equal keys)
     float s2;            // see cic.h
-    __device__ __forceinline__ void init() { m1 = -INFINITY; s1 = 0.f; kbest = -INFINITY; xbest = -INFINITY; kidx = 0x7fffffff; s2 = 0.f; }
+    __device__ __forceinline__ void init() { m1 = RP_EMPTY; s1 = 0.f; kbest = RP_EMPTY; xbest = RP_EMPTY; kidx = 0x7fffffff; s2 = 0.f; }
 };
-// online softmax step: (m, s) absorbs one value; one exp per value
+// online softmax step: (m, s) absorbs one value; one exp per value, no branch
 __device__ __forceinline__ void osm_add(float& m, float& s, float x) {
-    if (x == -INFINITY) return;                  // exp(-inf - m) = 0; also keeps (-inf) - (-inf) out of the arithmetic
-    const float e = __expf(-fabsf(x - m));       // m = -inf: e = 0
+    const float e = __expf(-fabsf(x - m));
     s = x > m ? s * e + 1.0f : s + e;
     m = fmaxf(m, x);
+}
+// the same step for a sum whose reference maximum `m` is maintained by the caller (read only here)
+__device__ __forceinline__ void osm_add_ref(float m, float& s, float x) {
+    const float e = __expf(-fabsf(x - m));
+    s = x > m ? s * e + 1.0f : s + e;
 }
 // merge of two (m, s) pairs
 __device__ __forceinline__ void osm_merge(float& m, float& s, float m2, float s2) {
     const float M = fmaxf(m, m2);
-    const float a = m == -INFINITY ? 0.f : s * __expf(m - M);
-    const float b = m2 == -INFINITY ? 0.f : s2 * __expf(m2 - M);
-    s = a + b;
+    s = s * __expf(m - M) + s2 * __expf(m2 - M);
     m = M;
 }
-// mode: CIC_SAMPLE_*; x: logit (already -inf at the constrained column); g: Gumbel noise or 0; col: its column
-__device__ __forceinline__ void rowpart_add(RowPart& p, int mode, float inv_t, float x, float g, int col) {
+// MODE: CIC_SAMPLE_* (compile time); x: logit (already -inf at the constrained column); g: Gumbel noise or 0; col: its
+// column.  Within one caller the columns arrive in increasing order, so a strictly larger key is the only way to
+// replace the best one (ties keep the lowest column).
+template <int MODE>
+__device__ __forceinline__ void rowpart_add_m(RowPart& p, float inv_t, float x, float g, int col) {
+    const float m_old = p.m1;
     osm_add(p.m1, p.s1, x);
-    if (mode == CIC_SAMPLE_NONE) return;
-    const bool gum = mode == CIC_SAMPLE_GUMBEL_ST;
-    const float k = mode == CIC_SAMPLE_GREEDY ? x : (gum ? (x + g) * inv_t : x * inv_t + g);
-    if (gum) {
-        // s2 = sum exp(k - kbest): the same online form, with the running best key as the maximum
-        float kb = p.kbest, s = p.s2;
-        osm_add(kb, s, k);
-        p.s2 = s;
+    if (MODE == CIC_SAMPLE_NONE) return;
+    if (MODE == CIC_SAMPLE_MULTINOMIAL_ST) {
+        // s2 = sum exp((x - m1) * inv_t), re-based whenever the running maximum moves
+        const float r1 = p.m1 * inv_t;
+        p.s2 = p.s2 * __expf(m_old * inv_t - r1) + __expf(x * inv_t - r1);
     }
-    if (k > p.kbest || (k == p.kbest && col < p.kidx)) { p.kbest = k; p.xbest = x; p.kidx = col; }
+    const bool gum = MODE == CIC_SAMPLE_GUMBEL_ST;
+    const float k = MODE == CIC_SAMPLE_GREEDY ? x : (gum ? (x + g) * inv_t : x * inv_t + g);
+    if (gum) osm_add_ref(p.kbest, p.s2, k);      // s2 = sum exp(k - kbest): the online form with the best key as the maximum
+    const bool better = k > p.kbest;
+    p.kbest = better ? k : p.kbest;
+    p.xbest = better ? x : p.xbest;
+    p.kidx = better ? col : p.kidx;
 }
-__device__ __forceinline__ void rowpart_merge(RowPart& p, int mode, const RowPart& q) {
+// the runtime-mode form (a wave-uniform switch over the straight-line bodies)
+__device__ __forceinline__ void rowpart_add(RowPart& p, int mode, float inv_t, float x, float g, int col) {
+    switch (mode) {
+        case CIC_SAMPLE_NONE: rowpart_add_m<CIC_SAMPLE_NONE>(p, inv_t, x, g, col); break;
+        case CIC_SAMPLE_GREEDY: rowpart_add_m<CIC_SAMPLE_GREEDY>(p, inv_t, x, g, col); break;
+        case CIC_SAMPLE_GUMBEL_ST: rowpart_add_m<CIC_SAMPLE_GUMBEL_ST>(p, inv_t, x, g, col); break;
+        case CIC_SAMPLE_MULTINOMIAL_ST: rowpart_add_m<CIC_SAMPLE_MULTINOMIAL_ST>(p, inv_t, x, g, col); break;
+        default: rowpart_add_m<CIC_SAMPLE_MULTINOMIAL>(p, inv_t, x, g, col); break;   // MULTINOMIAL, TEACHER
+    }
+}
+__device__ __forceinline__ void rowpart_merge(RowPart& p, int mode, float inv_t, const RowPart& q) {
+    if (mode == CIC_SAMPLE_MULTINOMIAL_ST) {
+        const float r = fmaxf(p.m1, q.m1) * inv_t;
+        p.s2 = p.s2 * __expf(p.m1 * inv_t - r) + q.s2 * __expf(q.m1 * inv_t - r);
+    }
     if (mode == CIC_SAMPLE_GUMBEL_ST) {
         float kb = p.kbest, s = p.s2;
         osm_merge(kb, s, q.kbest, q.s2);
         p.s2 = s;
     }
     osm_merge(p.m1, p.s1, q.m1, q.s1);
-    if (q.kbest > p.kbest || (q.kbest == p.kbest && q.kidx < p.kidx)) { p.kbest = q.kbest; p.xbest = q.xbest; p.kidx = q.kidx; }
+    const bool better = q.kbest > p.kbest || (q.kbest == p.kbest && q.kidx < p.kidx);
+    p.kbest = better ? q.kbest : p.kbest;
+    p.xbest = better ? q.xbest : p.xbest;
+    p.kidx = better ? q.kidx : p.kidx;
 }

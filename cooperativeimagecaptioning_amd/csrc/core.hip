@@ -15,44 +15,51 @@ void cic_set_error(const char* fmt, ...) {
 extern "C" int cic_version(void) { return 100; }
 extern "C" const char* cic_last_error(void) { return g_err; }
 
-// ---- in-situ kernel timing -------------------------------------------------------------------
+// ---- in-situ kernel timing: a caller-owned object (no library state) ----------------------------------------
+// The engines bracket the launches of a few kernels with a pair of HIP events on their own stream when the caller
+// hands them a cic_timer (cic_decode_io.timer); the events live in that object.
 #include <vector>
-namespace {
-struct ProfPair { hipEvent_t a, b; int id; };
-bool g_prof_on = false;
-std::vector<ProfPair> g_prof_pairs;      // recorded since the last reset
-std::vector<hipEvent_t> g_prof_pool;     // recycled events
-hipEvent_t prof_event() {
-    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
-    hipEvent_t e = nullptr;
-    if (hipEventCreate(&e) != hipSuccess) return nullptr;
-    return e;
-}
-}  // namespace
+struct cic_timer {
+    struct Pair { hipEvent_t a, b; int id; };
+    std::vector<Pair> pairs;          // recorded since the last reset
+    std::vector<hipEvent_t> pool;     // recycled events
+    hipEvent_t event() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+};
 
-bool cic_prof_on() { return g_prof_on; }
-void* cic_prof_begin(int id, hipStream_t st) {
-    if (!g_prof_on) return nullptr;
-    ProfPair p{prof_event(), prof_event(), id};
+void* cic_timer_begin(cic_timer* t, int id, hipStream_t st) {
+    if (!t) return nullptr;
+    cic_timer::Pair p{t->event(), t->event(), id};
     if (!p.a || !p.b) return nullptr;
     (void)hipEventRecord(p.a, st);
-    g_prof_pairs.push_back(p);
+    t->pairs.push_back(p);
     return p.b;
 }
-void cic_prof_end(void* h, hipStream_t st) {
+void cic_timer_end(void* h, hipStream_t st) {
     if (h) (void)hipEventRecord(static_cast<hipEvent_t>(h), st);
 }
-extern "C" int cic_prof_enable(int on) { g_prof_on = on != 0; return 0; }
-extern "C" int cic_prof_reset(void) {
-    for (auto& p : g_prof_pairs) { g_prof_pool.push_back(p.a); g_prof_pool.push_back(p.b); }
-    g_prof_pairs.clear();
+extern "C" cic_timer* cic_timer_create(void) { return new cic_timer(); }
+extern "C" void cic_timer_destroy(cic_timer* t) {
+    if (!t) return;
+    for (auto& p : t->pairs) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : t->pool) (void)hipEventDestroy(e);
+    delete t;
+}
+extern "C" int cic_timer_reset(cic_timer* t) {
+    CIC_REQUIRE(t);
+    for (auto& p : t->pairs) { t->pool.push_back(p.a); t->pool.push_back(p.b); }
+    t->pairs.clear();
     return 0;
 }
-extern "C" int cic_prof_collect(int id, double* total_ms, int* launches) {
-    CIC_REQUIRE(total_ms && launches && id >= 0 && id < CIC_PROF_COUNT);
+extern "C" int cic_timer_collect(cic_timer* t, int id, double* total_ms, int* launches) {
+    CIC_REQUIRE(t && total_ms && launches && id >= 0 && id < CIC_TIMED_COUNT);
     double tot = 0.0;
     int n = 0;
-    for (auto& p : g_prof_pairs) {
+    for (auto& p : t->pairs) {
         if (p.id != id) continue;
         CIC_HIP(hipEventSynchronize(p.b));
         float ms = 0.f;
@@ -62,116 +69,6 @@ extern "C" int cic_prof_collect(int id, double* total_ms, int* launches) {
     }
     *total_ms = tot;
     *launches = n;
-    return 0;
-}
-
-// ---- HIP graph cache ---------------------------------------------------------------------------------
-#include <unordered_map>
-namespace {
-bool g_graph_on = false;
-std::unordered_map<uint64_t, hipGraphExec_t> g_graphs;
-int64_t g_graph_stats[3] = {0, 0, 0};   // captures, replays, fallbacks
-}  // namespace
-
-uint64_t cic_hash_bytes(const void* p, size_t n, uint64_t h) {
-    const unsigned char* b = static_cast<const unsigned char*>(p);
-    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }   // FNV-1a
-    return h;
-}
-
-CicGraphScope::CicGraphScope(hipStream_t s, uint64_t k) : st(s), key(k) {
-    if (!g_graph_on || g_prof_on) return;
-    auto it = g_graphs.find(key);
-    if (it != g_graphs.end()) {
-        if (hipGraphLaunch(it->second, st) == hipSuccess) {
-            replayed = true;
-            ++g_graph_stats[1];
-            return;
-        }
-        (void)hipGetLastError();
-    }
-    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-        capturing = true;
-    } else {
-        (void)hipGetLastError();   // e.g. the legacy default stream: run the launches directly
-        ++g_graph_stats[2];
-    }
-}
-
-int CicGraphScope::finish(int rc) {
-    if (!capturing) return rc;
-    hipGraph_t graph = nullptr;
-    hipError_t e = hipStreamEndCapture(st, &graph);
-    capturing = false;
-    if (e != hipSuccess || graph == nullptr) {
-        (void)hipGetLastError();
-        cic_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e));
-        return rc ? rc : 2;
-    }
-    if (rc != 0) {   // an engine error during capture: nothing was launched
-        (void)hipGraphDestroy(graph);
-        return rc;
-    }
-    hipGraphExec_t exec = nullptr;
-    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (e != hipSuccess) {
-        cic_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
-        return 2;
-    }
-    if (g_graphs.size() >= 64) {   // bounded cache: drop everything rather than track recency
-        for (auto& kv : g_graphs) (void)hipGraphExecDestroy(kv.second);
-        g_graphs.clear();
-    }
-    g_graphs[key] = exec;
-    ++g_graph_stats[0];
-    CIC_HIP(hipGraphLaunch(exec, st));
-    return 0;
-}
-
-// ---- side stream: fork / join inside one engine call ----------------------------------------------------
-// A latency-bound launch chain (the BPTT loop: ~35 us per step on a fraction of the CUs) leaves most of the chip
-// idle; a product that does not depend on the chain (the logit layer's weight gradient) runs beside it on a second,
-// non-blocking HIP stream.  fork: side waits for everything `main` has queued so far; join: main waits for the side
-// work.  Both are event waits on the device - the host never blocks.
-static hipStream_t g_side = nullptr;
-static hipEvent_t g_side_fork = nullptr, g_side_join = nullptr;
-static int g_side_on = 0;   // measured: ON 6.08 ms/step vs OFF 5.81 (the GEMM's workgroups hold the CUs the chain's short
-                            // kernels need; their dispatch then waits for whole 25-100 us tiles): off by default
-extern "C" int cic_debug_side_stream(int on) { g_side_on = on; return 0; }
-
-int cic_side_fork(hipStream_t main, hipStream_t* side) {
-    *side = main;
-    if (!g_side_on) return 0;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(main, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return 0;   // graphs: one stream
-    if (!g_side) {
-        CIC_HIP(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
-        CIC_HIP(hipEventCreateWithFlags(&g_side_fork, hipEventDisableTiming));
-        CIC_HIP(hipEventCreateWithFlags(&g_side_join, hipEventDisableTiming));
-    }
-    CIC_HIP(hipEventRecord(g_side_fork, main));
-    CIC_HIP(hipStreamWaitEvent(g_side, g_side_fork, 0));
-    *side = g_side;
-    return 0;
-}
-
-int cic_side_join(hipStream_t main, hipStream_t side) {
-    if (side == main) return 0;
-    CIC_HIP(hipEventRecord(g_side_join, side));
-    CIC_HIP(hipStreamWaitEvent(main, g_side_join, 0));
-    return 0;
-}
-
-extern "C" int cic_graph_enable(int on) { g_graph_on = on != 0; return 0; }
-extern "C" int cic_graph_clear(void) {
-    for (auto& kv : g_graphs) (void)hipGraphExecDestroy(kv.second);
-    g_graphs.clear();
-    return 0;
-}
-extern "C" int cic_graph_stats(int64_t* out3) {
-    CIC_REQUIRE(out3);
-    for (int i = 0; i < 3; ++i) out3[i] = g_graph_stats[i];
     return 0;
 }
 

@@ -1,5 +1,8 @@
-// Diagnostics (not on the product path): shader-clock probe used by tools/ to interpret timings.
+// Diagnostics of the development build (-DCIC_DEVTOOLS, libcic_hip_dev.so; declared in include/cic_dev.h): shader-clock
+// probe and an empty launch, used by tools/ to interpret timings.  The product library does not contain them.
 #include "cic_common.h"
+#ifdef CIC_DEVTOOLS
+#include "cic_dev.h"
 
 namespace {
 __global__ void clock_probe_kernel(float* out, int spin) {
@@ -30,3 +33,4 @@ extern "C" int cic_debug_empty(int grid, int block, cic_stream_t s) {
     CIC_LAUNCH_CHECK();
     return 0;
 }
+#endif  // CIC_DEVTOOLS

@@ -29,6 +29,7 @@ struct SpkWs {
     float* bias_ih;                           // [5H] = i2h.bias + h2h.bias
     float *pre_img, *zeros;                   // [B,5H], [B,H]: the image step of an FCModel decode; a zero state
     int32_t *it_all, *unfinished, *any_unf;   // [T+1,B], [B], [T+1]
+    float *part, *lse_all;                    // row partials of one step's logits [6][B][nparts]; [T,B] log-sum-exp rows
     size_t bytes;
 };
 SpkWs spk_carve(const cic_speaker_dims& d, void* base);
@@ -49,6 +50,9 @@ int cic_a2c_cell_fused(Dual<const float> att_res, const float* Wa, const float* 
                        Dual<const uint8_t> keep, float p_drop, Dual<float> h_new, Dual<float> c_new, Dual<float> out, int B,
                        int nb, int H, hipStream_t st);
 int cic_logsoftmax_sample2(const cic_sampler_args* a, const cic_sampler_args* b, hipStream_t st);
+// the sampler on the row partials of the step's logits (no pass over the vocabulary); writes the rows' lse
+int cic_sample_finish2(const cic_sampler_args* a, const float* part_a, int part_rows_a, float* lse_a,
+                       const cic_sampler_args* b, const float* part_b, int part_rows_b, float* lse_b, int np, hipStream_t st);
 // dropout of the embedded regions with ragged region counts: rows beyond an image's own regions become 0
 int cic_att_keep_rows(const float* x, const uint8_t* keep, float p_drop, const float* masks, float* y, int B, int K, int H,
                       hipStream_t st);

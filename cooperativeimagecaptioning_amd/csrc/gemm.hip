@@ -14,21 +14,23 @@
 // Both operands use the same k permutation inside each group of 8 (MFMA step j multiplies
 // k = 8g+j (lanes 0-31) and k = 8g+4+j (lanes 32-63)), so the sum order is fixed and
 // reproducible run to run.
+#include <type_traits>
 #include "cic_common.h"
 
 namespace {
 
 bool aligned16(const void* p);
 
-// measurement / determinism switches, set through cic_debug_gemm_tail_split(flags)
-int g_tail_split = 1;   // bit 0: K-sliced tail tiles and K split over workgroups (float atomics) on / off
-int g_force_tile = 0;   // bits 8..15: 1 = 128x128, 2 = 64x64 tiles forced
-int g_walk = 1;         // bit 16 set: strip walkers off
-int g_walk16 = 1;       // bit 21 set: 16-wide strip walkers off
-int g_ldsb = 1;         // bit 22 set: LDS-staged column walker (K = 512 logit product) off
-int g_ldsb2 = 2;        // K parts per row tile of the logit walker: 2 or 4 (bits 25..26 of the debug word: 1 -> 4-wave form, 2 -> 4 parts)
-int g_rega2 = 1;        // bit 24 set: two-strip dX kernel (gemm_rega2_kernel) off
-int g_split_rows = 1;   // bit 23 set: 129..256-row products are not handed to the register-streaming kernels as two row blocks
+// dispatch switches: constants in the product build; the development build sets them through cic_debug_gemm_tail_split(flags)
+CIC_SWITCH(g_tail_split, 1);   // bit 0: K-sliced tail tiles and K split over workgroups (float atomics) on / off
+CIC_SWITCH(g_force_tile, 0);   // bits 8..15: 1 = 128x128, 2 = 64x64 tiles forced
+CIC_SWITCH(g_walk, 1);         // bit 16 set: strip walkers off
+CIC_SWITCH(g_walk16, 1);       // bit 21 set: 16-wide strip walkers off
+CIC_SWITCH(g_ldsb, 1);         // bit 22 set: LDS-staged column walker (K = 512 logit product) off
+CIC_SWITCH(g_ldsb2, 2);        // K parts per row tile of the logit walker: 2 or 4 (bits 25..26 of the debug word: 1 -> 4-wave form, 2 -> 4 parts)
+CIC_SWITCH(g_rega2, 1);        // bit 24 set: two-strip dX kernel (gemm_rega2_kernel) off
+CIC_SWITCH(g_logit_epi, 1);    // bit 27 set: no fused vocabulary epilogue in the logit walker (cic_gemm_logit_parts() = 0)
+CIC_SWITCH(g_split_rows, 1);   // bit 23 set: 129..256-row products are not handed to the register-streaming kernels as two row blocks
 
 constexpr int BK = 32;
 constexpr int KCS = BK + 4;  // row stride of a K-contiguous LDS image (floats)
@@ -430,12 +432,14 @@ int launch_skinny(const cic_gemm_args& g, bool vec, hipStream_t st) {
 //   i.e. one float4 per group when the operand is K-contiguous (weights W[N,K], activations x[M,K]);
 //   a K-strided B (dX = dY W) is read as 4 row-coalesced dwords per group.
 // ---------------------------------------------------------------------------------------------
+#ifdef CIC_DEVTOOLS
 __device__ unsigned long long* g_stamp_buf = nullptr;
+#endif
 __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // A operand of k's beyond K   // diagnostics: per-workgroup phase stamps (cic_debug_set_stamps)
 
 template <int KS, bool KCB>   // waves = KS (one 32-row strip per workgroup)
 __global__ __launch_bounds__(KS * 64) void gemm_rega_kernel(cic_gemm_args g, int gps) {
-    unsigned long long* stamps = g_stamp_buf;
+    unsigned long long* stamps = CIC_STAMP_BUF(g_stamp_buf);
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
     if (stamps) st0 = __builtin_amdgcn_s_memrealtime();
     // gps = groups (of 8 k) per K slice, a multiple of CH; processed in chunks of CH groups with a
@@ -1024,7 +1028,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
     const int li = lane & 15, lq = lane >> 4;
-    unsigned long long* stamps = g_stamp_buf;             // diagnostics: [workgroup][wave][64] phase stamps (100 MHz)
+    unsigned long long* stamps = CIC_STAMP_BUF(g_stamp_buf);             // diagnostics: [workgroup][wave][64] phase stamps (100 MHz)
     if (stamps) stamps += ((size_t)blockIdx.x * 4 + w) * 64;
     int sidx = 0;
     auto stamp = [&]() { if (stamps && lane == 0 && sidx < 60) stamps[sidx] = __builtin_amdgcn_s_memrealtime(); ++sidx; };
@@ -1145,9 +1149,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // 2.9 us per tile for 1.9 us of MFMAs).  The two K halves of a tile meet through 4 KB of LDS: the upper-half wave
 // parks its four sums there before the tile's barrier, the lower-half wave adds them (lower + upper: a fixed order)
 // while it stores the tile under the next tile's MFMAs.
-template <int NG, int KH>   // KH K parts per row tile: 4 * KH waves, KH per SIMD
+//
+// EPI: the fused vocabulary epilogue (cic.h, "Row partials of the vocabulary").  The lower-half wave of a row tile is the
+// one that finishes a logit (lower + upper + bias) while the NEXT tile's MFMAs run; with EPI it also feeds the value
+// to the running partial of its row - 4 rows x 1 column per lane and tile, reduced over the 16 lanes of a row group
+// once, after the walk.  Part index = the walker's index: a workgroup's columns are the tiles first, first + walkers, ...
+// Noise: injected uniforms (tests) or ONE Philox call per lane and tile - lane c of a quad draws the four uniforms
+// of row 4*lq + c at the quad's four columns, and a 4x4 transpose inside the quad (DPP) hands every lane its own
+// column of rows 4*lq + 0..3.
+template <int NG, int KH, int EPI>   // KH K parts per row tile: 4 * KH waves, KH per SIMD; EPI: the fused vocabulary epilogue
 __global__ __launch_bounds__(256 * KH) __attribute__((amdgpu_waves_per_eu(KH, KH))) void gemm_ldsb2_walk_kernel(
-    cic_gemm_args g, int row_groups, int walkers) {
+    cic_gemm_args g, int row_groups, int walkers, cic_logit_epilogue epi) {
     constexpr int K = 16 * NG, LDB = K + 4, TILE = 16 * LDB, NH = NG / KH, NT = 256 * KH;
     constexpr int CH = 8, NC = NH / CH;
     constexpr int F4 = 16 * (K / 4) / NT;                  // float4 per thread and staged tile
@@ -1200,61 +1212,195 @@ __global__ __launch_bounds__(256 * KH) __attribute__((amdgpu_waves_per_eu(KH, KH
     float prev[4];                                         // the previous tile's sums of this wave's K half
     int prev_n = -1;
     float prev_bias = 0.f;
-    auto store_row = [&](int v) {                          // lower-half waves: output register v of the previous tile
-        const int mm = m0 + 16 * rt + 4 * lq + v;
-        if (kh == 0 && prev_n >= 0) {
-            float x = prev[v];
+    // ---- fused epilogue (EPI).  Two software pipelines ride in the 16 slots between the MFMA groups of a tile:
+    //   upper-half wave (kh == 1): the Gumbel noise of THIS tile's 4 rows x 1 column per lane - one Philox call per lane
+    //     (lane c of a quad draws the four uniforms of row 4*lq + c at the quad's four columns, one round per slot), a 4x4
+    //     transpose inside the quad (DPP), -log(-log u) - parked in LDS for the lower-half wave (tests inject U instead);
+    //   lower-half wave (kh == 0): finishes the PREVIOUS tile's logits (lower + upper + bias, stored raw) and feeds them,
+    //     with that noise, to the running partial of their row: one (row, column) per slot group, straight-line code.
+    const cic_logit_epi_rows er = epi.blk[blk2 ? 1 : 0];
+    float* noisebuf = pairbuf + 2 * 4 * (KH - 1) * 4 * 64;  // [2 parities][4 row tiles][4 registers][64 lanes]
+    RowPart rp[4];
+    int cons[4];
+    float gprev[4] = {0.f, 0.f, 0.f, 0.f};
+    PhiloxState phs;
+    float uq[4] = {0.5f, 0.5f, 0.5f, 0.5f}, u4[4] = {0.5f, 0.5f, 0.5f, 0.5f};
 #pragma unroll
-            for (int u = 0; u < KH - 1; ++u) x += pairbuf[((((buf ^ 1) * 4 + rt) * (KH - 1) + u) * 4 + v) * 64 + lane];
-            x += prev_bias;
-            if (mm < Mloc && prev_n < g.N) gC[(size_t)mm * g.ldc + prev_n] = x;
+    for (int v = 0; v < 4; ++v) { rp[v].init(); cons[v] = -1; }
+    phs.init(0, 0);
+    if (EPI && kh == 0 && er.cons_seq) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int mm = m0 + 16 * rt + 4 * lq + v;
+            cons[v] = er.cons_seq[(size_t)(mm < Mloc ? mm : Mloc - 1) * er.cons_ld + er.cons_col];
+        }
+    }
+    // ROLE: 0 = no epilogue (every wave; the lower halves store their rows); with EPI: 1 = lower-half wave (MODE = its rows'
+    // sampling mode), 2 / 3 = upper-half wave making the noise from the Philox stream / from injected uniforms, 4 = an upper
+    // wave with nothing to add.  One straight-line loop body per role: no wave-uniform branch inside the MFMA stream.
+    auto walk = [&](auto role_, auto mode_) {
+        constexpr int ROLE = decltype(role_)::value, MODE = decltype(mode_)::value;
+        auto noise_slot = [&](int sl, int n) {             // slot sl of 16, tile column n of this lane
+            if (ROLE == 3) {                               // injected uniforms (tests)
+                if (sl == 0) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int mm = m0 + 16 * rt + 4 * lq + v;
+                        uq[v] = er.U[(size_t)(mm < Mloc ? mm : Mloc - 1) * er.ldu + (n < g.N ? n : g.N - 1)];
+                    }
+                }
+            } else if (sl == 0) {
+                const int c = li & 3;
+                const int qrow = m0 + 16 * rt + 4 * lq + c;
+                phs.init((er.elem0 + (uint64_t)qrow * (uint64_t)er.ldu + (uint64_t)(n - c)) >> 2, er.seed);   // the quad's 4 columns
+            } else if (sl <= 5) {
+                phs.round();
+                phs.round();
+            } else if (sl <= 9) {
+                // 4x4 transpose inside the quad, one destination register per slot: lane c takes element c of quad lane V
+                const int c = li & 3;
+                if (sl == 6) { u4[0] = u32_to_unit(phs.c0); u4[1] = u32_to_unit(phs.c1); u4[2] = u32_to_unit(phs.c2); u4[3] = u32_to_unit(phs.c3); }
+#define QB(x, V) dpp_f32<(V) * 0x55>(x)                        /* quad_perm [V,V,V,V]: lane V of the quad to all four */
+#define PICK(V) { const float b0 = QB(u4[0], V), b1 = QB(u4[1], V), b2 = QB(u4[2], V), b3 = QB(u4[3], V);          \
+                  uq[V] = c == 0 ? b0 : (c == 1 ? b1 : (c == 2 ? b2 : b3)); }
+                if (sl == 6) PICK(0)
+                if (sl == 7) PICK(1)
+                if (sl == 8) PICK(2)
+                if (sl == 9) PICK(3)
+#undef PICK
+#undef QB
+            }
+            if (sl >= 10 && sl <= 13) noisebuf[((buf * 4 + rt) * 4 + (sl - 10)) * 64 + lane] = gumbel_from_u(uq[sl - 10]);
+        };
+        auto finish_row = [&](int v) {                     // lower-half waves: output register v of the previous tile
+            const int mm = m0 + 16 * rt + 4 * lq + v;
+            if ((ROLE == 1 || kh == 0) && prev_n >= 0) {
+                float x = prev[v];
+#pragma unroll
+                for (int u = 0; u < KH - 1; ++u) x += pairbuf[((((buf ^ 1) * 4 + rt) * (KH - 1) + u) * 4 + v) * 64 + lane];
+                x += prev_bias;
+                if (mm < Mloc && prev_n < g.N) {
+                    gC[(size_t)mm * g.ldc + prev_n] = x;
+                    if (ROLE == 1) {
+                        const float xe = prev_n == cons[v] ? -INFINITY : x;      // decoding constraint, AttModel.py:438-442
+                        rowpart_add_m<MODE>(rp[v], er.inv_temp, xe, gprev[v], prev_n);
+                    }
+                }
+            }
+        };
+        auto load_noise = [&]() {
+            if (er.noise && prev_n >= 0) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) gprev[v] = noisebuf[(((buf ^ 1) * 4 + rt) * 4 + v) * 64 + lane];
+            }
+        };
+#pragma unroll 1
+        for (int t = first; t < tiles_n; t += walkers) {
+            load_tile(t + walkers);                        // next tile's rows in flight under this tile's MFMAs
+            const int n = t * 16 + li;
+            const int ncl = n < g.N ? n : g.N - 1;
+            float bias_v = 0.f;
+            if (g.bias) bias_v = g.bias[ncl];
+            const float* bt = lds + buf * TILE + li * LDB + 16 * NH * kh + 4 * lq;
+            float* nxt = lds + (buf ^ 1) * TILE;           // every wave left this buffer before the last barrier
+            f32x4acc acc[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[s] = f32x4acc{0.f, 0.f, 0.f, 0.f};
+            f32x4 bq[2][CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) bq[0][i] = *reinterpret_cast<const f32x4*>(bt + 16 * i);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if (c + 1 < NC) {
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) bq[(c + 1) & 1][i] = *reinterpret_cast<const f32x4*>(bt + 16 * ((c + 1) * CH + i));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c * CH + i][s], bq[c & 1][i][s], acc[s], 0, 0, 0);
+                    if (ROLE == 0) {
+                        if (c == 0 && i < 4) { finish_row(i); __builtin_amdgcn_sched_barrier(0); }
+                    } else if (ROLE != 4) {
+                        // 16 slots spread over the NC * CH MFMA groups of the tile
+                        constexpr int GN = NC * CH;
+#pragma unroll
+                        for (int sl = (c * CH + i) * 16 / GN; sl < (c * CH + i + 1) * 16 / GN; ++sl) {
+                            if (ROLE == 1) {
+                                if (sl == 0) load_noise();
+                                if ((sl & 3) == 1) finish_row(sl >> 2);
+                            } else {
+                                noise_slot(sl, n);
+                            }
+                        }
+                        // the lower wave's slots are pinned between the MFMA groups; the upper wave's noise pipeline is left to
+                        // the compiler's scheduler (measured: pinned 40.7 us, every 4th group 40.7, free 39.0 per launch)
+                        if (ROLE == 1) __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (c == NC - 1 && i < F4) { store_piece(nxt, i); __builtin_amdgcn_sched_barrier(0); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) prev[v] = (acc[0][v] + acc[1][v]) + (acc[2][v] + acc[3][v]);
+            if (kh >= 1) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) pairbuf[(((buf * 4 + rt) * (KH - 1) + (kh - 1)) * 4 + v) * 64 + lane] = prev[v];
+            }
+            prev_n = n;
+            prev_bias = bias_v;
+            __syncthreads();
+            buf ^= 1;
+        }
+        if (ROLE == 1) load_noise();
+        if (ROLE == 0 || ROLE == 1) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) finish_row(v);
         }
     };
-#pragma unroll 1
-    for (int t = first; t < tiles_n; t += walkers) {
-        load_tile(t + walkers);                            // next tile's rows in flight under this tile's MFMAs
-        const int n = t * 16 + li;
-        const int ncl = n < g.N ? n : g.N - 1;
-        float bias_v = 0.f;
-        if (g.bias) bias_v = g.bias[ncl];
-        const float* bt = lds + buf * TILE + li * LDB + 16 * NH * kh + 4 * lq;
-        float* nxt = lds + (buf ^ 1) * TILE;               // every wave left this buffer before the last barrier
-        f32x4acc acc[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc[s] = f32x4acc{0.f, 0.f, 0.f, 0.f};
-        f32x4 bq[2][CH];
-#pragma unroll
-        for (int i = 0; i < CH; ++i) bq[0][i] = *reinterpret_cast<const f32x4*>(bt + 16 * i);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            if (c + 1 < NC) {
-#pragma unroll
-                for (int i = 0; i < CH; ++i) bq[(c + 1) & 1][i] = *reinterpret_cast<const f32x4*>(bt + 16 * ((c + 1) * CH + i));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < CH; ++i) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c * CH + i][s], bq[c & 1][i][s], acc[s], 0, 0, 0);
-                if (c == 0 && i < 4) { store_row(i); __builtin_amdgcn_sched_barrier(0); }
-                if (c == NC - 1 && i < F4) { store_piece(nxt, i); __builtin_amdgcn_sched_barrier(0); }
-            }
-            __builtin_amdgcn_sched_barrier(0);
+    using std::integral_constant;
+    if (!EPI) {
+        walk(integral_constant<int, 0>{}, integral_constant<int, 0>{});
+    } else if (kh == 0) {
+        switch (er.mode) {
+            case CIC_SAMPLE_NONE: walk(integral_constant<int, 1>{}, integral_constant<int, CIC_SAMPLE_NONE>{}); break;
+            case CIC_SAMPLE_GREEDY: walk(integral_constant<int, 1>{}, integral_constant<int, CIC_SAMPLE_GREEDY>{}); break;
+            case CIC_SAMPLE_GUMBEL_ST: walk(integral_constant<int, 1>{}, integral_constant<int, CIC_SAMPLE_GUMBEL_ST>{}); break;
+            case CIC_SAMPLE_MULTINOMIAL_ST: walk(integral_constant<int, 1>{}, integral_constant<int, CIC_SAMPLE_MULTINOMIAL_ST>{}); break;
+            default: walk(integral_constant<int, 1>{}, integral_constant<int, CIC_SAMPLE_MULTINOMIAL>{}); break;   // + TEACHER
         }
-#pragma unroll
-        for (int v = 0; v < 4; ++v) prev[v] = (acc[0][v] + acc[1][v]) + (acc[2][v] + acc[3][v]);
-        if (kh >= 1) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) pairbuf[(((buf * 4 + rt) * (KH - 1) + (kh - 1)) * 4 + v) * 64 + lane] = prev[v];
-        }
-        prev_n = n;
-        prev_bias = bias_v;
-        __syncthreads();
-        buf ^= 1;
+    } else if (kh == 1 && er.noise) {
+        if (er.U) walk(integral_constant<int, 3>{}, integral_constant<int, 0>{});
+        else walk(integral_constant<int, 2>{}, integral_constant<int, 0>{});
+    } else {
+        walk(integral_constant<int, 4>{}, integral_constant<int, 0>{});
+    }
+    if (EPI && kh == 0) {
+        // the 16 lanes of a row group (same lq: one DPP row) hold the 16 columns of every tile: all-reduce them with DPP
+        // lane exchanges (xor 1, xor 2, mirror within 8, mirror within 16 - no LDS crossbar), lane li == 0 writes
+#define RP_STEP(CTRL)                                                                                              \
+    {                                                                                                              \
+        RowPart q;                                                                                                 \
+        q.m1 = dpp_f32<CTRL>(rp[v].m1); q.s1 = dpp_f32<CTRL>(rp[v].s1);                                              \
+        q.kbest = dpp_f32<CTRL>(rp[v].kbest); q.xbest = dpp_f32<CTRL>(rp[v].xbest);                                  \
+        q.kidx = __float_as_int(dpp_f32<CTRL>(__int_as_float(rp[v].kidx))); q.s2 = dpp_f32<CTRL>(rp[v].s2);         \
+        rowpart_merge(rp[v], er.mode, er.inv_temp, q);                                                             \
     }
 #pragma unroll
-    for (int v = 0; v < 4; ++v) store_row(v);
+        for (int v = 0; v < 4; ++v) {
+            RP_STEP(DPP_QUAD_XOR1) RP_STEP(DPP_QUAD_XOR2) RP_STEP(DPP_ROW_HALF_MIRROR) RP_STEP(DPP_ROW_MIRROR)
+            const int mm = m0 + 16 * rt + 4 * lq + v;
+            if (li == 0 && mm < Mloc && er.part) {
+                const size_t plane = (size_t)er.part_rows * walkers;
+                float* pp = er.part + (size_t)mm * walkers + first;
+                pp[0] = rp[v].m1; pp[plane] = rp[v].s1; pp[2 * plane] = rp[v].kbest; pp[3 * plane] = rp[v].xbest;
+                pp[4 * plane] = __int_as_float(rp[v].kidx); pp[5 * plane] = rp[v].s2;
+            }
+        }
+#undef RP_STEP
+    }
 }
 
 bool ldsb_walk_ok(const cic_gemm_args& g) {
@@ -1282,22 +1428,35 @@ int launch_ldsb_walk(const cic_gemm_args& g, hipStream_t st) {
     if (walkers > tiles_n) walkers = tiles_n;
     int grid = row_groups * walkers;
     if (g_ldsb2 == 2 || g_ldsb2 == 4) {
-        const size_t lds2_bytes = lds_bytes + 2 * 4 * (g_ldsb2 - 1) * 4 * 64 * sizeof(float);
+        // staged tiles + the K-half hand-off + the noise hand-off of the fused epilogue
+        const size_t lds2_bytes = lds_bytes + 2 * 4 * (g_ldsb2 - 1) * 4 * 64 * sizeof(float) + 2 * 4 * 4 * 64 * sizeof(float);
         static bool attr2_set = false;
         if (!attr2_set) {
-            CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2_walk_kernel<NG, 2>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bytes + 2 * 4 * 1 * 4 * 64 * 4)));
-            CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2_walk_kernel<NG, 4>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bytes + 2 * 4 * 3 * 4 * 64 * 4)));
+            CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2_walk_kernel<NG, 2, 0>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bytes + 2 * 4 * 1 * 4 * 64 * 4 + 8192)));
+            CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2_walk_kernel<NG, 4, 0>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bytes + 2 * 4 * 3 * 4 * 64 * 4 + 8192)));
+            CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2_walk_kernel<NG, 2, 1>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bytes + 2 * 4 * 1 * 4 * 64 * 4 + 8192)));
+            CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2_walk_kernel<NG, 4, 1>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bytes + 2 * 4 * 3 * 4 * 64 * 4 + 8192)));
             attr2_set = true;
         }
-        if (g_ldsb2 == 2)
-            hipLaunchKernelGGL((gemm_ldsb2_walk_kernel<NG, 2>), dim3(grid), dim3(512), lds2_bytes, st, g, row_groups, walkers);
+        cic_logit_epilogue epi = {};
+        if (g.epi) epi = *g.epi;
+        if (g.epi) {
+            if (g_ldsb2 == 2)
+                hipLaunchKernelGGL((gemm_ldsb2_walk_kernel<NG, 2, 1>), dim3(grid), dim3(512), lds2_bytes, st, g, row_groups, walkers, epi);
+            else
+                hipLaunchKernelGGL((gemm_ldsb2_walk_kernel<NG, 4, 1>), dim3(grid), dim3(1024), lds2_bytes, st, g, row_groups, walkers, epi);
+        } else if (g_ldsb2 == 2)
+            hipLaunchKernelGGL((gemm_ldsb2_walk_kernel<NG, 2, 0>), dim3(grid), dim3(512), lds2_bytes, st, g, row_groups, walkers, epi);
         else
-            hipLaunchKernelGGL((gemm_ldsb2_walk_kernel<NG, 4>), dim3(grid), dim3(1024), lds2_bytes, st, g, row_groups, walkers);
+            hipLaunchKernelGGL((gemm_ldsb2_walk_kernel<NG, 4, 0>), dim3(grid), dim3(1024), lds2_bytes, st, g, row_groups, walkers, epi);
         CIC_LAUNCH_CHECK();
         return 0;
     }
+    CIC_REQUIRE(!g.epi);
     hipLaunchKernelGGL((gemm_ldsb_walk_kernel<NG>), dim3(grid), dim3(256), lds_bytes, st, g, row_groups, walkers);
     CIC_LAUNCH_CHECK();
     return 0;
@@ -1484,6 +1643,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
 
 }  // namespace
 
+#ifdef CIC_DEVTOOLS
 extern "C" int cic_debug_gemm_tail_split(int on) {
     g_tail_split = on & 0xff;
     g_force_tile = (on >> 8) & 0xff;
@@ -1493,6 +1653,7 @@ extern "C" int cic_debug_gemm_tail_split(int on) {
     g_split_rows = ((on >> 23) & 1) ? 0 : 1;
     g_rega2 = ((on >> 24) & 1) ? 0 : 1;
     g_ldsb2 = ((on >> 25) & 3) == 1 ? 0 : (((on >> 25) & 3) == 2 ? 4 : 2);
+    g_logit_epi = ((on >> 27) & 1) ? 0 : 1;
     return 0;
 }
 
@@ -1500,6 +1661,7 @@ extern "C" int cic_debug_set_stamps(unsigned long long* buf) {
     CIC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)));
     return 0;
 }
+#endif
 
 static bool gemm_split_supported(const cic_gemm_args& g) {
     // the 16-wide strip walker (launch_rega): K-contiguous operands, x and h halves of 512, whole 16-column tiles
@@ -1509,9 +1671,35 @@ static bool gemm_split_supported(const cic_gemm_args& g) {
 }
 extern "C" int cic_gemm_split_ok(const cic_gemm_args* a) { return a && gemm_split_supported(*a) ? 1 : 0; }
 
+// rows 129..256 of K-contiguous activations are handed to the register-streaming kernels as two blocks of 128
+static bool split_rows_case(const cic_gemm_args& g) {
+    return g.rows_blk == 0 && g_split_rows && g.a_kc && g.M > 128 && g.M <= 256 && !g.colsum_A;
+}
+static int ldsb_walk_parts(const cic_gemm_args& g) {     // the geometry of launch_ldsb_walk
+    const int row_groups = g.rows_blk > 0 ? cic_cdiv(g.rows_blk, 64) + cic_cdiv(g.M - g.rows_blk, 64) : cic_cdiv(g.M, 64);
+    const int tiles_n = cic_cdiv(g.N, 16);
+    int walkers = 256 / row_groups;
+    if (walkers < 1) walkers = 1;
+    if (walkers > tiles_n) walkers = tiles_n;
+    return walkers;
+}
+extern "C" int cic_gemm_logit_parts(const cic_gemm_args* a) {
+    if (!a || a->n_split > 0 || a->colsum_A || !g_logit_epi || !(g_ldsb && (g_ldsb2 == 2 || g_ldsb2 == 4))) return 0;
+    cic_gemm_args g = *a;
+    if (split_rows_case(g)) {
+        g.rows_blk = 128; g.A_b = g.A + (size_t)128 * g.lda; g.C_b = g.C + (size_t)128 * g.ldc;
+        if (!rega_ok(g)) return 0;
+    } else if (g.rows_blk > 0 && !rega_ok(g)) {
+        return 0;
+    }
+    if (!ldsb_walk_ok(g) || g.M > 256) return 0;
+    return ldsb_walk_parts(g);
+}
+
 extern "C" int cic_gemm_f32(const cic_gemm_args* a, cic_stream_t s) {
     CIC_REQUIRE(a != nullptr);
     const cic_gemm_args& g = *a;
+    CIC_REQUIRE(!g.epi || cic_gemm_logit_parts(a) > 0);
     if (g.n_split > 0) {
         CIC_REQUIRE(gemm_split_supported(g));
         return launch_rega(g, cic_s(s));
@@ -1541,6 +1729,17 @@ extern "C" int cic_gemm_f32(const cic_gemm_args* a, cic_stream_t s) {
         h2.A_b = g.A + (size_t)128 * g.lda;
         h2.C_b = g.C + (size_t)128 * g.ldc;
         if (g.K2 > 0) h2.A2_b = g.A2 + (size_t)128 * g.lda2;
+        cic_logit_epilogue e2;
+        if (g.epi) {                             // the second row block continues the first one's rows
+            e2 = *g.epi;
+            cic_logit_epi_rows& b = e2.blk[1];
+            b = e2.blk[0];
+            if (b.U) b.U += (size_t)128 * b.ldu;
+            b.elem0 += (uint64_t)128 * (uint64_t)b.ldu;
+            if (b.cons_seq) b.cons_seq += (size_t)128 * b.cons_ld;
+            if (b.part) b.part += (size_t)128 * ldsb_walk_parts(h2);
+            h2.epi = &e2;
+        }
         if (rega_ok(h2)) {
             if (g_ldsb && ldsb_walk_ok(h2)) return launch_ldsb_walk(h2, cic_s(s));
             return launch_rega(h2, cic_s(s));

@@ -15,7 +15,7 @@
 
 namespace {
 
-int g_gru_fused = 1;   // cic_debug_gru_fused(0): GEMM + cell launches per step (A/B measurement)
+CIC_SWITCH(g_gru_fused, 1);   // development build: cic_debug_gru_fused(0) = GEMM + cell launches per step (A/B measurement)
 
 // ---- token preparation -----------------------------------------------------------------
 // generated captions: tokens = [<bos>, seq[:, 0:L]], lens from masks [1,1,(seq>0)[:, :L-1]]
@@ -489,10 +489,12 @@ int check_ldims(const cic_listener_dims& d) {
 
 }  // namespace
 
+#ifdef CIC_DEVTOOLS
 extern "C" int cic_debug_gru_fused(int on) {
     g_gru_fused = on;
     return 0;
 }
+#endif
 
 extern "C" size_t cic_listener_ws_bytes(const cic_listener_dims* d) {
     if (!d) return 0;
@@ -507,31 +509,13 @@ static int listener_bwd_impl(const cic_listener_dims* dp, const cic_listener_par
 extern "C" int cic_listener_fwd(const cic_listener_dims* dp, const cic_listener_params* p, const cic_listener_io* io,
                                 void* ws, size_t ws_bytes, cic_stream_t s) {
     CIC_REQUIRE(dp && p && io && ws);
-    uint64_t key = cic_hash_bytes("listener_fwd", 12, 1469598103934665603ull);
-    key = cic_hash_bytes(dp, sizeof(*dp), key);
-    key = cic_hash_bytes(p, sizeof(*p), key);
-    key = cic_hash_bytes(io, sizeof(*io), key);
-    key = cic_hash_bytes(&ws, sizeof(ws), key);
-    CicGraphScope gs(cic_s(s), key);
-    if (gs.replayed) return 0;
-    return gs.finish(listener_fwd_impl(dp, p, io, ws, ws_bytes, s));
+    return listener_fwd_impl(dp, p, io, ws, ws_bytes, s);
 }
 
 extern "C" int cic_listener_bwd(const cic_listener_dims* dp, const cic_listener_params* p, const cic_listener_io* io,
                                 const cic_listener_bwd_io* bio, void* ws, size_t ws_bytes, cic_stream_t s) {
     CIC_REQUIRE(dp && p && io && bio && ws);
-    uint64_t key = cic_hash_bytes("listener_bwd", 12, 1469598103934665603ull);
-    key = cic_hash_bytes(dp, sizeof(*dp), key);
-    key = cic_hash_bytes(p, sizeof(*p), key);
-    key = cic_hash_bytes(io, sizeof(*io), key);
-    key = cic_hash_bytes(&bio->g_rows, sizeof(void*), key);
-    key = cic_hash_bytes(&bio->g_scalar, sizeof(void*), key);
-    if (bio->grads) key = cic_hash_bytes(bio->grads, sizeof(*bio->grads), key);
-    key = cic_hash_bytes(&bio->d_onehot, sizeof(void*), key);
-    key = cic_hash_bytes(&ws, sizeof(ws), key);
-    CicGraphScope gs(cic_s(s), key);
-    if (gs.replayed) return 0;
-    return gs.finish(listener_bwd_impl(dp, p, io, bio, ws, ws_bytes, s));
+    return listener_bwd_impl(dp, p, io, bio, ws, ws_bytes, s);
 }
 
 static int listener_fwd_impl(const cic_listener_dims* dp, const cic_listener_params* p, const cic_listener_io* io,

@@ -49,10 +49,17 @@ __global__ __launch_bounds__(SNW * 64) void sampler_bwd_kernel(const float* __re
                                                           const float* __restrict__ dslp,       // [B,T] or null
                                                           const int32_t* __restrict__ Lp, int mode, float tau,
                                                           float* __restrict__ dlogits,          // [T,B,V1] (may alias G)
-                                                          int T, int B, int V1) {
+                                                          int T, int B, int V1,
+                                                          // logp_all holds RAW logits and lse_all their [T,B] log-sum-exp
+                                                          // (row-wise decodes), or log-probs and NULL
+                                                          const float* __restrict__ lse_all,
+                                                          // U == NULL: the uniforms are drawn here, element i of the
+                                                          // [T+1,B,V1] slab = element u_elem0 + i of the Philox stream
+                                                          int u_philox, uint64_t u_seed, uint64_t u_elem0) {
     constexpr int NT = SNW * 64;
     __shared__ float sh[SNW];
     const int row = blockIdx.x, t = row / B, b = row % B, tid = threadIdx.x;
+    const float lse = lse_all ? lse_all[row] : 0.f;
     const int L = Lp ? *Lp : T;
     const float* lp = logp_all + (size_t)row * V1;
     float* out = dlogits + (size_t)row * V1;
@@ -68,7 +75,9 @@ __global__ __launch_bounds__(SNW * 64) void sampler_bwd_kernel(const float* __re
     // row goes out before the first use (element loads under column conditions compile to one load + full wait each:
     // 36 serial round trips per thread at RV = 3)
     const bool fast = (V1 & 3) == 0 && ((reinterpret_cast<uintptr_t>(logp_all) | reinterpret_cast<uintptr_t>(dlogits) |
-                                         reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(U)) & 15) == 0;
+                                         reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(U)) & 15) == 0 &&
+                      (U || !u_philox || (u_elem0 & 3) == 0);
+    const uint64_t urow_elem = u_elem0 + ((uint64_t)(t + 1) * (uint64_t)B + (uint64_t)b) * (uint64_t)V1;
     if (!unf && ds == 0.f) {   // block-uniform: nothing flows into this row
         if (fast) {
             for (int q = tid; q < nq; q += NT) reinterpret_cast<f32x4*>(out)[q] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -100,7 +109,9 @@ __global__ __launch_bounds__(SNW * 64) void sampler_bwd_kernel(const float* __re
 #pragma unroll
             for (int r = 0; r < RV; ++r) {
                 const int q = tid + NT * r;
-                uv[r] = reinterpret_cast<const f32x4*>(urow)[q < nq ? q : nq - 1];
+                const int qc = q < nq ? q : nq - 1;
+                if (urow) uv[r] = reinterpret_cast<const f32x4*>(urow)[qc];
+                else uv[r] = philox_uniform4(u_seed, (urow_elem >> 2) + (uint64_t)qc);   // one call = the float4's four uniforms
             }
         }
 #pragma unroll
@@ -108,7 +119,7 @@ __global__ __launch_bounds__(SNW * 64) void sampler_bwd_kernel(const float* __re
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const bool ok = (tid + NT * r) < nq;
-                x[r][e] = ok ? xv[r][e] : -INFINITY;
+                x[r][e] = ok ? xv[r][e] - lse : -INFINITY;
                 gg[r][e] = (ok && unf) ? gv[r][e] : 0.f;
                 float z = -INFINITY;
                 if (ok && unf) z = gum ? (x[r][e] + gumbel_from_u(uv[r][e])) * inv_t : x[r][e] * inv_t;
@@ -122,11 +133,18 @@ __global__ __launch_bounds__(SNW * 64) void sampler_bwd_kernel(const float* __re
             for (int e = 0; e < 4; ++e) {
                 const int c = 4 * (tid + NT * r) + e;
                 const bool ok = (tid + NT * r) < nq && c < V1;
-                x[r][e] = ok ? lp[c] : -INFINITY;
+                x[r][e] = ok ? lp[c] - lse : -INFINITY;
                 gg[r][e] = (ok && unf) ? g[c] : 0.f;
                 float z = -INFINITY;
                 if (ok && unf) {
-                    z = (mode == CIC_SAMPLE_GUMBEL_ST) ? (x[r][e] + gumbel_from_u(urow[c])) * inv_t : x[r][e] * inv_t;
+                    if (mode == CIC_SAMPLE_GUMBEL_ST) {
+                        float u;
+                        if (urow) u = urow[c];
+                        else { const uint64_t el = urow_elem + (uint64_t)c; u = philox_uniform4(u_seed, el >> 2)[el & 3]; }
+                        z = (x[r][e] + gumbel_from_u(u)) * inv_t;
+                    } else {
+                        z = x[r][e] * inv_t;
+                    }
                 }
                 y[r][e] = z;
                 zm = fmaxf(zm, z);
@@ -662,20 +680,7 @@ extern "C" int cic_speaker_decode_bwd(const cic_speaker_dims* dp, const cic_spea
                                       const cic_decode_bwd_io* bio, void* ws_fwd, size_t ws_fwd_bytes, void* ws_bwd,
                                       size_t ws_bwd_bytes, cic_stream_t s) {
     CIC_REQUIRE(dp && p && io && bio && ws_fwd && ws_bwd && bio->grads && (bio->att_raw || io->fc_mode));
-    uint64_t key = cic_hash_bytes("decode_bwd", 10, 1469598103934665603ull);
-    key = cic_hash_bytes(dp, sizeof(*dp), key);
-    key = cic_hash_bytes(p, sizeof(*p), key);
-    key = cic_hash_bytes(io, sizeof(*io), key);
-    key = cic_hash_bytes(&bio->d_onehot, sizeof(void*), key);
-    key = cic_hash_bytes(&bio->dslp, sizeof(void*), key);
-    key = cic_hash_bytes(bio->grads, sizeof(*bio->grads), key);
-    key = cic_hash_bytes(&bio->att_raw, sizeof(void*), key);
-    key = cic_hash_bytes(&bio->phase, sizeof(int), key);
-    key = cic_hash_bytes(&ws_fwd, sizeof(ws_fwd), key);
-    key = cic_hash_bytes(&ws_bwd, sizeof(ws_bwd), key);
-    CicGraphScope gs(cic_s(s), key);
-    if (gs.replayed) return 0;
-    return gs.finish(decode_bwd_impl(dp, p, io, bio, ws_fwd, ws_fwd_bytes, ws_bwd, ws_bwd_bytes, s));
+    return decode_bwd_impl(dp, p, io, bio, ws_fwd, ws_fwd_bytes, ws_bwd, ws_bwd_bytes, s);
 }
 
 static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params* p, const cic_decode_io* io,
@@ -690,7 +695,7 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     SpkBws g = spk_bcarve(d, ws_bwd, true);
     CIC_REQUIRE(ws_bwd_bytes >= g.bytes);
     const bool ps = io->mode == CIC_SAMPLE_GUMBEL_PS || io->mode == CIC_SAMPLE_MULTINOMIAL_PS;
-    CIC_REQUIRE(!(bio->d_onehot && io->mode == CIC_SAMPLE_GUMBEL_ST) || io->U);
+    CIC_REQUIRE(!(bio->d_onehot && io->mode == CIC_SAMPLE_GUMBEL_ST) || io->U || io->u_philox);
     CIC_REQUIRE(!bio->d_onehot || io->seq);
     CIC_REQUIRE(!ps || (io->soft_raw && io->xpre && io->seq && (io->mode != CIC_SAMPLE_GUMBEL_PS || io->U)));
     const int phase = bio->phase;
@@ -709,7 +714,8 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         dim3 grid(T * B), blk(1024);
         const int64_t* tgt = io->mode == CIC_SAMPLE_TEACHER ? io->pick : nullptr;
 #define GO(RV) hipLaunchKernelGGL((sampler_bwd_kernel<RV>), grid, blk, 0, st, w.logp_all, io->U, bio->d_onehot, w.it_all, \
-                                  tgt, io->seq, bio->dslp, io->L, io->mode, io->temp, g.dlogits, T, B, V1)
+                                  tgt, io->seq, bio->dslp, io->L, io->mode, io->temp, g.dlogits, T, B, V1, w.lse_all,        \
+                                  io->u_philox, io->u_seed, io->u_offset * 4ull)
         if (V1 <= 4096) GO(1); else if (V1 <= 12288) GO(3); else if (V1 <= 32768) GO(8);
         else { cic_set_error("vocabulary too large"); return 1; }
 #undef GO
@@ -718,15 +724,10 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     // 2. logit layer, batched over time: d_out = dlogits W,  dW += dlogits^T out,  db += colsum
     if (!ps && do_logit) RUN(gemm_nn(g.dlogits, V1, p->logit_w, H, g.d_out_all, H, T * B, H, V1, false, st));
 
-    // 2b. the logit layer's weight gradient needs only d logits and the saved outputs: it can run on a side stream
-    //     beside the latency-bound BPTT loop (cic_debug_side_stream(1); measured slower than one stream, so the
-    //     fork is a no-op by default and the product simply runs here; not for partial sampling, whose d logits
-    //     are made inside the loop)
-    hipStream_t side = st;
-    if (!ps && do_logit) {
-        if (phase == CIC_BWD_ALL) RUN(cic_side_fork(st, &side));
-        RUN(gemm_tn(g.dlogits, V1, w.out_all, H, gr->logit_w, H, V1, H, T * B, true, side, gr->logit_b));
-    }
+    // 2b. the logit layer's weight gradient needs only d logits and the saved outputs (a side stream for it beside the
+    //     latency-bound BPTT loop measured slower than one stream - its workgroups hold the CUs the loop's short kernels
+    //     need; not for partial sampling, whose d logits are made inside the loop)
+    if (!ps && do_logit) RUN(gemm_tn(g.dlogits, V1, w.out_all, H, gr->logit_w, H, V1, H, T * B, true, st, gr->logit_b));
     if (!do_rest) return 0;        // CIC_BWD_LOGIT: the logit layer's gradient is final; d out waits in ws_bwd
     // 3. BPTT over the cell + attention (only dh, dc are carried)
     float* dh_in = g.dh_a;
@@ -768,7 +769,7 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
             const float* ah = w.att_h_all + (size_t)t * B * A;
 #define GO(NI, KPW, HOLD) hipLaunchKernelGGL((attn_bwd_kernel<NI, KPW, 16, HOLD>), grid, blk, 0, st, dres, al, ah, \
                                              w.p_att, w.att, p->alpha_w, dah, ddot, K, A, H)
-            void* ph = cic_prof_begin(CIC_PROF_ATTN_BWD, st);
+            void* ph = cic_timer_begin(io->timer, CIC_TIMED_ATTN_BWD, st);
             if (A == H && (H & 31) == 0 && H <= 512 && K <= 64) {
                 dim3 blkc((H / 32) * 64);
                 const bool twin = false;   // measured: 7.5 us vs 6.9 us single-WG at B = 128 (latency-, not bandwidth-bound)
@@ -787,7 +788,7 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
             else if (mx <= 512) { if (K <= 48) GO(2, 3, true); else GO(2, 4, true); }
             else GO(4, 4, false);
 #undef GO
-            cic_prof_end(ph, st);
+            cic_timer_end(ph, st);
             CIC_LAUNCH_CHECK();
         }
         if (fc) {
@@ -816,7 +817,6 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     if (ps) {
         RUN(gemm_tn(g.dlogits, V1, w.out_all, H, gr->logit_w, H, V1, H, T * B, true, st, gr->logit_b));
     }
-    RUN(cic_side_join(st, side));
     // 4. weight gradients of the recurrent part, batched over time
     // (i2h.bias and h2h.bias receive the same column sums of dpre: one by-product, two targets)
     RUN(gemm_tn(g.dpre_all, 5 * H, w.x_all, E, gr->i2h_w, E, 5 * H, E, T * B, true, st, gr->i2h_b, gr->h2h_b));

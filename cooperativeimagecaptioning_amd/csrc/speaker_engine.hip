@@ -8,7 +8,7 @@
 
 namespace {
 
-int g_gates_att_fused = 1;   // cic_debug_gates_att_fused: 0 = separate h2att launch (A/B timing)
+CIC_SWITCH(g_gates_att_fused, 1);   // development build: cic_debug_gates_att_fused(0) = separate h2att launch (A/B timing)
 
 __global__ void fill_i32_kernel(int32_t* p, int n, int32_t v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -56,7 +56,9 @@ __global__ __launch_bounds__(256) void decode_init_kernel(DecodeInit a, DecodeIn
 
 }  // namespace
 
+#ifdef CIC_DEVTOOLS
 extern "C" int cic_debug_gates_att_fused(int on) { g_gates_att_fused = on; return 0; }
+#endif
 
 int cic_fill_i32(int32_t* p, int n, int32_t v, hipStream_t st) {
     hipLaunchKernelGGL(fill_i32_kernel, dim3(cic_cdiv(n, 256)), dim3(256), 0, st, p, n, v);
@@ -91,6 +93,8 @@ SpkWs spk_carve(const cic_speaker_dims& d, void* base) {
     w.it_all = c.i32((T + 1) * B);
     w.unfinished = c.i32(B);
     w.any_unf = c.i32(T + 1);
+    w.part = c.f32((size_t)CIC_PART_PLANES * CIC_PART_MAX_ENTRIES);
+    w.lse_all = c.f32(T * B);
     w.bytes = c.used();
     return w;
 }
@@ -123,14 +127,7 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
 extern "C" int cic_speaker_decode_fwd(const cic_speaker_dims* dp, const cic_speaker_params* p,
                                       const cic_decode_io* io, void* ws, size_t ws_bytes, cic_stream_t s) {
     CIC_REQUIRE(dp && p && io && ws);
-    uint64_t key = cic_hash_bytes("decode_fwd", 10, 1469598103934665603ull);
-    key = cic_hash_bytes(dp, sizeof(*dp), key);
-    key = cic_hash_bytes(p, sizeof(*p), key);
-    key = cic_hash_bytes(io, sizeof(*io), key);
-    key = cic_hash_bytes(&ws, sizeof(ws), key);
-    CicGraphScope gs(cic_s(s), key);
-    if (gs.replayed) return 0;
-    return gs.finish(decode_fwd_impl(dp, p, &io, &ws, &ws_bytes, 1, s));
+    return decode_fwd_impl(dp, p, &io, &ws, &ws_bytes, 1, s);
 }
 
 static bool pair_ok(const cic_speaker_dims& d, const cic_decode_io* a, const cic_decode_io* b) {
@@ -147,22 +144,13 @@ extern "C" int cic_speaker_decode_fwd_pair(const cic_speaker_dims* dp, const cic
                                            const cic_decode_io* io_a, void* ws_a, size_t ws_a_bytes,
                                            const cic_decode_io* io_b, void* ws_b, size_t ws_b_bytes, cic_stream_t s) {
     CIC_REQUIRE(dp && p && io_a && ws_a && io_b && ws_b && ws_a != ws_b);
-    uint64_t key = cic_hash_bytes("decode_fwd_pair", 15, 1469598103934665603ull);
-    key = cic_hash_bytes(dp, sizeof(*dp), key);
-    key = cic_hash_bytes(p, sizeof(*p), key);
-    key = cic_hash_bytes(io_a, sizeof(*io_a), key);
-    key = cic_hash_bytes(io_b, sizeof(*io_b), key);
-    key = cic_hash_bytes(&ws_a, sizeof(ws_a), key);
-    key = cic_hash_bytes(&ws_b, sizeof(ws_b), key);
-    CicGraphScope gs(cic_s(s), key);
-    if (gs.replayed) return 0;
     const cic_decode_io* ios[2] = {io_a, io_b};
     void* wss[2] = {ws_a, ws_b};
     const size_t wsb[2] = {ws_a_bytes, ws_b_bytes};
-    if (pair_ok(*dp, io_a, io_b)) return gs.finish(decode_fwd_impl(dp, p, ios, wss, wsb, 2, s));
+    if (pair_ok(*dp, io_a, io_b)) return decode_fwd_impl(dp, p, ios, wss, wsb, 2, s);
     int rc = decode_fwd_impl(dp, p, ios, wss, wsb, 1, s);          // shapes outside the paired kernels: one after the other
     if (!rc) rc = decode_fwd_impl(dp, p, ios + 1, wss + 1, wsb + 1, 1, s);
-    return gs.finish(rc);
+    return rc;
 }
 
 // nb = 1: one decode.  nb = 2: two decodes of the same images (e.g. the sampled and the greedy decode of a joint
@@ -297,7 +285,7 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         // att_masks are an input of the step (the same images in both decodes)
         CIC_REQUIRE(nb == 1 || io[0]->att_masks == io[1]->att_masks);
         if (!fc) {
-            CIC_PROF(CIC_PROF_ATTN_FWD, st,
+            CIC_TIMED(io[0]->timer, CIC_TIMED_ATTN_FWD, st,
                      rc = cic_attn_fwd2(Dual<const float>{att_h.a, att_h.b}, Dual<const float>{w[0].p_att, w[1].p_att},
                                         Dual<const float>{w[0].att, w[1].att}, p->alpha_w, p->alpha_b, io[0]->att_masks, att_res,
                                         SLAB(alpha_all, B * K), SLAB(dot_all, B * K), B, nb, K, A, H, st));
@@ -326,12 +314,44 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
                               fc ? 1 : 0));
         }
         // logprobs = log_softmax(logit(output)); choose the input of step t+1   (:328-365,444)
-        {
-            cic_gemm_args g = {};
-            g.M = M; g.N = V1; g.K = H; g.A = out.a; g.lda = H; g.a_kc = 1; g.B = p->logit_w; g.ldb = H; g.b_kc = 1;
-            g.C = logp.a; g.ldc = V1; g.bias = p->logit_b;
-            CIC_PROF(CIC_PROF_LOGIT_GEMM, st, rc = pair_gemm(g, out.b, nullptr, logp.b));
-            if (rc) return rc;
+        // Row-wise modes: the logits stay RAW in the workspace (+ their log-sum-exp per row); the vocabulary is reduced
+        // to row partials by the logit product's own epilogue (or, for shapes that kernel does not take, by a pass over
+        // the logits) and the sampler works on the partials.  Partial-sampling modes need whole soft rows: the row
+        // kernel normalises in place as before.
+        cic_gemm_args lg = {};
+        lg.M = M; lg.N = V1; lg.K = H; lg.A = out.a; lg.lda = H; lg.a_kc = 1; lg.B = p->logit_w; lg.ldb = H; lg.b_kc = 1;
+        lg.C = logp.a; lg.ldc = V1; lg.bias = p->logit_b;
+        if (nb == 2) { lg.rows_blk = B; lg.A_b = out.b; lg.C_b = logp.b; }
+        cic_logit_epilogue epi = {};
+        int np = 0;
+        if (!ps) {
+            for (int q = 0; q < nb; ++q) {
+                cic_logit_epi_rows& e = epi.blk[q];
+                const int mode = io[q]->mode;
+                e.mode = mode; e.inv_temp = 1.0f / io[q]->temp;
+                const bool gum = mode == CIC_SAMPLE_GUMBEL_ST;
+                const bool multi = mode == CIC_SAMPLE_MULTINOMIAL || mode == CIC_SAMPLE_MULTINOMIAL_ST;
+                const bool ss = mode == CIC_SAMPLE_TEACHER && io[q]->ss_u && io[q]->ss_prob > 0.f && !io[q]->ss_pick;
+                e.noise = (gum || (multi && !io[q]->pick) || ss) ? 1 : 0;
+                CIC_REQUIRE(!e.noise || io[q]->U || io[q]->u_philox);
+                e.U = (e.noise && io[q]->U) ? io[q]->U + (size_t)(t + 1) * B * V1 : nullptr; e.ldu = V1;
+                e.philox = io[q]->u_philox; e.seed = io[q]->u_seed;
+                e.elem0 = io[q]->u_offset * 4ull + (uint64_t)(t + 1) * (uint64_t)B * (uint64_t)V1;
+                if (io[q]->decoding_constraint && t + 1 >= 2) { e.cons_seq = io[q]->seq; e.cons_ld = T; e.cons_col = t - 1; }
+                e.part = w[q].part; e.part_rows = B;
+            }
+            np = cic_gemm_logit_parts(&lg);
+            // the walker's Philox draw covers whole aligned groups of four uniforms
+            for (int q = 0; q < nb; ++q)
+                if (epi.blk[q].noise && !epi.blk[q].U && ((V1 & 3) || (epi.blk[q].elem0 & 3))) np = 0;
+            if (np > 0) lg.epi = &epi;
+        }
+        CIC_TIMED(io[0]->timer, CIC_TIMED_LOGIT_GEMM, st, rc = cic_gemm_f32(&lg, st));
+        if (rc) return rc;
+        if (!ps && np == 0) {
+            np = CIC_PART_MAX_ENTRIES / B < 32 ? CIC_PART_MAX_ENTRIES / B : 32;
+            CIC_REQUIRE(np >= 1);
+            for (int q = 0; q < nb; ++q) RUN(cic_logit_partials(q ? logp.b : logp.a, B, V1, V1, &epi.blk[q], np, s));
         }
         cic_sampler_args sa[2];
         for (int q = 0; q < nb; ++q) {
@@ -360,7 +380,13 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
                 a.emb_scale = 1.0f / (1.0f - p_drop); a.emb_dim = E; a.emb_plain = fc ? 1 : 0;
             }
         }
-        CIC_PROF(CIC_PROF_SAMPLER, st, rc = cic_logsoftmax_sample2(&sa[0], nb == 2 ? &sa[1] : nullptr, st));
+        if (ps) {
+            CIC_TIMED(io[0]->timer, CIC_TIMED_SAMPLER, st, rc = cic_logsoftmax_sample2(&sa[0], nb == 2 ? &sa[1] : nullptr, st));
+        } else {
+            CIC_TIMED(io[0]->timer, CIC_TIMED_SAMPLER, st,
+                     rc = cic_sample_finish2(&sa[0], w[0].part, B, w[0].lse_all + (size_t)t * B, nb == 2 ? &sa[1] : nullptr,
+                                             w[1].part, B, nb == 2 ? w[1].lse_all + (size_t)t * B : nullptr, np, st));
+        }
         if (rc) return rc;
     }
 #undef SLAB

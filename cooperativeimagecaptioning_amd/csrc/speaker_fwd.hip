@@ -158,7 +158,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const float* __restri
 // TWIN: two workgroups per image (grid = 2B) when the batch alone cannot fill the chip: both compute
 // all K scores (each reads all of p_att), each produces one half of the output columns (reads half of
 // att).  Per-CU bytes drop from 147 KB to 110 KB and all 256 CUs pull from the Infinity Cache.
-__device__ unsigned long long* g_attn_stamps = nullptr;   // diagnostics (cic_debug_set_attn_stamps)
+#ifdef CIC_DEVTOOLS
+__device__ unsigned long long* g_attn_stamps = nullptr;   // diagnostics (cic_debug_set_attn_stamps, development build)
+#endif
 
 template <int JMAX, int NCG>   // region groups of 8: K <= 8*JMAX;  NCG 32-column groups per wave
 __global__ __launch_bounds__(1024) void attn_fwd_cols_kernel(Dual<const float> att_h_d, Dual<const float> p_att_d,
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_cols_kernel(Dual<const float> a
                                                              Dual<float> att_res_d, Dual<float> alpha_d, Dual<float> dot_d, int B0,
                                                              int K, int H, int att_div) {
     __shared__ float sp[16 * 64];
-    unsigned long long* stamps = g_attn_stamps;
+    unsigned long long* stamps = CIC_STAMP_BUF(g_attn_stamps);
     unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     if (stamps) s0 = __builtin_amdgcn_s_memrealtime();
     // rows [0,B0) are images of decode a, rows [B0, 2*B0) the same images in decode b (its own activations)
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_cols_kernel(Dual<const float> a
     }
 }
 
-extern "C" int cic_debug_set_attn_stamps(unsigned long long* buf);
+
 
 // ---------------------------------------------------------------------------------------
 // K4 cell pointwise  (Att2in2Core.forward, models/AttModel.py:515-529)
@@ -573,7 +575,7 @@ __device__ __forceinline__ ArgMax block_argmax(ArgMax a, float* shv, int* shi) {
 template <int RV>   // RV float4 per thread: rows up to RV*4096 floats
 __global__ __launch_bounds__(SNW * 64) void logsoftmax_sample_kernel(cic_sampler_args a0, cic_sampler_args a1) {
     constexpr int NT = SNW * 64;
-    unsigned long long* stamps = g_attn_stamps;          // diagnostics: [row][wave][8] phase stamps (100 MHz)
+    unsigned long long* stamps = CIC_STAMP_BUF(g_attn_stamps);          // diagnostics: [row][wave][8] phase stamps (100 MHz)
     if (stamps) stamps += ((size_t)blockIdx.x * SNW + (threadIdx.x >> 6)) * 8;
     int sidx = 0;
     auto stamp = [&]() { if (stamps && (threadIdx.x & 63) == 0 && sidx < 8) stamps[sidx] = __builtin_amdgcn_s_memrealtime(); ++sidx; };
@@ -848,6 +850,150 @@ __global__ __launch_bounds__(SNW * 64) void logsoftmax_sample_kernel(cic_sampler
     stamp();
 }
 
+// ---------------------------------------------------------------------------------------
+// Row partials of the vocabulary from logits in memory (cic.h): the stand-in of the logit walker's fused epilogue for
+// shapes that walker does not take.  One wave per (row, part); part p = columns [p*chunk, (p+1)*chunk).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ RowPart wave_merge_rowpart(RowPart rp, int mode, float inv_t) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        RowPart q;
+        q.m1 = __shfl_xor(rp.m1, o, 64); q.s1 = __shfl_xor(rp.s1, o, 64);
+        q.kbest = __shfl_xor(rp.kbest, o, 64); q.xbest = __shfl_xor(rp.xbest, o, 64);
+        q.kidx = __shfl_xor(rp.kidx, o, 64); q.s2 = __shfl_xor(rp.s2, o, 64);
+        rowpart_merge(rp, mode, inv_t, q);
+    }
+    return rp;
+}
+
+__global__ __launch_bounds__(256) void logit_partials_kernel(const float* __restrict__ logits, int M, int N, int ld,
+                                                             cic_logit_epi_rows e, int np, int chunk) {
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = wid / np, p = wid % np;
+    if (row >= M) return;
+    const int cons = e.cons_seq ? e.cons_seq[(size_t)row * e.cons_ld + e.cons_col] : -1;
+    RowPart rp;
+    rp.init();
+    const int c1 = min(N, (p + 1) * chunk);
+    for (int c = p * chunk + lane; c < c1; c += 64) {
+        float x = logits[(size_t)row * ld + c];
+        if (c == cons) x = -INFINITY;                                   // decoding constraint, AttModel.py:438-442
+        float g = 0.f;
+        if (e.noise) {
+            float u;
+            if (e.U) u = e.U[(size_t)row * e.ldu + c];
+            else {
+                const uint64_t el = e.elem0 + (uint64_t)row * (uint64_t)e.ldu + (uint64_t)c;
+                u = philox_uniform4(e.seed, el >> 2)[el & 3];
+            }
+            g = gumbel_from_u(u);
+        }
+        rowpart_add(rp, e.mode, e.inv_temp, x, g, c);
+    }
+    rp = wave_merge_rowpart(rp, e.mode, e.inv_temp);
+    if (lane == 0) {
+        const size_t plane = (size_t)e.part_rows * np;
+        float* pp = e.part + (size_t)row * np + p;
+        pp[0] = rp.m1; pp[plane] = rp.s1; pp[2 * plane] = rp.kbest; pp[3 * plane] = rp.xbest;
+        pp[4 * plane] = __int_as_float(rp.kidx); pp[5 * plane] = rp.s2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// The sampler on row partials: log-sum-exp, token choice, gathered log-prob, straight-through value, EOS bookkeeping
+// and the next step's embedding (models/AttModel.py:328-365,401-434,438-444; gumbel.py:13-30; multinomial.py:4-27) from
+// the `np` partials of a row - no pass over the vocabulary.  One wave per batch row.  a.logits holds the RAW logits
+// (read only for a token that is not the row's best key: an injected pick, a teacher target); the row's lse goes to
+// `lse` so that the backward pass can normalise them.
+// ---------------------------------------------------------------------------------------
+struct FinishArgs {
+    cic_sampler_args s;
+    const float* part;
+    int part_rows;
+    float* lse;            // [B]
+};
+__global__ __launch_bounds__(256) void sample_finish_kernel(FinishArgs a0, FinishArgs a1, int np) {
+    const int lane = threadIdx.x & 63;
+    const int rg = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool second = rg >= a0.s.B;
+    const FinishArgs fa = second ? a1 : a0;
+    const cic_sampler_args& a = fa.s;
+    const int b = second ? rg - a0.s.B : rg;
+    if (b >= a.B) return;
+    const float inv_t = 1.0f / a.temp;
+    const size_t plane = (size_t)fa.part_rows * np;
+    RowPart rp;
+    rp.init();
+    for (int p = lane; p < np; p += 64) {
+        const float* pp = fa.part + (size_t)b * np + p;
+        RowPart q;
+        q.m1 = pp[0]; q.s1 = pp[plane]; q.kbest = pp[2 * plane]; q.xbest = pp[3 * plane];
+        q.kidx = __float_as_int(pp[4 * plane]); q.s2 = pp[5 * plane];
+        rowpart_merge(rp, a.mode, inv_t, q);
+    }
+    rp = wave_merge_rowpart(rp, a.mode, inv_t);
+    const float lse = rp.m1 + logf(rp.s1);
+    if (fa.lse && lane == 0) fa.lse[b] = lse;
+    if (a.mode == CIC_SAMPLE_NONE) return;
+
+    const bool gumbel_mode = a.mode == CIC_SAMPLE_GUMBEL_ST;
+    const bool ss_on = a.mode == CIC_SAMPLE_TEACHER && a.ss_u && a.ss_prob > 0.f;
+    int it = rp.kidx;
+    int it_feed = -1;                                   // teacher mode: token fed to the next step
+    if (a.mode == CIC_SAMPLE_TEACHER) {
+        const int target = (int)a.pick[b];
+        const int drawn = a.ss_pick ? (int)a.ss_pick[b] : rp.kidx;
+        it_feed = (ss_on && a.ss_u[b] < a.ss_prob) ? drawn : target;   // AttModel.py:119-128
+        it = target;                                     // the loss gathers log p(target)
+    } else if (a.pick && a.mode != CIC_SAMPLE_GREEDY && !gumbel_mode) {
+        it = (int)a.pick[b];
+    }
+    float x_it = rp.xbest;
+    if (it != rp.kidx) {
+        const int cons = (a.decoding_constraint && a.step >= 2) ? a.seq[(size_t)b * a.seq_ld + (a.step - 2)] : -1;
+        x_it = it == cons ? -INFINITY : a.logits[(size_t)b * a.ld + it];
+    }
+    const float slp = x_it - lse;
+    float v = 1.0f;
+    if (gumbel_mode) {
+        const float y = 1.0f / rp.s2;                   // softmax(k)[arg max k] = exp(0) / sum exp(k - kbest), gumbel.py:13-15
+        v = (1.0f - y) + y;                              // (y_hard - y).detach() + y at the arg-max entry, gumbel.py:28
+    } else if (a.mode == CIC_SAMPLE_MULTINOMIAL_ST) {
+        const float y = __expf((x_it - rp.m1) * inv_t) / rp.s2;         // softmax(logp / tau)[it], multinomial.py:10-15
+        v = (1.0f - y) + y;
+    }
+    // next step's input: xt = dropout(relu(embed(it))) (AttModel.py:74-76,399), un-masked `it`
+    if (a.emb_x) {
+        const int tok = it_feed >= 0 ? it_feed : it;
+        const int E4 = a.emb_dim >> 2;
+        for (int j = lane; j < E4; j += 64) {
+            f32x4 ev = reinterpret_cast<const f32x4*>(a.emb_w + (size_t)tok * a.emb_dim)[j];
+            uint32_t kp = 0x01010101u;
+            if (a.emb_keep) kp = *reinterpret_cast<const uint32_t*>(a.emb_keep + (size_t)b * a.emb_dim + 4 * j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float kf = (float)((kp >> (8 * e)) & 0xffu);
+                const float r = a.emb_plain ? ev[e] : fmaxf(ev[e], 0.f);
+                ev[e] = a.emb_keep ? r * (kf * a.emb_scale) : r;
+            }
+            reinterpret_cast<f32x4*>(a.emb_x + (size_t)b * a.emb_dim)[j] = ev;
+        }
+    }
+    // EOS bookkeeping (AttModel.py:401-434)
+    if (lane == 0) {
+        const int t = a.step;
+        int unf = (it > 0) ? 1 : 0;
+        if (t > 1) unf = unf & a.unfinished[b];
+        a.unfinished[b] = unf;
+        a.it_next[b] = it_feed >= 0 ? it_feed : it;         // un-masked: embed(it) precedes the masking (:399)
+        a.seq[(size_t)b * a.seq_ld + (t - 1)] = unf ? it : 0;   // it * unfinished (:409)
+        a.slp[(size_t)b * a.seq_ld + (t - 1)] = slp;
+        if (a.stv) a.stv[(size_t)b * a.seq_ld + (t - 1)] = unf ? v : 1.0f;   // finished rows -> exact EOS one-hot (:419-420)
+        if (unf) atomicOr(a.any_unfinished + t, 1);
+    }
+}
+
 // L = number of appended columns: the reference breaks at the first t >= 1 whose unfinished
 // sum is 0 (AttModel.py:407-408); otherwise seq_length.
 __global__ void finalize_len_kernel(const int* __restrict__ any_unf, int T, int* __restrict__ L) {
@@ -865,10 +1011,12 @@ __global__ void finalize_len_kernel(const int* __restrict__ any_unf, int T, int*
 }  // namespace
 
 // ---- launchers ---------------------------------------------------------------------------
+#ifdef CIC_DEVTOOLS
 extern "C" int cic_debug_set_attn_stamps(unsigned long long* buf) {
     CIC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), &buf, sizeof(buf)));
     return 0;
 }
+#endif
 
 extern "C" int cic_attn_fwd(const float* att_h, const float* p_att, const float* att, const float* w_alpha,
                             const float* b_alpha, const float* masks, float* att_res, float* alpha,
@@ -994,11 +1142,13 @@ int cic_cell_fwd2(Dual<const float> pre, Dual<const float> c_prev, Dual<const ui
     return 0;
 }
 
-int g_a2c_cell_fused = 1;
+CIC_SWITCH(g_a2c_cell_fused, 1);
+#ifdef CIC_DEVTOOLS
 extern "C" int cic_debug_a2c_cell_fused(int on) {
     g_a2c_cell_fused = on;
     return 0;
 }
+#endif
 bool cic_a2c_cell_fused_ok(int H) { return g_a2c_cell_fused && H == 512; }
 
 int cic_a2c_cell_fused(Dual<const float> att_res, const float* Wa, const float* ba, Dual<float> pre, Dual<const float> c_prev,
@@ -1060,7 +1210,7 @@ int cic_soft_mask(const float* soft_raw, const int32_t* seq, const int32_t* L, f
     return 0;
 }
 
-static int check_sampler_args(const cic_sampler_args* a);
+static int check_sampler_args(const cic_sampler_args* a, bool noise_in_partials = false);
 
 extern "C" int cic_logsoftmax_sample(const cic_sampler_args* a, cic_stream_t s) {
     return cic_logsoftmax_sample2(a, nullptr, cic_s(s));
@@ -1086,7 +1236,36 @@ int cic_logsoftmax_sample2(const cic_sampler_args* a, const cic_sampler_args* b,
     return 0;
 }
 
-static int check_sampler_args(const cic_sampler_args* a) {
+extern "C" int cic_logit_partials(const float* logits, int M, int N, int ld, const cic_logit_epi_rows* e, int nparts,
+                                  cic_stream_t s) {
+    CIC_REQUIRE(logits && e && e->part && M > 0 && N > 0 && ld >= N && nparts > 0 && (int64_t)M * nparts <= CIC_PART_MAX_ENTRIES);
+    CIC_REQUIRE(e->part_rows >= M && (!e->noise || e->U || e->philox));
+    const int chunk = cic_cdiv(N, nparts);
+    hipLaunchKernelGGL(logit_partials_kernel, dim3(cic_cdiv((int64_t)M * nparts, 4)), dim3(256), 0, cic_s(s), logits, M, N, ld, *e,
+                       nparts, chunk);
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+
+// the sampler of one decode (b == NULL) or of a pair on the row partials of this step's logits
+int cic_sample_finish2(const cic_sampler_args* a, const float* part_a, int part_rows_a, float* lse_a,
+                       const cic_sampler_args* b, const float* part_b, int part_rows_b, float* lse_b, int np, hipStream_t st) {
+    if (int rc = check_sampler_args(a, true)) return rc;
+    if (b) { if (int rc = check_sampler_args(b, true)) return rc; }
+    CIC_REQUIRE(part_a && np > 0 && (!b || part_b));
+    auto ok = [](const cic_sampler_args* x) {
+        return x->mode != CIC_SAMPLE_GUMBEL_PS && x->mode != CIC_SAMPLE_MULTINOMIAL_PS;
+    };
+    CIC_REQUIRE(ok(a) && (!b || ok(b)));
+    FinishArgs fa{*a, part_a, part_rows_a, lse_a};
+    FinishArgs fb = b ? FinishArgs{*b, part_b, part_rows_b, lse_b} : fa;
+    const int rows = a->B + (b ? b->B : 0);
+    hipLaunchKernelGGL(sample_finish_kernel, dim3(cic_cdiv(rows, 4)), dim3(256), 0, st, fa, fb, np);
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+
+static int check_sampler_args(const cic_sampler_args* a, bool noise_in_partials) {
     CIC_REQUIRE(a && a->logits && a->B > 0 && a->V1 > 0 && a->ld >= a->V1);
     CIC_REQUIRE(!a->emb_x || (a->emb_w && a->mode != CIC_SAMPLE_NONE && a->emb_dim > 0 && (a->emb_dim & 3) == 0 && a->emb_dim <= 4096));
     if (a->mode != CIC_SAMPLE_NONE) {
@@ -1099,7 +1278,7 @@ static int check_sampler_args(const cic_sampler_args* a) {
         CIC_REQUIRE(a->mode != CIC_SAMPLE_TEACHER || a->pick);
         const bool ps = a->mode == CIC_SAMPLE_GUMBEL_PS || a->mode == CIC_SAMPLE_MULTINOMIAL_PS;
         CIC_REQUIRE(!ps || (a->soft && a->ld_soft >= a->V1));
-        CIC_REQUIRE(!needs_u || (a->U && a->ldu >= a->V1));
+        CIC_REQUIRE(!needs_u || noise_in_partials || (a->U && a->ldu >= a->V1));
     }
     return 0;
 }

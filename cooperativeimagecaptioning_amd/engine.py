@@ -107,7 +107,7 @@ def speaker_decode_fwd_pair(dims, params, a, b):
 def speaker_decode_io(dims, params, att_pre, mode, temp=1.0, att_masks=None, att_keep=None, x_keep=None,
                       out_keep=None, U=None, pick=None, decoding_constraint=0, want_stv=False, ws=None,
                       first_token=None, out=None, ss_u=None, ss_prob=0.0, ss_pick=None, ps_u=None, ps_prob=0.0,
-                      fc_x0=None):
+                      fc_x0=None, u_stream=None, timer=None):
     """-> dict(seq i32[B,T], slp f32[B,T], stv f32[B,T]|None, L i32[1], ws); partial-sampling modes add
     soft f32[T,B,V+1] (the caption rows handed to the listener) and the saved soft_raw / xpre."""
     dev = att_pre.device if att_pre is not None else fc_x0.device
@@ -115,7 +115,7 @@ def speaker_decode_io(dims, params, att_pre, mode, temp=1.0, att_masks=None, att
     nbytes = lib.cic_speaker_decode_ws_bytes(C.byref(dims))
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    if out is None:   # callers that replay HIP graphs pass the same output buffers every step
+    if out is None:
         out = dict(seq=torch.zeros(B, T, dtype=torch.int32, device=dev), slp=torch.zeros(B, T, device=dev),
                    stv=torch.ones(B, T, device=dev) if want_stv else None,
                    L=torch.zeros(1, dtype=torch.int32, device=dev))
@@ -134,6 +134,11 @@ def speaker_decode_io(dims, params, att_pre, mode, temp=1.0, att_masks=None, att
         io.fc_mode, io.x0 = 1, _p(fc_x0)
     io.att_keep, io.x_keep, io.out_keep = _p(att_keep), _p(x_keep), _p(out_keep)
     io.U, io.pick, io.first_token = _p(U), _p(pick), _p(first_token)
+    if u_stream is not None:      # (seed, offset): the kernels draw the Gumbel uniforms themselves (no [T+1,B,V+1] slab)
+        assert U is None
+        io.u_philox, io.u_seed, io.u_offset = 1, int(u_stream[0]), int(u_stream[1])
+    if timer is not None:
+        io.timer = timer.handle
     io.ss_u, io.ss_prob, io.ss_pick = _p(ss_u), float(ss_prob), _p(ss_pick)
     io.seq, io.slp, io.stv, io.L = _p(out['seq']), _p(out['slp']), _p(out['stv']), _p(out['L'])
     out['io'] = io
@@ -308,45 +313,36 @@ def clamp_adam(p, g, m, v, lr, step, grad_clip=0.1, betas=(0.9, 0.999), eps=1e-8
                              grad_clip, int(step), grad_scale, stream()), 'cic_clamp_adam')
 
 
-PROF_IDS = {'attn_fwd': 0, 'logit_gemm': 1, 'attn_bwd': 2, 'sampler': 3}
-lib.cic_prof_enable.argtypes = [C.c_int]
-lib.cic_prof_collect.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+TIMED_IDS = {'attn_fwd': 0, 'logit_gemm': 1, 'attn_bwd': 2, 'sampler': 3}
+lib.cic_timer_create.restype = C.c_void_p
+lib.cic_timer_destroy.argtypes = [C.c_void_p]
+lib.cic_timer_destroy.restype = None
+lib.cic_timer_reset.argtypes = [C.c_void_p]
+lib.cic_timer_collect.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
 
 
-def prof_enable(on):
-    check(lib.cic_prof_enable(int(bool(on))), 'cic_prof_enable')
+class KernelTimer:
+    """A caller-owned cic_timer: decodes that are handed it (speaker_decode_io(..., timer=...)) bracket the launches of
+    their attention / logit / sampler kernels with HIP events on their own stream, forward and backward."""
 
+    def __init__(self):
+        self.handle = lib.cic_timer_create()
+        if not self.handle:
+            raise _lib.CicError('cic_timer_create failed')
 
-def prof_reset():
-    check(lib.cic_prof_reset(), 'cic_prof_reset')
+    def reset(self):
+        check(lib.cic_timer_reset(self.handle), 'cic_timer_reset')
 
+    def collect(self):
+        """-> {kernel: dict(ms=total elapsed, n=launches)} since reset(); synchronises the recorded events."""
+        out = {}
+        for name, i in TIMED_IDS.items():
+            ms, n = C.c_double(0.0), C.c_int(0)
+            check(lib.cic_timer_collect(self.handle, i, C.byref(ms), C.byref(n)), 'cic_timer_collect')
+            out[name] = dict(ms=ms.value, n=n.value)
+        return out
 
-def prof_collect():
-    """-> {kernel: dict(ms=total elapsed, n=launches)} for the launches bracketed since prof_reset()."""
-    out = {}
-    for name, i in PROF_IDS.items():
-        ms, n = C.c_double(0.0), C.c_int(0)
-        check(lib.cic_prof_collect(i, C.byref(ms), C.byref(n)), 'cic_prof_collect')
-        out[name] = dict(ms=ms.value, n=n.value)
-    return out
-
-
-lib.cic_graph_enable.argtypes = [C.c_int]
-lib.cic_graph_stats.argtypes = [C.POINTER(C.c_int64)]
-
-
-def graph_enable(on):
-    """Capture/replay the sequence engines as HIP graphs (needs a non-default stream and stable buffers)."""
-    from . import bufcache
-    bufcache.STABLE_ADDRESSES = bool(on)
-    check(lib.cic_graph_enable(int(bool(on))), 'cic_graph_enable')
-
-
-def graph_clear():
-    check(lib.cic_graph_clear(), 'cic_graph_clear')
-
-
-def graph_stats():
-    a = (C.c_int64 * 3)()
-    check(lib.cic_graph_stats(a), 'cic_graph_stats')
-    return dict(captures=a[0], replays=a[1], fallbacks=a[2])
+    def __del__(self):
+        h, self.handle = getattr(self, 'handle', None), None
+        if h:
+            lib.cic_timer_destroy(h)

@@ -96,6 +96,7 @@ class AttModel(nn.Module):
         self.noise = NoiseSource()
         self._ws = {}
         self._buf = BufCache()
+        self.timer = None            # engine.KernelTimer: in-step kernel timing of this model's decodes (bench.py)
 
     # ---- engine plumbing -----------------------------------------------------------------
     def flat(self):
@@ -169,7 +170,8 @@ class AttModel(nn.Module):
         nz = self.noise.decode_noise(tag, B, K, self.rnn_size, self.input_encoding_size, self.vocab_size + 1, T, p,
                                      need_u=(mode in ('gumbel', 'gumbel_ps')) or
                                      (mode in ('multinomial', 'multinomial_st', 'multinomial_ps') and pick is None) or ss,
-                                     device=att_raw.device, need_ss=ss, need_ps=ps and ps_prob > 0.0)
+                                     device=att_raw.device, need_ss=ss, need_ps=ps and ps_prob > 0.0,
+                                     u_in_kernel=not ps)
         ss_pick = None
         if mode == 'teacher':
             ss_pick = nz.get('pick') if ss else None     # recorded scheduled-sampling draws (tests)
@@ -202,7 +204,7 @@ class AttModel(nn.Module):
                                        want_stv=want_stv, ws=self._ws.get(ws_key), first_token=first_token, out=out,
                                        ss_u=nz.get('ss_u') if ss else None, ss_prob=ss_prob if ss else 0.0,
                                        ss_pick=ss_pick, ps_u=nz.get('ps_u') if ps else None,
-                                       ps_prob=ps_prob if ps else 0.0)
+                                       ps_prob=ps_prob if ps else 0.0, u_stream=nz.get('u_stream'), timer=self.timer)
         self._ws[ws_key] = fwd['ws']
         return dims, params, fwd, (mode, att_raw, grad, ws_key)
 
@@ -210,7 +212,7 @@ class AttModel(nn.Module):
         """logit_grads_ready: called between the logit layer's backward and the BPTT loop (data-parallel runs start the
         all-reduce of the logit bucket there; only when this decode is the last one writing the logit gradient)."""
         fl = self.flat()
-        if dslp is not None:   # stable address for the HIP-graph key
+        if dslp is not None:
             dslp = self._buf.stage(('dslp_in', res.dims.T), dslp.contiguous(), torch.float32)
         key = ('bwd', res.dims.B, res.dims.K, res.dims.T)
         kw = dict(d_onehot=d_onehot, dslp=dslp)

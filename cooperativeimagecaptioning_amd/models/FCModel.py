@@ -110,16 +110,15 @@ class FCModel(nn.Module):
         elif p > 0.0:
             keep = self.noise._get((tag, 'out_keep'), (T + 2, B, self.rnn_size), torch.uint8, dev)
             ops.dropout_keep_(keep, p, self.noise.seed, self.noise._next_offset())
-        U = None
-        if mode == 'multinomial' and pick is None:
-            U = self.noise._get((tag, 'gumbel_u'), (T + 1, B, self.vocab_size + 1), torch.float32, dev)
-            ops.uniform_(U, self.noise.seed, self.noise._next_offset())
+        u_stream = None
+        if mode == 'multinomial' and pick is None:      # Gumbel-max draws from a Philox stream, inside the kernels
+            u_stream = (self.noise.seed, self.noise._next_offset())
         ws_key = (tag, B, T, grad)
         out = dict(seq=self._buf.get((ws_key, 'seq'), (B, T), torch.int32, dev, fill=0),
                    slp=self._buf.get((ws_key, 'slp'), (B, T), torch.float32, dev, fill=0), stv=None,
                    L=self._buf.get((ws_key, 'L'), (1,), torch.int32, dev, fill=0))
         from .AttModel import MODES
-        io = engine.speaker_decode_io(dims, params, None, MODES[mode], temp, out_keep=keep, U=U, pick=pick,
+        io = engine.speaker_decode_io(dims, params, None, MODES[mode], temp, out_keep=keep, u_stream=u_stream, pick=pick,
                                       decoding_constraint=decoding_constraint, ws=self._ws.get(ws_key),
                                       first_token=first_token, out=out, fc_x0=x0)
         self._ws[ws_key] = io['ws']

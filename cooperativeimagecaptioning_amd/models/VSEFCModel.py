@@ -134,7 +134,7 @@ class VSEFCModel(nn.Module):
 
     def run_backward(self, res, g_scalar=None, g_rows=None, param_grads=True, d_onehot=None):
         fl = self.flat()
-        if g_scalar is not None:   # stable addresses for the HIP-graph key
+        if g_scalar is not None:
             g_scalar = self._buf.stage('g_scalar', g_scalar.reshape(1), torch.float32)
         if g_rows is not None:
             g_rows = self._buf.stage('g_rows', g_rows.contiguous(), torch.float32)

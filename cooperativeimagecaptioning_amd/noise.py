@@ -16,7 +16,7 @@ class NoiseSource:
         self.seed = int(seed)
         self.counter = 0          # Philox offset in units of 2^32 calls: one fresh sub-stream per tensor
         self.override = None      # {tag: {att_keep,x_keep,out_keep,gumbel_u,pick}} numpy/torch arrays
-        self._buf = {}            # persistent device buffers (stable addresses for HIP-graph replay)
+        self._buf = {}            # persistent device buffers
 
     def manual_seed(self, seed):
         self.seed, self.counter = int(seed), 0
@@ -32,7 +32,10 @@ class NoiseSource:
             t = self._buf[k] = torch.empty(shape, dtype=dtype, device=device)
         return t
 
-    def decode_noise(self, tag, B, K, H, E, V1, T, p, need_u, device, need_ss=False, need_ps=False):
+    def decode_noise(self, tag, B, K, H, E, V1, T, p, need_u, device, need_ss=False, need_ps=False, u_in_kernel=False):
+        """u_in_kernel: the [T+1,B,V1] Gumbel uniforms are not materialised; out['u_stream'] = (seed, offset) names the
+        Philox stream the decode kernels draw them from themselves - element for element the numbers ops.uniform_ would
+        have written with that (seed, offset)."""
         if self.override is not None:
             ov = self.override.get(tag)
             if ov is None:
@@ -61,7 +64,9 @@ class NoiseSource:
                 t = self._get((tag, key), shape, torch.uint8, device)
                 ops.dropout_keep_(t, p, self.seed, self._next_offset())
                 out[key] = t
-        if need_u:
+        if need_u and u_in_kernel:
+            out['u_stream'] = (self.seed, self._next_offset())
+        elif need_u:
             u = self._get((tag, 'gumbel_u'), (T + 1, B, V1), torch.float32, device)
             ops.uniform_(u, self.seed, self._next_offset())
             out['gumbel_u'] = u

@@ -34,46 +34,17 @@ typedef void* cic_stream_t; /* hipStream_t */
 int cic_version(void);
 const char* cic_last_error(void);
 
-/* ---- in-situ kernel timing (HIP events recorded by the engines around selected launches) ---- */
-enum { CIC_PROF_ATTN_FWD = 0, CIC_PROF_LOGIT_GEMM = 1, CIC_PROF_ATTN_BWD = 2, CIC_PROF_SAMPLER = 3, CIC_PROF_COUNT = 4 };
-/* While enabled, every launch of the listed kernels inside the sequence engines is bracketed by a
- * pair of HIP events on the engine's stream.  cic_prof_collect synchronises those events and
- * returns the summed elapsed time and launch count of one kernel id since the last reset. */
-int cic_prof_enable(int on);
-int cic_prof_reset(void);
-int cic_prof_collect(int id, double* total_ms, int* launches);
-
-/* ---- HIP graphs -----------------------------------------------------------------------------
- * When enabled, each sequence engine call (decode fwd/bwd, listener fwd/bwd) is stream-captured the first
- * time it is seen with a given set of arguments (every pointer, size and scalar is part of the key) and
- * replayed with hipGraphLaunch afterwards: ~150 launches become one.  Callers must therefore keep the
- * buffers they pass at stable addresses and must not use the legacy default stream (capture is refused
- * there; the engine then falls back to direct launches).  cic_graph_stats: [captures, replays, fallbacks]. */
-int cic_graph_enable(int on);
-int cic_graph_clear(void);
-int cic_graph_stats(int64_t* out3);
-
-/* diagnostics: shader clock in MHz (out2[0]) measured over `spin` dependent FMAs; an empty launch */
-int cic_debug_clock_mhz(float* out2, int spin, cic_stream_t s);
-int cic_debug_empty(int grid, int block, cic_stream_t s);
-/* diagnostics: per-workgroup phase stamps of the register-streaming GEMM (NULL = off) */
-int cic_debug_set_stamps(unsigned long long* buf);
-int cic_debug_set_attn_stamps(unsigned long long* buf);
-/* diagnostics: per-workgroup phase stamps of the per-timestep GEMMs (rega / LDS-staged walker) and of the row kernels
- * (attention, sampler); NULL = off */
-/* diagnostics, A/B timing of the GEMM dispatch: bit 0 clear = K-sliced tail tiles and K split over workgroups off (fixed
- * summation order); bits 8..15: 1 / 2 force 128x128 / 64x64 tiles; set bits turn a kernel family OFF: 16 strip walkers,
- * 21 16-wide walkers, 22 LDS-staged logit walker, 23 row-block split of 129..256-row products, 24 two-strip dX kernel;
- * bits 25..26: K parts per row tile of the logit walker (0 = two, 1 = its 4-wave form with one, 2 = four) */
-int cic_debug_gemm_tail_split(int on);
-/* diagnostics: 0 = the decode engines launch the attention query product on its own (A/B timing of the column split) */
-int cic_debug_gates_att_fused(int on);
-/* diagnostics: 1 runs the logit weight-gradient product on a side stream beside the BPTT loop (default 0: measured slower) */
-int cic_debug_side_stream(int on);
-/* diagnostics: 0 runs every listener GRU step as a GEMM launch + a cell launch instead of the fused step kernel */
-int cic_debug_gru_fused(int on);
-/* diagnostics: 0 runs the speaker's a2c product and cell as two launches instead of the fused kernel */
-int cic_debug_a2c_cell_fused(int on);
+/* ---- in-situ kernel timing: a caller-owned object, no library state -------------------------------------
+ * A decode whose cic_decode_io.timer is set brackets every launch of the kernels listed below with a pair of HIP
+ * events on its own stream (forward and backward); the events live in the cic_timer.  cic_timer_collect
+ * synchronises them and returns the summed elapsed time and the launch count of one kernel id since the last
+ * reset.  One timer per stream / host thread; NULL timer = nothing is recorded. */
+typedef struct cic_timer cic_timer;
+enum { CIC_TIMED_ATTN_FWD = 0, CIC_TIMED_LOGIT_GEMM = 1, CIC_TIMED_ATTN_BWD = 2, CIC_TIMED_SAMPLER = 3, CIC_TIMED_COUNT = 4 };
+cic_timer* cic_timer_create(void);
+void cic_timer_destroy(cic_timer* t);
+int cic_timer_reset(cic_timer* t);
+int cic_timer_collect(cic_timer* t, int id, double* total_ms, int* launches);
 
 /* ---- RNG (replaces torch.rand / nn.Dropout's bernoulli_ draws) ---------------------- */
 /* Philox4x32-10 counter RNG.  u[i] = (r >> 8) * 2^-24 in [0,1), as torch.rand does
@@ -129,11 +100,45 @@ typedef struct {
     const float* B2_tail; int ldb2_tail;
     const float* bias_tail;
     float* C_tail; float* C_tail_b; int ldc_tail;
+    /* Fused vocabulary epilogue (optional; the logit product of a decode step, AttModel.py:444 + :328-365): while a
+     * workgroup still holds the logits it made, it reduces them to ROW PARTIALS (below) so that the log-softmax and the
+     * sampler need no second pass over the [M, N] logits.  C still receives the raw logits (the backward pass reads
+     * them).  Only where cic_gemm_logit_parts() > 0; else leave NULL and run cic_logit_partials on C. */
+    const struct cic_logit_epilogue* epi;
 } cic_gemm_args;
+/* Row partials of the vocabulary: the columns of a row are dealt to `nparts` parts; a part reduces its columns
+ * (after the decoding constraint, AttModel.py:438-442: one column per row set to -inf) to six numbers, stored as
+ * planes  part[plane][row][p],  plane stride = part_rows * nparts floats:
+ *   0  m1     max x                         1  s1   sum exp(x - m1)          (log-softmax: lse = M + log S)
+ *   2  kbest  best sampling key             3  xbest the logit at that column  4  kidx  its column (int32 bits)
+ *   5  s2     GUMBEL_ST: sum exp(k - kbest) (the straight-through value y = softmax(k)[it], gumbel.py:28);
+ *             multinomial / teacher modes: sum exp((x - m1) * inv_temp)       (y = softmax(logp/tau), multinomial.py)
+ * sampling key k:  GREEDY x;  GUMBEL_ST (x + g) * inv_temp;  MULTINOMIAL, MULTINOMIAL_ST, TEACHER x * inv_temp + g
+ * (g = 0 without noise), g = -log(-log(u + 1e-20) + 1e-20) in f32 (gumbel.py:6-11).  Ties: lowest column.
+ * Uniform u of (row r, column c): U[r*ldu + c], or - U == NULL and philox != 0 - element elem0 + r*ldu + c of the
+ * Philox stream of cic_uniform_f32(seed, offset 0) (counter = element / 4, lane = element % 4). */
+typedef struct {
+    int mode;                  /* CIC_SAMPLE_*; CIC_SAMPLE_NONE: planes 0-1 only */
+    float inv_temp;
+    int noise;                 /* != 0: the keys carry Gumbel noise */
+    const float* U; int ldu;
+    int philox; uint64_t seed; uint64_t elem0;
+    const int32_t* cons_seq; int cons_ld; int cons_col;   /* constrained column of row r: cons_seq[r*cons_ld + cons_col]; NULL: none */
+    float* part; int part_rows;
+} cic_logit_epi_rows;
+typedef struct cic_logit_epilogue {
+    cic_logit_epi_rows blk[2];   /* rows [0, rows_blk) and [rows_blk, M) of the product (blk[0] alone without row blocks) */
+} cic_logit_epilogue;
+enum { CIC_PART_PLANES = 6, CIC_PART_MAX_ENTRIES = 16384 };   /* rows * nparts never exceeds 16384 per row block */
 int cic_gemm_f32(const cic_gemm_args* a, cic_stream_t s);
+/* number of parts per row the fused epilogue of cic_gemm_f32 writes for these arguments; 0: not fused for them */
+int cic_gemm_logit_parts(const cic_gemm_args* a);
+/* the same partials from logits already in memory (any shape): rows of `logits` [M, ld], nparts parts of contiguous
+ * columns */
+int cic_logit_partials(const float* logits, int M, int N, int ld, const cic_logit_epi_rows* e, int nparts, cic_stream_t s);
 /* 1 if cic_gemm_f32 implements the column split for these arguments, 0 if not */
 int cic_gemm_split_ok(const cic_gemm_args* a);
-/* measurement helper: average duration (us) of `iters` back-to-back launches of the product, HIP events on s */
+/* measurement helper (stateless): average duration (us) of `iters` back-to-back launches of the product, HIP events on s */
 int cic_gemm_f32_timed(const cic_gemm_args* a, int iters, double* avg_us, cic_stream_t s);
 /* out[n] (+)= sum_m X[m*ldx + n]   — bias gradients. */
 int cic_colsum_f32(const float* X, int M, int N, int ldx, float* out, int accumulate,
@@ -283,6 +288,12 @@ typedef struct {
     float* slp;               /* out [B,T]  sampled log-probs        (AttModel.py:413,423) */
     float* stv;               /* out [B,T]  straight-through values, or NULL */
     int32_t* L;               /* out [1]    number of columns the reference would return */
+    /* U == NULL and u_philox != 0: the [T+1,B,V+1] uniforms are not materialised; element i of that slab is element i
+     * of the stream cic_uniform_f32(out, n, u_seed, u_offset) would write (counter u_offset + i/4, lane i%4), drawn
+     * inside the kernels that consume it (forward and backward).  Not for the partial-sampling modes. */
+    int u_philox;
+    uint64_t u_seed, u_offset;
+    cic_timer* timer;         /* optional in-situ timing of this decode's kernels (forward and backward), or NULL */
 } cic_decode_io;
 
 /* Bytes of workspace a decode needs; the same workspace must be handed, untouched, to

@@ -1,0 +1,37 @@
+/* cic_dev.h - development build of the library ONLY (libcic_hip_dev.so = the same sources compiled with
+ * -DCIC_DEVTOOLS).  The product library libcic_hip.so exports none of these and holds no mutable global state: its
+ * dispatch choices are compile-time constants and its kernels carry no stamp code.  tools/ load the development
+ * build for A/B timing of kernel variants and for in-kernel phase stamps (tools/_devlib.py). */
+#ifndef CIC_DEV_H
+#define CIC_DEV_H
+#include "cic.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* diagnostics: shader clock in MHz (out2[0]) measured over `spin` dependent FMAs; an empty launch */
+int cic_debug_clock_mhz(float* out2, int spin, cic_stream_t s);
+int cic_debug_empty(int grid, int block, cic_stream_t s);
+/* diagnostics: per-workgroup phase stamps of the register-streaming GEMM (NULL = off) */
+int cic_debug_set_stamps(unsigned long long* buf);
+int cic_debug_set_attn_stamps(unsigned long long* buf);
+/* diagnostics: per-workgroup phase stamps of the per-timestep GEMMs (rega / LDS-staged walker) and of the row kernels
+ * (attention, sampler); NULL = off */
+/* diagnostics, A/B timing of the GEMM dispatch: bit 0 clear = K-sliced tail tiles and K split over workgroups off (fixed
+ * summation order); bits 8..15: 1 / 2 force 128x128 / 64x64 tiles; set bits turn a kernel family OFF: 16 strip walkers,
+ * 21 16-wide walkers, 22 LDS-staged logit walker, 23 row-block split of 129..256-row products, 24 two-strip dX kernel;
+ * bits 25..26: K parts per row tile of the logit walker (0 = two, 1 = its 4-wave form with one, 2 = four);
+ * bit 27: the logit walker without its fused vocabulary epilogue (the row partials then come from cic_logit_partials) */
+int cic_debug_gemm_tail_split(int on);
+/* diagnostics: 0 = the decode engines launch the attention query product on its own (A/B timing of the column split) */
+int cic_debug_gates_att_fused(int on);
+/* diagnostics: 0 runs every listener GRU step as a GEMM launch + a cell launch instead of the fused step kernel */
+int cic_debug_gru_fused(int on);
+/* diagnostics: 0 runs the speaker's a2c product and cell as two launches instead of the fused kernel */
+int cic_debug_a2c_cell_fused(int on);
+
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CIC_DEV_H */

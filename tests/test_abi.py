@@ -48,3 +48,18 @@ def test_ciderd_refuses_a_vocabulary_that_does_not_fit_its_ngram_keys():
         a.vocab_size = bad
         assert fn(C.byref(a), C.addressof(dummy), 64, None) != 0
         assert b'vocab_size' in _lib.lib.cic_last_error()
+
+
+def test_product_library_has_no_debug_switches_or_global_state():
+    """'no global state, re-entrant per stream'.  The dispatch switches, stamp buffers, HIP-graph cache and
+    profiler registry of the development build (include/cic_dev.h, -DCIC_DEVTOOLS) are not in libcic_hip.so: no
+    cic_debug_* / cic_graph_* / cic_prof_* entry point, and no writable g_* data symbol."""
+    import subprocess
+    from cooperativeimagecaptioning_amd import _lib
+    assert _lib._LIB_PATH.endswith('libcic_hip.so')
+    for name in ('cic_debug_gemm_tail_split', 'cic_debug_set_stamps', 'cic_debug_side_stream', 'cic_graph_enable',
+                 'cic_prof_enable'):
+        assert not hasattr(_lib.lib, name), name
+    out = subprocess.run(['nm', '-D', '--defined-only', _lib._LIB_PATH], capture_output=True, text=True).stdout
+    writable = [ln for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in 'BbDd' and 'g_' in ln.split()[2]]
+    assert not writable, writable

@@ -96,8 +96,11 @@ def test_decode_matches_reference(name, mode):
                                     (6, dict(K=9, D=32, H=64, V=199, T=16))])
 def test_paired_decodes_equal_sequential_decodes(B, dims):
     """cic_speaker_decode_fwd_pair (sampled + greedy decode in lock step, one launch per kernel over 2B rows) leaves
-    exactly the bytes two sequential cic_speaker_decode_fwd calls leave: outputs AND the whole saved-activation
-    workspaces.  B = 6 takes the documented fallback (row blocks need B % 32 == 0)."""
+    exactly the bytes two sequential cic_speaker_decode_fwd calls leave: token ids AND every saved activation (states,
+    attention weights, gate pre-activations, raw logits).  The log-sum-exp of a vocabulary row is reduced from row
+    partials whose number follows the launch geometry (2B rows give other column parts than B rows), so the gathered
+    log-probs / straight-through values may differ in the last bit: compared to 2e-6.  B = 6 takes the documented
+    fallback (row blocks need B % 32 == 0)."""
     from cooperativeimagecaptioning_amd import engine, _lib
     K, D, H, V, T = dims['K'], dims['D'], dims['H'], dims['V'], dims['T']
     g = torch.Generator().manual_seed(100 + B)
@@ -135,7 +138,73 @@ def test_paired_decodes_equal_sequential_decodes(B, dims):
     engine.speaker_decode_fwd_pair(d, params, a1, b1)
     torch.cuda.synchronize()
     assert 0 < int(a0['L']) <= T and 0 < int(b0['L']) <= T
+    # the workspace ends with the row partials of the last step and the [T,B] log-sum-exp rows (engine_util.h: SpkWs)
+    tail = 6 * 16384 * 4 + (T * B * 4 + 255) // 256 * 256
     for x, y in ((a0, a1), (b0, b1)):
-        for k in ('seq', 'slp', 'stv', 'L', 'ws'):
+        for k in ('seq', 'L'):
+            assert torch.equal(x[k], y[k]), k
+        for k in ('slp', 'stv'):
             if x[k] is not None:
-                assert torch.equal(x[k], y[k]), k
+                np.testing.assert_allclose(x[k].cpu().numpy(), y[k].cpu().numpy(), rtol=0, atol=2e-6, err_msg=k)
+        assert torch.equal(x['ws'][:-tail], y['ws'][:-tail]), 'saved activations'
+        lse_x = x['ws'][-(tail - 6 * 16384 * 4):][:T * B * 4].view(torch.float32)
+        lse_y = y['ws'][-(tail - 6 * 16384 * 4):][:T * B * 4].view(torch.float32)
+        np.testing.assert_allclose(lse_x.cpu().numpy(), lse_y.cpu().numpy(), rtol=0, atol=4e-6)
+
+
+@pytest.mark.parametrize('B,dims', [(32, dict(K=36, D=64, H=512, V=9487, T=16)), (6, dict(K=9, D=32, H=64, V=199, T=16))])
+@pytest.mark.parametrize('mode', ['gumbel_st', 'multinomial'])
+def test_in_kernel_philox_noise_equals_the_materialised_uniform_stream(B, dims, mode):
+    """The decode kernels draw their Gumbel uniforms from (seed, offset) themselves (io.u_philox): the same numbers, element
+    for element, that cic_uniform_f32 writes into a [T+1,B,V+1] slab with that (seed, offset) — so a decode on the
+    in-kernel stream equals, bit for bit, the decode that is handed the slab, forward (tokens, log-probs, saved
+    activations) and backward (gradients; float atomics: 1e-5).  Both the logit walker's fused epilogue (H = 512,
+    V = 9487) and the stand-alone partial kernel (small widths) are covered."""
+    from cooperativeimagecaptioning_amd import engine, _lib, ops
+    K, D, H, V, T = dims['K'], dims['D'], dims['H'], dims['V'], dims['T']
+    g = torch.Generator().manual_seed(300 + B)
+
+    def lin(o, i, s=1.0):
+        r = s / np.sqrt(i)
+        return ((torch.rand(o, i, generator=g) * 2 - 1) * r).cuda(), ((torch.rand(o, generator=g) * 2 - 1) * r).cuda()
+    W = {'embed.0.weight': torch.randn(V + 2, H, generator=g).cuda()}
+    for nm, (o, i, s) in {'att_embed.0': (H, D, 1), 'logit': (V + 1, H, 6), 'ctx2att': (H, H, 1), 'core.a2c': (2 * H, H, 1),
+                          'core.i2h': (5 * H, H, 1), 'core.h2h': (5 * H, H, 1), 'core.attention.h2att': (H, H, 1),
+                          'core.attention.alpha_net': (1, H, 3)}.items():
+        W[nm + '.weight'], W[nm + '.bias'] = lin(o, i, s)
+    W['logit.bias'][0] = 2.0
+    p = 0.5
+    d = engine.speaker_dims(B, K, D, H, H, H, V, T, p)
+    params = engine.speaker_params(W)
+    att_raw = (torch.randn(B, K, D, generator=g).abs() * 0.5).cuda()
+    att_pre = engine.speaker_att_embed_fwd(d, params, att_raw)
+    nz = dict(att_keep=(torch.rand(B, K, H, generator=g) >= p).to(torch.uint8).cuda(),
+              x_keep=(torch.rand(T + 1, B, H, generator=g) >= p).to(torch.uint8).cuda(),
+              out_keep=(torch.rand(T + 1, B, H, generator=g) >= p).to(torch.uint8).cuda())
+    seed, offset = 1234, 7 << 32
+    U = torch.empty(T + 1, B, V + 1, device='cuda')
+    ops.uniform_(U, seed, offset)
+    m = dict(gumbel_st=_lib.SAMPLE_GUMBEL_ST, multinomial=_lib.SAMPLE_MULTINOMIAL)[mode]
+    st = mode == 'gumbel_st'
+    a = engine.speaker_decode_io(d, params, att_pre, m, 0.8, U=U, want_stv=st, **nz)
+    b = engine.speaker_decode_io(d, params, att_pre, m, 0.8, u_stream=(seed, offset), want_stv=st, **nz)
+    a['ws'].zero_(), b['ws'].zero_()
+    engine.speaker_decode_launch(d, params, a)
+    engine.speaker_decode_launch(d, params, b)
+    torch.cuda.synchronize()
+    assert 0 < int(a['L']) <= T and len(set(a['seq'].cpu().numpy().reshape(-1).tolist())) > 5
+    for k in ('seq', 'slp', 'stv', 'L', 'ws'):
+        if a[k] is not None:
+            assert torch.equal(a[k], b[k]), k
+    G = torch.randn(T, B, V + 1, generator=g).cuda() if st else None
+    w2 = torch.randn(B, T, generator=g).cuda()
+    ga = {k: torch.zeros_like(v) for k, v in W.items()}
+    gb = {k: torch.zeros_like(v) for k, v in W.items()}
+    engine.speaker_decode_bwd(d, params, a, ga, att_raw, d_onehot=G, dslp=w2)
+    engine.speaker_decode_bwd(d, params, b, gb, att_raw, d_onehot=G, dslp=w2)
+    torch.cuda.synchronize()
+    for k in ga:
+        if k.endswith('alpha_net.bias'):
+            continue          # a softmax shift: its gradient is mathematically 0, rounding noise on both sides
+        scale = float(ga[k].abs().max()) + 1e-12         # sums of float atomics: the noise scales with the largest terms
+        np.testing.assert_allclose(gb[k].cpu().numpy(), ga[k].cpu().numpy(), rtol=1e-5, atol=1e-5 * scale, err_msg=k)

@@ -2,6 +2,8 @@
 """rocprofv3 probe: attention kernel duration vs batch, in a cache-polluting loop like the real step."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _devlib  # noqa: F401,E402  (development build of the library: dispatch switches, stamps)
 import torch
 from cooperativeimagecaptioning_amd import ops, _lib
 lib = _lib.lib

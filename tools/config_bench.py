@@ -8,6 +8,8 @@ import os
 import sys
 import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _devlib  # noqa: F401,E402  (development build of the library: dispatch switches, stamps)
 import torch
 from cooperativeimagecaptioning_amd import models, optimizer as optim, synthetic
 from cooperativeimagecaptioning_amd.misc import rewards

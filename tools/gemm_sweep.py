@@ -4,6 +4,8 @@ K-sliced tail on / off (cic_debug_gemm_tail_split), HIP events over back-to-back
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _devlib  # noqa: F401,E402  (development build of the library: dispatch switches, stamps)
 import torch
 from cooperativeimagecaptioning_amd import ops, _lib
 

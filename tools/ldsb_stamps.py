@@ -3,6 +3,8 @@
 after the first tile is staged, then per tile: MFMA chain done / staged + epilogue issued / barrier passed."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _devlib  # noqa: F401,E402  (development build of the library: dispatch switches, stamps)
 import torch, numpy as np
 from cooperativeimagecaptioning_amd import _lib
 from cooperativeimagecaptioning_amd._lib import GemmArgs, lib

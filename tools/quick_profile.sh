@@ -7,7 +7,7 @@ out=$R/gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --output-format csv -d $out/trace -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_rocprof.json 2> $out/trace.err
+rocprofv3 --kernel-trace --output-format csv -d $out/trace -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --profile-steps 0 > $out/bench_rocprof.json 2> $out/trace.err
 cd $R
 kt=$(find $out/trace -name '*kernel_trace.csv' | head -1)
 python tools/trace_summary.py $kt 10 $out/step_breakdown.md > $out/trace_summary.log

@@ -5,6 +5,8 @@ import ctypes as C
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _devlib  # noqa: F401,E402  (development build of the library: dispatch switches, stamps)
 import torch
 from cooperativeimagecaptioning_amd import _lib
 from cooperativeimagecaptioning_amd._lib import GemmArgs, lib
