@@ -30,8 +30,10 @@ def load(model, opt, iteration=None):
     """models/__init__.py:35-50: continue from <start_from>/model[-<iteration>].pth (tensors only)."""
     if vars(opt).get('start_from', None) is not None:
         assert os.path.isdir(opt.start_from), " %s must be a a path" % opt.start_from
-        assert os.path.isfile(os.path.join(opt.start_from, "infos_" + opt.id + ".pkl")), \
-            "infos.pkl file does not exist in path %s" % opt.start_from
+        # this implementation's checkpoints carry infos_<id>.json (train.checkpoint); a reference checkpoint directory
+        # carries infos_<id>.pkl, which is accepted as a marker but never unpickled
+        assert any(os.path.isfile(os.path.join(opt.start_from, "infos_" + opt.id + ext)) for ext in ('.json', '.pkl')), \
+            "infos file does not exist in path %s" % opt.start_from
         name = 'model-' + iteration + '.pth' if iteration else 'model.pth'
         sd = torch.load(os.path.join(opt.start_from, name), map_location='cpu', weights_only=True)
         utils.load_state_dict(model, sd)

@@ -58,16 +58,26 @@ class SyntheticLoader:
     drawing 9.4 M normals per call costs 50-150 ms of host time, an order of magnitude more than the step);
     pool = 0 draws a fresh batch on every call."""
 
-    def __init__(self, opt, seed=1234, K=36, iters_per_epoch=100, pool=8):
+    def __init__(self, opt, seed=1234, K=36, iters_per_epoch=100, pool=8, pin=True):
         self.opt, self.seed, self.K, self.n, self.ipe = opt, seed, K, 0, iters_per_epoch
         self.vocab_size, self.seq_length = opt.vocab_size, opt.seq_length
         self.pool = int(pool)
+        self.pin = bool(pin) and torch.cuda.is_available()      # pool batches live in page-locked memory: asynchronous uploads
         self._cache = {}
+
+    def state_dict(self, rewind=0):
+        """Position of the stream (the reference keeps loader.iterators in infos, train.py:312); rewind: batches
+        already handed out that the caller has not consumed."""
+        return dict(n=max(0, int(self.n) - int(rewind)))
+
+    def load_state_dict(self, st):
+        self.n = int(st.get('n', 0))
 
     def _make(self, idx):
         b = make_batch(self.opt, K=self.K, seed=self.seed + idx)
-        return dict(fc_feats=b['fc_feats'].numpy(), att_feats=b['att_feats'].numpy(), att_masks=None,
-                    labels=b['labels'].numpy(), masks=b['masks'].numpy(), gts=b['gts'])
+        host = (lambda t: t.pin_memory().numpy()) if self.pin and self.pool > 0 else (lambda t: t.numpy())
+        return dict(fc_feats=host(b['fc_feats']), att_feats=host(b['att_feats']), att_masks=None,
+                    labels=host(b['labels']), masks=host(b['masks']), gts=b['gts'])
 
     def get_batch(self, split):
         if self.pool > 0:

@@ -76,17 +76,72 @@ def save_model(model, opt, model_kind, iteration=None):
         torch.save(sd, os.path.join(opt.checkpoint_path, f'{model_kind}-{iteration}.pth'))
 
 
-def checkpoint(opt, model, optimizer_dict, iteration, epoch, loss_history):
+def checkpoint(opt, model, optimizer_dict, iteration, epoch, loss_history, loader=None):
+    """train.py:299-336 (save_any_kind_of_model, save_optimizer, dump_infos_miscellaneous, save_results): weights,
+    optimizer states, and the infos / histories records as JSON (the reference pickles them; nothing here is ever
+    unpickled).  Besides the reference's fields the infos record carries what this implementation needs to continue
+    the SAME run: the schedule values in force and the position of the noise stream and of the loader."""
     if dist.is_initialized() and dist.get_rank() != 0:
         return
     save_model(model, opt, 'alternatingModel' if opt.is_alternating else 'model', iteration)
     save_optimizer(opt, optimizer_dict)
-    infos = dict(iter=iteration, epoch=epoch, gumbel_temp=float(model.caption_generator.gumbel_temp),
+    cg = model.caption_generator
+    infos = dict(iter=iteration, epoch=epoch, gumbel_temp=float(cg.gumbel_temp),
+                 ss_prob=float(cg.ss_prob), current_lr=float(getattr(opt, 'current_lr', opt.learning_rate)),
+                 retrieval_reward_weight=float(model.retrieval_reward_weight),
+                 prob_gumbel_softmax=float(cg.prob_gumbel_softmax), prob_multinomial_soft=float(cg.prob_multinomial_soft),
+                 noise=dict(seed=int(cg.noise.seed), counter=int(cg.noise.counter)),
+                 iterators=_loader_state(loader),
                  opt={k: v for k, v in vars(opt).items() if isinstance(v, (int, float, str, list, type(None)))})
-    with open(os.path.join(opt.checkpoint_path, 'infos_' + opt.id + '.json'), 'w') as f:   # JSON, not pickle
-        json.dump(infos, f)
+    for name in ('infos_' + opt.id + '.json', f'infos_{opt.id}-{iteration}.json'):       # save_pkl writes both (:109-118)
+        with open(os.path.join(opt.checkpoint_path, name), 'w') as f:                     # JSON, not pickle
+            json.dump(infos, f)
     with open(os.path.join(opt.checkpoint_path, 'histories_' + opt.id + '.json'), 'w') as f:
         json.dump(dict(loss_history=loss_history), f)
+
+
+def _loader_state(loader):
+    """Position of the batch source, as the reference keeps loader.iterators / split_ix in infos (train.py:312-313)."""
+    inner = getattr(loader, 'loader', loader)             # PrefetchLoader wraps the real one
+    if inner is None:
+        return None
+    if hasattr(inner, 'state_dict'):
+        # batches the prefetcher pulled ahead of the step are replayed after a resume
+        return inner.state_dict(rewind=int(loader.ahead()) if hasattr(loader, 'ahead') else 0)
+    return None
+
+
+def load_infos(opt):
+    """train.py:143-159: the infos record of the run to continue ({} for a fresh run), after checking that the saved
+    model options agree with the command line.  Only this repository's own JSON record is read."""
+    infos = {}
+    if vars(opt).get('start_from', None) is not None:
+        filename = os.path.join(opt.start_from, 'infos_' + opt.id + '.json')
+        if not os.path.isfile(filename):
+            if os.path.isfile(filename[:-5] + '.pkl'):
+                print(f'{filename[:-5]}.pkl is a pickle of the reference implementation: not loaded (pickles execute code); '
+                      f'schedules restart from iteration 0')
+            return infos
+        with open(filename) as f:
+            print('read from [%s]' % filename)
+            infos = json.load(f)
+        saved = infos.get('opt', {})
+        for checkme in ('caption_model', 'rnn_type', 'rnn_size', 'num_layers'):
+            assert saved.get(checkme) == vars(opt).get(checkme), \
+                "Command line argument and saved model disagree on '%s' " % checkme
+    return infos
+
+
+def load_from_infos(infos, loader, opt):
+    """train.py:360-367."""
+    iteration = infos.get('iter', 0)
+    epoch = infos.get('epoch', 0)
+    epoch_start = epoch
+    st = infos.get('iterators')
+    inner = getattr(loader, 'loader', loader)
+    if loader is not None and st is not None and hasattr(inner, 'load_state_dict'):
+        inner.load_state_dict(st)
+    return epoch, epoch_start, iteration
 
 
 def load_data(data, opt, device):
@@ -106,27 +161,46 @@ def train(opt, loader=None):
         dist.init_process_group('nccl')                      # RCCL over xGMI: one rank per GPU
     device = torch.device('cuda', local_rank)
     opt.use_att = utils.if_use_att(opt)
+    made_synthetic = False
     if loader is None:
-        if not opt.synthetic:
-            raise NotImplementedError('the COCO reader (h5py/lmdb, dataloader.py) is host I/O outside this hot '
-                                      'path: pass a loader object with get_batch("train") or use --synthetic 1')
-        opt.vocab_size = getattr(opt, 'vocab_size', None) or 9487
-        opt.seq_length = getattr(opt, 'seq_length', None) or 16
-        loader = synthetic.SyntheticLoader(opt, seed=1234 + rank, pool=getattr(opt, 'synthetic_pool', 8))
-    else:
+        if opt.synthetic:
+            made_synthetic = True
+            opt.vocab_size = getattr(opt, 'vocab_size', None) or 9487
+            opt.seq_length = getattr(opt, 'seq_length', None) or 16
+            loader = synthetic.SyntheticLoader(opt, seed=1234 + rank, pool=getattr(opt, 'synthetic_pool', 8))
+        else:
+            from .dataloader import DataLoader       # the reference's on-disk formats, read with numpy (dataloader.py)
+            loader = DataLoader(opt)
+    if not made_synthetic:
         opt.vocab_size, opt.seq_length = loader.vocab_size, loader.seq_length
+    infos = load_infos(opt)                                   # {} for a fresh run
+    if infos.get('iterators') is not None and hasattr(loader, 'load_state_dict'):
+        loader.load_state_dict(infos['iterators'])            # before the prefetcher pulls its first batch
     if getattr(opt, 'prefetch', 1):
         from .prefetch import PrefetchLoader          # the next batch is uploaded on a copy stream under this step's compute
         loader = PrefetchLoader(loader, device, 'train')
+    opt.gumbel_temp = infos.get('gumbel_temp', opt.gumbel_temp)                # train.py:366, before the model reads it
     torch.manual_seed(opt.seed)                               # same initial weights on every rank
-    model = models.AlternatingJointModel(opt).to(device).train()
-    model.caption_generator.noise.manual_seed(opt.seed * 1000 + rank)
+    model = models.AlternatingJointModel(opt).to(device).train()   # loads <start_from>/*.pth when asked to continue
+    cg = model.caption_generator
+    cg.noise.manual_seed(opt.seed * 1000 + rank)
+    if infos:                                                 # the schedule values and stream positions in force at the checkpoint
+        cg.ss_prob = infos.get('ss_prob', cg.ss_prob)
+        cg.prob_gumbel_softmax = infos.get('prob_gumbel_softmax', cg.prob_gumbel_softmax)
+        cg.prob_multinomial_soft = infos.get('prob_multinomial_soft', cg.prob_multinomial_soft)
+        model.retrieval_reward_weight = infos.get('retrieval_reward_weight', model.retrieval_reward_weight)
+        if infos.get('noise'):
+            cg.noise.counter = int(infos['noise']['counter'])   # every rank keeps its own seed and continues its stream
     optimizer_dict = load_optimizer(model, opt)
+    if infos.get('current_lr') is not None:
+        opt.current_lr = infos['current_lr']
+        for o in _all_optimizers(optimizer_dict):
+            utils.set_lr(o, opt.current_lr)
     if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
         from .optimizer import overlap_gradient_exchange
         overlap_gradient_exchange(model, optimizer_dict)
     update_lr_flag = True
-    iteration, epoch, epoch_start = 0, 0, 0
+    epoch, epoch_start, iteration = load_from_infos(infos, None, opt)
     loss_history = {}
     num_turns = len(opt.alternating_turn) if opt.is_alternating else 1
     init_scorer(opt.cached_tokens)
@@ -161,7 +235,7 @@ def train(opt, loader=None):
         if iteration % opt.losses_log_every == 0:
             loss_history[iteration] = train_loss
         if iteration % opt.save_checkpoint_every == 0:
-            checkpoint(opt, model, optimizer_dict, iteration, epoch, loss_history)
+            checkpoint(opt, model, optimizer_dict, iteration, epoch, loss_history, loader)
         if (epoch >= opt.max_epochs != -1) or (0 < opt.max_iterations <= iteration):
             break
     if hasattr(loader, 'close'):

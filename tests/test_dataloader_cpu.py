@@ -1,0 +1,115 @@
+"""CPU: the data layer (cooperativeimagecaptioning_amd/dataloader.py) against the reference's get_batch contract
+(dataloader.py:171-245) on a small dataset in the reference's on-disk formats: per-image fc `.npy` and att
+`.npz['feat']` files with ragged region counts, labels / label_start_ix / label_end_ix arrays, a json with ix_to_word
+and splits.  The h5 label container itself cannot be read here (h5py is not in the image): the same three arrays come
+from an .npz."""
+import argparse
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+
+def _dataset(tmp, n=11, D=12, seq_length=16, ragged=True, seed=0):
+    rs = np.random.RandomState(seed)
+    fc_dir, att_dir = os.path.join(tmp, 'fc'), os.path.join(tmp, 'att')
+    os.makedirs(fc_dir), os.makedirs(att_dir)
+    images, labels, start, end = [], [], [], []
+    feats = {}
+    for i in range(n):
+        iid = 1000 + 7 * i
+        K = int(rs.randint(3, 8)) if ragged else 5
+        fc = rs.rand(D).astype('float32')
+        att = rs.rand(K, D).astype('float32')
+        np.save(os.path.join(fc_dir, f'{iid}.npy'), fc)
+        np.savez(os.path.join(att_dir, f'{iid}.npz'), feat=att.reshape(1, K, D))      # prepro_feats writes [h, w, C]
+        feats[iid] = (fc, att)
+        ncap = int(rs.randint(1, 4))
+        start.append(len(labels) + 1)                                                # 1-based, as prepro_labels.py
+        for _ in range(ncap):
+            ln = int(rs.randint(3, seq_length + 1))
+            row = np.zeros(seq_length, np.int64)
+            row[:ln] = rs.randint(1, 30, size=ln)
+            labels.append(row)
+        end.append(len(labels))
+        images.append({'id': iid, 'split': 'train' if i < n - 3 else ('val' if i < n - 1 else 'restval'),
+                       'file_path': f'x/{iid}.jpg'})
+    np.savez(os.path.join(tmp, 'labels.npz'), labels=np.stack(labels), label_start_ix=np.array(start), label_end_ix=np.array(end))
+    with open(os.path.join(tmp, 'data.json'), 'w') as f:
+        json.dump({'ix_to_word': {str(i): f'w{i}' for i in range(1, 30)}, 'images': images}, f)
+    opt = argparse.Namespace(input_json=os.path.join(tmp, 'data.json'), input_label_h5=os.path.join(tmp, 'labels.npz'),
+                             input_fc_dir=fc_dir, input_att_dir=att_dir, batch_size=4, seq_per_img=2, train_only=0,
+                             use_att=True, use_fc=True, pin_memory=0)
+    return opt, images, feats, np.stack(labels), np.array(start), np.array(end)
+
+
+@pytest.mark.parametrize('ragged', [True, False])
+def test_get_batch_contract(tmp_path, ragged):
+    from cooperativeimagecaptioning_amd.dataloader import DataLoader
+    opt, images, feats, labels, start, end = _dataset(str(tmp_path), ragged=ragged)
+    random.seed(3)
+    dl = DataLoader(opt, workers=2)
+    assert dl.vocab_size == 29 and dl.seq_length == 16
+    assert len(dl.split_ix['train']) == 9 and len(dl.split_ix['val']) == 2       # restval joins train (train_only 0)
+    order = list(dl.split_ix['train'])
+    seen, wraps = [], 0
+    for it in range(3):
+        d = dl.get_batch('train')
+        B, spi = 4, 2
+        ixs = [inf['ix'] for inf in d['infos']]
+        seen += ixs
+        assert d['fc_feats'].shape == (B * spi, 12) and d['labels'].shape == (B * spi, 18) and d['masks'].shape == (B * spi, 18)
+        kmax = max(feats[images[ix]['id']][1].shape[0] for ix in ixs)
+        assert d['att_feats'].shape == (B * spi, kmax, 12)
+        for i, ix in enumerate(ixs):
+            fc, att = feats[images[ix]['id']]
+            for q in range(spi):
+                np.testing.assert_array_equal(d['fc_feats'][i * spi + q], fc)
+                np.testing.assert_array_equal(d['att_feats'][i * spi + q, :att.shape[0]], att)
+                assert not d['att_feats'][i * spi + q, att.shape[0]:].any()            # zero padding
+                if d['att_masks'] is not None:
+                    np.testing.assert_array_equal(d['att_masks'][i * spi + q], (np.arange(kmax) < att.shape[0]).astype('float32'))
+                lab = d['labels'][i * spi + q]
+                assert lab[0] == 0 and lab[17] == 0                                     # <bos> / <eos> columns
+                cand = labels[start[ix] - 1:end[ix]]
+                assert any(np.array_equal(lab[1:17], c) for c in cand)                  # one of the image's own captions
+                nnz = int((lab != 0).sum())
+                np.testing.assert_array_equal(d['masks'][i * spi + q], (np.arange(18) < nnz + 2).astype('float32'))
+            np.testing.assert_array_equal(d['gts'][i], cand)
+        if not ragged:
+            assert d['att_masks'] is None                                               # all images the same length (:228-229)
+        elif len({feats[images[ix]['id']][1].shape[0] for ix in ixs}) > 1:
+            assert d['att_masks'] is not None
+        wraps += int(d['bounds']['wrapped'])
+        assert d['bounds']['it_max'] == 9
+    assert seen[:9] == order and wraps == 1                 # first epoch in split order, wrapped once in 12 images
+    assert sorted(seen[9:]) == sorted(dl.split_ix['train'])[:0] or set(seen[9:]) <= set(order)
+    dl.close()
+
+
+def test_state_dict_resumes_the_stream(tmp_path):
+    from cooperativeimagecaptioning_amd.dataloader import DataLoader
+    opt, *_ = _dataset(str(tmp_path))
+    random.seed(5)
+    a = DataLoader(opt, workers=2)
+    a.get_batch('train')
+    st = a.state_dict()
+    nxt = [inf['ix'] for inf in a.get_batch('train')['infos']]
+    b = DataLoader(opt, workers=2)
+    b.load_state_dict(json.loads(json.dumps(st)))           # survives the JSON infos record
+    assert [inf['ix'] for inf in b.get_batch('train')['infos']] == nxt
+    assert a.state_dict(rewind=1)['iterators']['train'] == st['iterators']['train']
+    a.close(), b.close()
+
+
+def test_val_split_and_unsupported_stores(tmp_path):
+    from cooperativeimagecaptioning_amd.dataloader import DataLoader, HybridLoader
+    opt, images, feats, *_ = _dataset(str(tmp_path))
+    dl = DataLoader(opt, workers=1)
+    d = dl.get_batch('val', batch_size=2)
+    assert [inf['id'] for inf in d['infos']] == [images[8]['id'], images[9]['id']] and d['bounds']['wrapped']
+    dl.close()
+    with pytest.raises(NotImplementedError):
+        HybridLoader('features.lmdb', '.npy')

@@ -77,3 +77,48 @@ def test_prefetch_loader_hands_over_the_same_batches():
             np.testing.assert_array_equal(off.cpu().numpy(), np.arange(0, 5 * 4 + 1, 5))
     finally:
         pf.close()
+
+
+def _flat_weights(model):
+    return {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+
+def test_resume_continues_the_same_run(tmp_path, capsys):
+    """--start_from on this implementation's own checkpoint (reference train.py:143-159,360-367, optimizer.py:43-67):
+    4 iterations straight == 2 iterations + checkpoint + resume + 2 iterations.  Iteration / epoch counters, learning
+    rate, Gumbel temperature (annealed every iteration here), the Adam moments and step, the position of the noise
+    stream and of the loader all continue; the weights agree to float-atomic tolerance (gradient products combine
+    partial tiles with float atomics, so two runs of the same step differ in the last bits)."""
+    import json
+    from cooperativeimagecaptioning_amd import opts, train
+    extra = ['--retrieval_reward', 'gumbel', '--gumbel_temperature_annealing_factor', '1e-9', '--num_iteration_for_annealing', '1',
+             '--learning_rate_decay_start', '0', '--learning_rate_decay_every', '1',
+             '--learning_rate_decay_rate', '0.5']
+
+    def run(path, iters, start_from=None, ckpt_every=2):
+        argv = [a for a in COMMON] + extra + ['--max_iterations', str(iters), '--checkpoint_path', str(path)]
+        argv[argv.index('--save_checkpoint_every') + 1] = str(ckpt_every)
+        if start_from is not None:
+            argv += ['--start_from', str(start_from)]
+        opt = opts.parse_opt(argv)
+        opt.vocab_size, opt.seq_length = 199, 16
+        return train.train(opt), opt
+    a_dir, b_dir, c_dir = tmp_path / 'a', tmp_path / 'b', tmp_path / 'c'
+    straight, opt_a = run(a_dir, 4, ckpt_every=4)
+    capsys.readouterr()
+    run(b_dir, 2)
+    infos = json.load(open(os.path.join(str(b_dir), 'infos_cli.json')))
+    assert infos['iter'] == 2 and infos['noise']['counter'] > 0 and infos['iterators'] == {'n': 2}
+    resumed, opt_c = run(c_dir, 4, start_from=b_dir, ckpt_every=4)
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith('iter ')]
+    assert [l.split(' ')[1] for l in lines[-2:]] == ['2', '3']                   # the counter continued
+    ia = json.load(open(os.path.join(str(a_dir), 'infos_cli.json')))
+    ic = json.load(open(os.path.join(str(c_dir), 'infos_cli.json')))
+    for k in ('iter', 'epoch', 'gumbel_temp', 'ss_prob', 'current_lr', 'noise', 'iterators'):
+        assert ia[k] == ic[k], k
+    assert straight.caption_generator.flat().step == resumed.caption_generator.flat().step == 4
+    wa, wc = _flat_weights(straight), _flat_weights(resumed)
+    for k in wa:
+        if k.endswith('alpha_net.bias'):
+            continue          # a softmax shift: its gradient is rounding noise, which Adam turns into lr-sized steps
+        np.testing.assert_allclose(wc[k].numpy(), wa[k].numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
