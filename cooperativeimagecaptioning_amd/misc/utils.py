@@ -16,21 +16,14 @@ def if_use_att(opt):
 
 
 def decode_sequence(ix_to_word, seq):
-    """misc/utils.py:23-37: 0 is the END token."""
-    N, D = seq.size()
-    out = []
-    for i in range(N):
-        txt = ''
-        for j in range(D):
-            ix = int(seq[i, j])
-            if ix > 0:
-                if j >= 1:
-                    txt = txt + ' '
-                txt = txt + ix_to_word[str(ix)]
-            else:
-                break
-        out.append(txt)
-    return out
+    """Token ids -> sentences (the reference's misc/utils.py:23-37 contract: ix_to_word is keyed by the decimal
+    string of the id, 0 ends a caption and is not printed)."""
+    rows = torch.as_tensor(seq).cpu().tolist()
+    sentences = []
+    for row in rows:
+        end = row.index(0) if 0 in row else len(row)
+        sentences.append(' '.join(ix_to_word[str(tok)] for tok in row[:end]))
+    return sentences
 
 
 def to_contiguous(tensor):
@@ -67,34 +60,44 @@ def clip_gradient(optimizer, grad_clip):
                 param.grad.data.clamp_(-grad_clip, grad_clip)
 
 
+def _map_leaves(fn, x):
+    """fn over the leaves of nested dicts / lists / tuples (lists come back as lists, as the reference returns them)."""
+    if isinstance(x, dict):
+        return {k: _map_leaves(fn, v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_map_leaves(fn, v) for v in x]
+    return fn(x)
+
+
 def var_wrapper(x, cuda=True, volatile=False):
-    """misc/utils.py:72-87 (Variable/volatile are gone from torch; volatile -> detached)."""
-    if type(x) is dict:
-        return {k: var_wrapper(v, cuda, volatile) for k, v in x.items()}
-    if type(x) is list or type(x) is tuple:
-        return [var_wrapper(v, cuda, volatile) for v in x]
-    if isinstance(x, np.ndarray):
-        x = torch.from_numpy(x)
-    if torch.is_tensor(x):
-        x = x.cuda() if cuda else x.cpu()
-        if volatile:
-            x = x.detach()
-    return x
+    """misc/utils.py:72-87: numpy arrays / tensors inside nested containers -> tensors on the device (`cuda`) or the
+    host; everything else is passed through.  torch.autograd.Variable and `volatile` no longer exist: a volatile
+    request yields detached tensors (callers also run under torch.no_grad())."""
+    def leaf(v):
+        if isinstance(v, np.ndarray):
+            v = torch.from_numpy(v)
+        if not torch.is_tensor(v):
+            return v
+        v = v.cuda() if cuda else v.cpu()
+        return v.detach() if volatile else v
+    return _map_leaves(leaf, x)
 
 
 def load_state_dict(model, state_dict):
-    """misc/utils.py:89-107: tolerant loader (flatten-and-copy on shape mismatch)."""
-    model_state_dict = model.state_dict()
-    keys = set(list(model_state_dict.keys()) + list(state_dict.keys()))
-    for k in keys:
-        if k not in state_dict:
-            print(f'key {k} in model.state_dict() not in loaded state_dict')
-        elif k not in model_state_dict:
-            print(f'key {k} in loaded state_dict not in model.state_dict()')
-        else:
-            if state_dict[k].size() != model_state_dict[k].size():
+    """Tolerant checkpoint loader with the behaviour of misc/utils.py:89-107: keys on one side only are reported and
+    skipped; a tensor whose shape differs is copied element for element over the common leading part of the two
+    flattened tensors (a vocabulary that grew keeps its trained rows)."""
+    own = model.state_dict()
+    for k in sorted(own.keys() - state_dict.keys()):
+        print(f'key {k} in model.state_dict() not in loaded state_dict')
+    for k in sorted(state_dict.keys() - own.keys()):
+        print(f'key {k} in loaded state_dict not in model.state_dict()')
+    with torch.no_grad():
+        for k in own.keys() & state_dict.keys():
+            src, dst = state_dict[k], own[k]
+            if src.shape != dst.shape:
                 print(f'key {k} size not match in model.state_dict() and loaded state_dict. '
                       f'Try to flatten and copy the values in common parts')
-            n = min(model_state_dict[k].numel(), state_dict[k].numel())
-            model_state_dict[k].view(-1)[:n].copy_(state_dict[k].view(-1)[:n])
-    model.load_state_dict(model_state_dict)
+            n = min(src.numel(), dst.numel())
+            dst.reshape(-1)[:n].copy_(src.reshape(-1)[:n])
+    model.load_state_dict(own)

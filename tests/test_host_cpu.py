@@ -207,3 +207,19 @@ def test_compute_modules_fail_loudly_without_the_library(tmp_path):
             "print('imported'); sys.exit(1)\n")
     out = subprocess.run([sys.executable, '-c', code], cwd=str(tmp_path), capture_output=True, text=True, timeout=180)
     assert out.returncode == 0 and out.stdout.strip() == 'CicError', (out.stdout, out.stderr)
+
+
+def test_misc_utils_helpers():
+    """decode_sequence / var_wrapper / load_state_dict keep the reference's contracts (misc/utils.py:23-37,72-107)."""
+    import torch
+    from cooperativeimagecaptioning_amd.misc import utils
+    words = {str(i): f'w{i}' for i in range(1, 6)}
+    assert utils.decode_sequence(words, torch.tensor([[3, 1, 0, 4], [0, 2, 2, 2], [5, 5, 5, 5]])) == ['w3 w1', '', 'w5 w5 w5 w5']
+    out = utils.var_wrapper({'a': np.ones((2, 2), np.float32), 'b': [np.zeros(3), 'text', (torch.ones(1), 7)]}, cuda=False, volatile=True)
+    assert torch.is_tensor(out['a']) and torch.is_tensor(out['b'][0]) and out['b'][1] == 'text'
+    assert isinstance(out['b'][2], list) and torch.is_tensor(out['b'][2][0]) and out['b'][2][1] == 7
+    small, big = torch.nn.Linear(3, 2), torch.nn.Linear(3, 4)
+    sd = {k: v.clone() for k, v in big.state_dict().items()}
+    sd['extra'] = torch.zeros(1)
+    utils.load_state_dict(small, sd)                    # shape mismatch: the common leading part is copied
+    assert torch.equal(small.weight.reshape(-1), big.weight.reshape(-1)[:6]) and torch.equal(small.bias, big.bias[:2])
