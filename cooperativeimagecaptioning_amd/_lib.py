@@ -45,7 +45,8 @@ class GemmArgs(C.Structure):
                 ('sum_order_free', C.c_int), ('c_is_zero', C.c_int), ('colsum_A', c_ptr), ('colsum_A2', c_ptr), ('rows_blk', C.c_int), ('A_b', c_ptr), ('A2_b', c_ptr), ('C_b', c_ptr),
                 ('n_split', C.c_int), ('B2_tail', c_ptr), ('ldb2_tail', C.c_int), ('bias_tail', c_ptr),
                 ('C_tail', c_ptr), ('C_tail_b', c_ptr), ('ldc_tail', C.c_int),
-                ('epi', c_ptr)]        # fused vocabulary epilogue (the decode engine's logit product); NULL here
+                ('epi', c_ptr),        # fused vocabulary epilogue (the decode engine's logit product); NULL here
+                ('precision', C.c_int)]   # 0 f32 accuracy (default), 1 f32-input MFMA only, 2 bf16 operands
 
 
 class SamplerArgs(C.Structure):

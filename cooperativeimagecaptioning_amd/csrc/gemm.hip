@@ -29,6 +29,7 @@ CIC_SWITCH(g_walk16, 1);       // bit 21 set: 16-wide strip walkers off
 CIC_SWITCH(g_ldsb, 1);         // bit 22 set: LDS-staged column walker (K = 512 logit product) off
 CIC_SWITCH(g_ldsb2, 2);        // K parts per row tile of the logit walker: 2 or 4 (bits 25..26 of the debug word: 1 -> 4-wave form, 2 -> 4 parts)
 CIC_SWITCH(g_rega2, 1);        // bit 24 set: two-strip dX kernel (gemm_rega2_kernel) off
+CIC_SWITCH(g_bfx, 1);          // bit 28 set: the LDS-tiled products stay on the f32-input MFMA (no bf16-part kernel)
 CIC_SWITCH(g_logit_epi, 1);    // bit 27 set: no fused vocabulary epilogue in the logit walker (cic_gemm_logit_parts() = 0)
 CIC_SWITCH(g_split_rows, 1);   // bit 23 set: 129..256-row products are not handed to the register-streaming kernels as two row blocks
 
@@ -268,6 +269,236 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(cic_gemm_args g, int 
             __builtin_amdgcn_sched_barrier(0);
             // the sums are finished on the straight-line path (the empty asm keeps them there): computed inside the
             // bounds-checked store blocks, every block would wait for ALL earlier memory operations, stores included
+            float vv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[i][j][e] + bv + cold[e];
+                if (g.relu) v = fmaxf(v, 0.f);
+                asm volatile("" : "+v"(v));
+                vv[e] = v;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m < g.M && nok) g.C[(size_t)m * g.ldc + n] = vv[e];
+            }
+        }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The same LDS-tiled product on the bf16 matrix cores, at f32 accuracy: every f32 operand element is cut into NP bf16
+// parts while its tile is staged into LDS (x = x1 + x2 + x3, each part the bf16 rounding of what the previous ones left:
+// 3 x 8 mantissa bits = the 24 of an f32), and a product is the sum of the part products that matter:
+//     a b  ~=  a1 b1 + (a1 b2 + a2 b1) + (a2 b2 + a1 b3 + a3 b1)          (the dropped terms are <= 2^-24 |a b|)
+// Part products are exact in f32 (8 x 8 mantissa bits) and are summed in f32 accumulators, small terms first.
+// v_mfma_f32_32x32x16_bf16 does 16 k per 32 cycles where the f32-input v_mfma_f32_32x32x2_f32 does 2 k per 64: six part
+// products per k-step are 2.67x the f32 MFMA rate for the same f32 inputs and f32 result (error vs an f64 product
+// ~1e-7 relative, the level of the f32 MFMA's own fma chain; tests/test_gpu_kernels.py).  NP = 1 is the plain bf16
+// product (operands rounded to bf16 once): the reduced-precision variant of BASELINE configs[1].
+//   LDS images, per part:  K-contiguous operand  [rows][BK] bf16, 80-byte rows  -> one ds_read_b128 per fragment;
+//                          K-strided operand     [BK][rows] bf16 (+64 B / row)  -> two ds_read_b64_tr_b16 per fragment
+//                          (the hardware transpose read hands every lane 4 consecutive k of its row; no transposing store).
+// Same workgroup / tail / epilogue scheme as gemm_kernel.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <int NP>
+__device__ __forceinline__ void split_bf16(const f32x4 v, bf16x4 (&out)[NP]) {
+    f32x4 r = v;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const bf16x4 h = __builtin_convertvector(r, bf16x4);        // round to nearest even (v_cvt_pk_bf16_f32)
+        out[p] = h;
+        if (p + 1 < NP) r = r - __builtin_convertvector(h, f32x4);  // exact: the part is a prefix of r's mantissa
+    }
+}
+
+template <int ROWS, bool KC, int THREADS, int NP>
+struct TileBf {
+    static constexpr int NV = ROWS * BK / 4 / THREADS;                 // float4 per thread per tile (as Tile<>)
+    static constexpr int KSTRIDE = BK + 8;                             // bf16 per row of a K-contiguous image: 80 bytes
+    static constexpr int RSTRIDE = ROWS + 32;                          // bf16 per k-row of a K-strided image: +64 bytes
+    static constexpr int PART = KC ? ROWS * KSTRIDE : BK * RSTRIDE;    // bf16 per part
+    static constexpr int LDS_BF16 = NP * PART;
+    static_assert(NV >= 1 && NV * THREADS * 4 == ROWS * BK, "tile/threads mismatch");
+
+    // registers (the f32 tile as Tile<ROWS, KC, true, THREADS>::load left it) -> bf16 parts in LDS
+    __device__ static __forceinline__ void store(const f32x4 (&r)[NV], __bf16* L, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * THREADS;
+            bf16x4 parts[NP];
+            split_bf16<NP>(r[i], parts);
+            int off;
+            if (KC) { const int rr = idx >> 3, q = idx & 7; off = rr * KSTRIDE + 4 * q; }          // 4 k of one row
+            else { constexpr int QR = ROWS / 4; const int kk = idx / QR, q = idx % QR; off = kk * RSTRIDE + 4 * q; }   // 4 rows of one k
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4*>(L + p * PART + off) = parts[p];
+        }
+    }
+
+    // MFMA fragment of part p for the 32 rows starting at row0, k-step s (16 k): lane (r = lane & 31, h = lane >> 5)
+    // gets op[row0 + r][16 s + 8 h + 0..7]
+    __device__ static __forceinline__ bf16x8 frag(const __bf16* L, int p, int row0, int s, int lane) {
+        if (KC) {
+            const int r = lane & 31, h = lane >> 5;
+            return *reinterpret_cast<const bf16x8*>(L + p * PART + (row0 + r) * KSTRIDE + 16 * s + 8 * h);
+        } else {
+            // 16-lane group g: rows row0 + 16 (g & 1) + 0..15, k 16 s + 8 (g >> 1) + 0..7 as two 4-k blocks; lane 4q + pp of
+            // the group addresses k-row q, rows 4 pp .. 4 pp + 3 of the block
+            const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+            const __bf16* base = L + p * PART + (16 * s + 8 * (g >> 1) + q) * RSTRIDE + row0 + 16 * (g & 1) + 4 * pp;
+            typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base + 4 * RSTRIDE));
+            union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+            u.s.a = lo; u.s.b = hi;
+            return u.v;
+        }
+    }
+};
+
+template <int BM, int BN, int WM, int WN, bool KCA, bool KCB, int NP>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bfx_kernel(cic_gemm_args g, int full, int ks) {
+    constexpr int THREADS = WM * WN * 64;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    using LA_ = Tile<BM, KCA, true, THREADS>;            // global -> registers (f32)
+    using LB_ = Tile<BN, KCB, true, THREADS>;
+    using TA = TileBf<BM, KCA, THREADS, NP>;
+    using TB = TileBf<BN, KCB, THREADS, NP>;
+    __shared__ __attribute__((aligned(16))) __bf16 lds[TA::LDS_BF16 + TB::LDS_BF16];
+    __bf16* LA = lds;
+    __bf16* LB = lds + TA::LDS_BF16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int h = lane >> 5, r = lane & 31;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);      // XCD-aware tile order (as gemm_kernel)
+    int slice = 0, nslice = 1;
+    if (bid >= full) {               // K-sliced tail tile
+        const int rem = bid - full;
+        slice = rem % ks;
+        nslice = ks;
+        bid = full + rem / ks;
+    }
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    f32x4 ra[LA_::NV], rb[LB_::NV];
+    const bool do_colsum = !KCA && g.colsum_A != nullptr && n0 == 0;
+    f32x4 cs4 = {0.f, 0.f, 0.f, 0.f};                   // column sums of op(A) = bias gradient: rows 4q .. 4q+3 of this thread
+    const int K = g.K;                                  // (no second operand pair on this path)
+    const int nk_all = (K + BK - 1) / BK;
+    const int per = (nk_all + nslice - 1) / nslice;
+    const int kt0 = slice * per;
+    const int nk = min(nk_all, kt0 + per);
+    if (kt0 < nk) {
+        LA_::load(ra, g.A, g.lda, m0, g.M, kt0 * BK, K, tid);
+        LB_::load(rb, g.B, g.ldb, n0, g.N, kt0 * BK, K, tid);
+#pragma unroll 1
+        for (int kt = kt0; kt < nk; ++kt) {
+            __syncthreads();   // everyone is done reading the previous tile
+            TA::store(ra, LA, tid);
+            TB::store(rb, LB, tid);
+            if (do_colsum) {
+#pragma unroll
+                for (int i = 0; i < LA_::NV; ++i) cs4 += ra[i];
+            }
+            __syncthreads();
+            if (kt + 1 < nk) {   // next tile in flight under the MFMAs
+                LA_::load(ra, g.A, g.lda, m0, g.M, (kt + 1) * BK, K, tid);
+                LB_::load(rb, g.B, g.ldb, n0, g.N, (kt + 1) * BK, K, tid);
+            }
+#pragma unroll
+            for (int s = 0; s < BK / 16; ++s) {
+                bf16x8 af[TM][NP], bf[TN][NP];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) af[i][p] = TA::frag(LA, p, wm * (BM / WM) + i * 32, s, lane);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) bf[j][p] = TB::frag(LB, p, wn * (BN / WN) + j * 32, s, lane);
+                // part products, smallest first: (pa, pb) with pa + pb = 2, then 1, then 0
+#pragma unroll
+                for (int order = NP - 1; order >= 0; --order)
+#pragma unroll
+                    for (int pa = 0; pa <= order; ++pa) {
+                        const int pb = order - pa;
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][pa], bf[j][pb], acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    if (do_colsum) {                    // block-uniform
+        constexpr int QR = BM / 4, GROUPS = THREADS / QR;
+        __syncthreads();                // the last K-tile's fragment reads are done: LDS is free
+        float* lf = reinterpret_cast<float*>(lds);
+        static_assert(sizeof(float) * GROUPS * BM <= sizeof(__bf16) * (TA::LDS_BF16 + TB::LDS_BF16), "colsum scratch");
+        *reinterpret_cast<f32x4*>(lf + (tid / QR) * BM + 4 * (tid % QR)) = cs4;
+        __syncthreads();
+        if (tid < BM && m0 + tid < g.M) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < GROUPS; ++q) t += lf[q * BM + tid];
+            atomicAdd(g.colsum_A + m0 + tid, t);
+            if (g.colsum_A2) atomicAdd(g.colsum_A2 + m0 + tid, t);
+        }
+    }
+    // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)   (as gemm_kernel)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / WN) + j * 32 + r;
+            const bool nok = n < g.N;
+            const int nc = nok ? n : g.N - 1;
+            const float bv = (g.bias && slice == 0) ? g.bias[nc] : 0.f;
+            if (nslice > 1) {                    // block-uniform
+                float va[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = acc[i][j][e] + bv;
+                    asm volatile("" : "+v"(v));
+                    va[e] = v;
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (m < g.M && nok) atomicAdd(g.C + (size_t)m * g.ldc + n, va[e]);
+                }
+                continue;
+            }
+            float cold[16];
+            if (g.accumulate) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    cold[e] = g.C[(size_t)(m < g.M ? m : g.M - 1) * g.ldc + nc];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) cold[e] = 0.f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
             float vv[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -1591,6 +1822,26 @@ int launch_shape(const cic_gemm_args& g, bool vec, bool want_tail, hipStream_t s
         }
     }
     dim3 blk(WM * WN * 64);
+    // bf16-part products (f32 accuracy at 2.67x the f32 MFMA rate; precision 2: plain bf16) for aligned single-pair
+    // products; CIC_PRECISION_F32_MFMA keeps the exact-f32 MFMA kernel
+    const int np = (!vec || g.K2 > 0 || !g_bfx || g.precision == CIC_PRECISION_F32_MFMA) ? 0
+                   : (g.precision == CIC_PRECISION_BF16 ? 1 : 3);
+    if (np) {
+#define CIC_BFX_GO(KA, KB)                                                                                                   \
+    do {                                                                                                                     \
+        if (np == 3) hipLaunchKernelGGL((gemm_bfx_kernel<BM, BN, WM, WN, KA, KB, 3>), dim3(grid), blk, 0, st, g, full, ks);   \
+        else hipLaunchKernelGGL((gemm_bfx_kernel<BM, BN, WM, WN, KA, KB, 1>), dim3(grid), blk, 0, st, g, full, ks);           \
+    } while (0)
+        switch ((g.a_kc ? 2 : 0) | (g.b_kc ? 1 : 0)) {
+            case 3: CIC_BFX_GO(true, true); break;
+            case 2: CIC_BFX_GO(true, false); break;
+            case 1: CIC_BFX_GO(false, true); break;
+            default: CIC_BFX_GO(false, false); break;
+        }
+#undef CIC_BFX_GO
+        CIC_LAUNCH_CHECK();
+        return 0;
+    }
 #define CIC_GEMM_GO(KA, KB, V) \
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, KA, KB, V>), dim3(grid), blk, 0, st, g, full, ks)
     const int code = (g.a_kc ? 4 : 0) | (g.b_kc ? 2 : 0) | (vec ? 1 : 0);
@@ -1654,6 +1905,7 @@ extern "C" int cic_debug_gemm_tail_split(int on) {
     g_rega2 = ((on >> 24) & 1) ? 0 : 1;
     g_ldsb2 = ((on >> 25) & 3) == 1 ? 0 : (((on >> 25) & 3) == 2 ? 4 : 2);
     g_logit_epi = ((on >> 27) & 1) ? 0 : 1;
+    g_bfx = ((on >> 28) & 1) ? 0 : 1;
     return 0;
 }
 
@@ -1765,19 +2017,18 @@ extern "C" int cic_gemm_f32(const cic_gemm_args* a, cic_stream_t s) {
     if (g_force_tile == 2) return launch_shape<64, 64, 2, 2>(g, vec, true, cic_s(s));
     if (g_force_tile == 3) return launch_shape<128, 128, 2, 4>(g, vec, true, cic_s(s));   // 8 waves, 64x32 per wave
     if (g_force_tile == 4) return launch_shape<128, 128, 4, 2>(g, vec, true, cic_s(s));   // 8 waves, 32x64 per wave
-    // Tile choice (measured on the shapes of the B = 128 joint step, tools/gemm_sweep.py): a lone 128x128 workgroup
-    // runs its CU at ~90 % of the f32 MFMA rate, a 64x64 one at about half of that but four of them share a CU.
+    // Tile choice (measured on the shapes of the B = 128 joint step with the bf16-part kernel, tools/gemm_sweep.py ->
+    // profiles/r02_gemm_sweep.log): a 128x128 workgroup of 8 waves (4x2: 32x64 per wave, two waves per SIMD) is the
+    // efficient tile; what decides is how evenly the tiles cover 256 CUs.
     //   >= 400 big tiles: 128x128, several rounds of full tiles;
-    //   48..192 big tiles and a free summation order: 128x128 tiles, every tile K-sliced so that ~512 workgroups
-    //     cover the chip (unless the 64x64 grid is an exact multiple of the CU count and K is short: d_out, K = 9488,
-    //     228 us on 256 exact 64x64 tiles vs 200 us K-sliced);
+    //   a free summation order (gradient products), >= 48 big tiles and K >= 1024: 128x128 tiles, the tail round (or every
+    //     tile when there are fewer than 256) K-sliced so that ~512 workgroups cover the chip - d_out 135 us (64x64
+    //     tiles: 266), dW logit 136 (177), dx 56 (76), listener dW hh 95 (120);
     //   otherwise 64x64 tiles, K-sliced only when there are fewer than one per CU.
     const int64_t small_tiles = (int64_t)cic_cdiv(g.M, 64) * cic_cdiv(g.N, 64);
     const bool free_sum = g.sum_order_free && g_tail_split && g.K2 == 0 && !g.relu;
-    // 128x128 tiles run with 8 waves (64x32 per wave, two waves per SIMD): 2-4 % faster than 4 waves of 64x64 (sweep)
-    if (big_tiles >= 400) return launch_shape<128, 128, 2, 4>(g, vec, true, cic_s(s));
-    if (free_sum && big_tiles >= 48 && big_tiles <= 192 && g.K >= 1024 && ((small_tiles % 256) != 0 || g.K > 4096))
-        return launch_shape<128, 128, 2, 4>(g, vec, true, cic_s(s));
+    if (big_tiles >= 400) return launch_shape<128, 128, 4, 2>(g, vec, true, cic_s(s));
+    if (free_sum && big_tiles >= 48 && g.K >= 1024) return launch_shape<128, 128, 4, 2>(g, vec, true, cic_s(s));
     return launch_shape<64, 64, 2, 2>(g, vec, small_tiles < 256, cic_s(s));
 }
 

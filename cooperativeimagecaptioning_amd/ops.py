@@ -46,7 +46,7 @@ def dropout_keep_(keep, p, seed, offset=0):
 
 
 def gemm(A, B, C_, a_kc=True, b_kc=True, bias=None, accumulate=False, relu=False, A2=None, B2=None,
-         M=None, N=None, K=None, K2=None, sum_order_free=False):
+         M=None, N=None, K=None, K2=None, sum_order_free=False, precision=0):
     """C = op(A) op(B) (+ op(A2) op(B2)) (+bias) (+C).  2-D tensors; rows may be strided views
     (stride(1) == 1).  See cic_gemm_f32 in include/cic.h."""
     def ld(t):
@@ -72,6 +72,7 @@ def gemm(A, B, C_, a_kc=True, b_kc=True, bias=None, accumulate=False, relu=False
     g.bias = bias.data_ptr() if bias is not None else None
     g.accumulate, g.relu = int(accumulate), int(relu)
     g.sum_order_free = int(sum_order_free)
+    g.precision = int(precision)      # 0 f32 accuracy, 1 f32-input MFMA only, 2 bf16 operands (cic.h)
     check(_gemm(C.byref(g), stream()), 'cic_gemm_f32')
     return C_
 

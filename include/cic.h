@@ -105,7 +105,14 @@ typedef struct {
      * sampler need no second pass over the [M, N] logits.  C still receives the raw logits (the backward pass reads
      * them).  Only where cic_gemm_logit_parts() > 0; else leave NULL and run cic_logit_partials on C. */
     const struct cic_logit_epilogue* epi;
+    /* Arithmetic of the LDS-tiled (batched) products; the per-timestep kernels always use the f32-input MFMA.
+     *   CIC_PRECISION_F32 (0, default): f32 in, f32 out, f32 accuracy - the implementation may cut the operands into three
+     *     bf16 parts and sum six part products on the bf16 matrix cores (error ~1e-7 relative, as an f32 fma chain);
+     *   CIC_PRECISION_F32_MFMA: the f32-input MFMA only (bitwise a k-ordered f32 fma chain per output);
+     *   CIC_PRECISION_BF16: operands rounded to bf16 once, f32 accumulation (reduced precision, ~3e-3 relative). */
+    int precision;
 } cic_gemm_args;
+enum { CIC_PRECISION_F32 = 0, CIC_PRECISION_F32_MFMA = 1, CIC_PRECISION_BF16 = 2 };
 /* Row partials of the vocabulary: the columns of a row are dealt to `nparts` parts; a part reduces its columns
  * (after the decoding constraint, AttModel.py:438-442: one column per row set to -inf) to six numbers, stored as
  * planes  part[plane][row][p],  plane stride = part_rows * nparts floats:

@@ -64,6 +64,35 @@ def test_gemm(ops, M, N, K, a_kc, b_kc):
     np.testing.assert_allclose(Cd.cpu().double().numpy(), ref2.numpy(), rtol=1e-5, atol=tol)
 
 
+@pytest.mark.parametrize('M,N,K,a_kc,b_kc', [(4608, 512, 2048, True, True), (2048, 512, 9488, True, False),
+                                              (9488, 512, 2048, False, False), (512, 2048, 4608, False, True),
+                                              (300, 200, 136, True, True), (260, 132, 72, False, False)])
+def test_gemm_precisions(ops, M, N, K, a_kc, b_kc):
+    """The LDS-tiled products at their three arithmetic settings (cic.h, cic_gemm_args.precision) against an f64 product
+    of the same f32 operands: the default - operands cut into three bf16 parts, six part products on the bf16 matrix
+    cores - must be as accurate as the f32-input MFMA's own fma chain (both ~1e-7 of sum |a b|); plain bf16 operands
+    are the reduced-precision setting (2^-8 per operand)."""
+    g = torch.Generator().manual_seed(11 * M + N + K)
+    A = torch.randn((M, K) if a_kc else (K, M), generator=g) * torch.logspace(-2, 2, K if a_kc else M, base=2.0)
+    B = torch.randn((N, K) if b_kc else (K, N), generator=g)
+    opA, opB = (A if a_kc else A.t()).double(), (B.t() if b_kc else B).double()
+    ref = opA @ opB
+    mag = (opA.abs() @ opB.abs()).numpy()                 # sum_k |a b|: the scale rounding errors ride on
+    err = {}
+    for name, prec in (('f32', 0), ('f32_mfma', 1), ('bf16', 2)):
+        Cd = dev(torch.zeros(M, N))
+        ops.gemm(dev(A), dev(B), Cd, a_kc, b_kc, precision=prec)
+        torch.cuda.synchronize()
+        err[name] = float(np.max(np.abs(Cd.cpu().double().numpy() - ref.numpy()) / mag))
+    assert err['f32_mfma'] < 4e-7 and err['f32'] < 4e-7, err      # f32-level: a few 2^-24 of sum |a b|
+    assert 1e-5 < err['bf16'] < 8e-3, err                          # bf16 operands: ~2^-9 .. 2^-8 per factor
+    # every setting is deterministic run to run (forward products keep a fixed summation order)
+    C1, C2 = dev(torch.zeros(M, N)), dev(torch.zeros(M, N))
+    ops.gemm(dev(A), dev(B), C1, a_kc, b_kc)
+    ops.gemm(dev(A), dev(B), C2, a_kc, b_kc)
+    assert torch.equal(C1, C2)
+
+
 def test_gemm_dual_and_strided(ops):
     # pre = x W_i2h^T + h W_h2h^T + b, written into a column window of a wider buffer
     g = torch.Generator().manual_seed(5)
