@@ -63,7 +63,7 @@ class SamplerArgs(C.Structure):
 
 
 class SpeakerDims(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ('B', 'K', 'D', 'H', 'E', 'A', 'V', 'T')] + [('p_drop', C.c_float)]
+    _fields_ = [(n, C.c_int) for n in ('B', 'K', 'D', 'H', 'E', 'A', 'V', 'T')] + [('p_drop', C.c_float), ('compute_dtype', C.c_int)]
 
 
 SPEAKER_PARAM_FIELDS = [

@@ -16,6 +16,7 @@ struct Carver {
     int32_t* i32(size_t n) { return static_cast<int32_t*>(take(n * sizeof(int32_t))); }
     double* f64(size_t n) { return static_cast<double*>(take(n * sizeof(double))); }
     uint64_t* u64(size_t n) { return static_cast<uint64_t*>(take(n * sizeof(uint64_t))); }
+    uint16_t* u16(size_t n) { return static_cast<uint16_t*>(take(n * sizeof(uint16_t))); }
     size_t used() const { return (off + 255) & ~size_t(255); }
 };
 
@@ -29,6 +30,7 @@ struct SpkWs {
     float* bias_ih;                           // [5H] = i2h.bias + h2h.bias
     float *pre_img, *zeros;                   // [B,5H], [B,H]: the image step of an FCModel decode; a zero state
     int32_t *it_all, *unfinished, *any_unf;   // [T+1,B], [B], [T+1]
+    uint16_t *att_bf, *p_att_bf;              // bf16 copies of att / p_att (compute_dtype bf16 only)
     float *part, *lse_all;                    // row partials of one step's logits [6][B][nparts]; [T,B] log-sum-exp rows
     size_t bytes;
 };
@@ -40,7 +42,11 @@ int cic_add_vec(const float* a, const float* b, float* o, int n, hipStream_t st)
 bool cic_attn_pair_ok(int K, int A, int H);
 int cic_attn_fwd2(Dual<const float> att_h, Dual<const float> p_att, Dual<const float> att, const float* w_alpha,
                   const float* b_alpha, const float* masks, Dual<float> att_res, Dual<float> alpha, Dual<float> dot, int B,
-                  int nb, int K, int A, int H, hipStream_t st, int att_div = 1);
+                  int nb, int K, int A, int H, hipStream_t st, int att_div = 1,
+                  Dual<const uint16_t> p_att_bf = Dual<const uint16_t>{nullptr, nullptr},
+                  Dual<const uint16_t> att_bf = Dual<const uint16_t>{nullptr, nullptr});
+// x <- bf16(x) (round to nearest even, in place as f32) and its packed bf16 copy
+int cic_round_pack_bf16(float* x, uint16_t* packed, int64_t n, hipStream_t st);
 int cic_cell_fwd2(Dual<const float> pre, Dual<const float> c_prev, Dual<const uint8_t> keep, float p_drop, Dual<float> h_new,
                   Dual<float> c_new, Dual<float> out, int B, int nb, int H, hipStream_t st, int state_dropped = 0);
 int cic_embed_fwd2(const float* E, Dual<const int32_t> it, Dual<const uint8_t> keep, float p_drop, Dual<float> x, int B,
@@ -60,64 +66,78 @@ int cic_relu_keep_fwd(const float* xpre, const uint8_t* keep, float p_drop, floa
 int cic_soft_mask(const float* soft_raw, const int32_t* seq, const int32_t* L, float* soft_out, int T, int B, int V1,
                   hipStream_t st);
 
+// The stream of an engine call together with the arithmetic of its batched products (cic_gemm_args.precision): the GEMM
+// shorthands below take it where they used to take the stream, and it still converts to the stream for launches.
+struct GemmCtx {
+    hipStream_t st;
+    int precision;
+    GemmCtx(hipStream_t s, int p = CIC_PRECISION_F32) : st(s), precision(p) {}
+    operator hipStream_t() const { return st; }
+};
+
 // C[M,N] = A[M,K] W[N,K]^T (+bias) (+C)           — nn.Linear forward
 static inline int gemm_nt(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
-                          const float* bias, bool accumulate, bool relu, hipStream_t st) {
+                          const float* bias, bool accumulate, bool relu, GemmCtx st) {
     cic_gemm_args g = {};
     g.M = M; g.N = N; g.K = K;
     g.A = A; g.lda = lda; g.a_kc = 1;
     g.B = W; g.ldb = ldw; g.b_kc = 1;
     g.C = C; g.ldc = ldc; g.bias = bias; g.accumulate = accumulate; g.relu = relu;
-    return cic_gemm_f32(&g, st);
+    g.precision = st.precision;
+    return cic_gemm_f32(&g, st.st);
 }
 // C = A1 W1^T + A2 W2^T + bias
 static inline int gemm_nt2(const float* A1, int lda1, const float* W1, int ldw1, int K1, const float* A2, int lda2,
                            const float* W2, int ldw2, int K2, float* C, int ldc, int M, int N, const float* bias,
-                           hipStream_t st) {
+                           GemmCtx st) {
     cic_gemm_args g = {};
     g.M = M; g.N = N; g.K = K1;
     g.A = A1; g.lda = lda1; g.a_kc = 1;
     g.B = W1; g.ldb = ldw1; g.b_kc = 1;
     g.K2 = K2; g.A2 = A2; g.lda2 = lda2; g.B2 = W2; g.ldb2 = ldw2;
     g.C = C; g.ldc = ldc; g.bias = bias;
-    return cic_gemm_f32(&g, st);
+    g.precision = st.precision;
+    return cic_gemm_f32(&g, st.st);
 }
 // C[M,N] = A[M,K] Bm[K,N] (+C)                    — dX = dY W   (W stored [K=out, N=in]); a gradient product:
 // the summation order is free
 static inline int gemm_nn(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K,
-                          bool accumulate, hipStream_t st, bool order_free = true, bool c_is_zero = false) {
+                          bool accumulate, GemmCtx st, bool order_free = true, bool c_is_zero = false) {
     cic_gemm_args g = {};
     g.M = M; g.N = N; g.K = K;
     g.A = A; g.lda = lda; g.a_kc = 1;
     g.B = Bm; g.ldb = ldb; g.b_kc = 0;
     g.C = C; g.ldc = ldc; g.accumulate = accumulate; g.sum_order_free = order_free; g.c_is_zero = c_is_zero;
-    return cic_gemm_f32(&g, st);
+    g.precision = st.precision;
+    return cic_gemm_f32(&g, st.st);
 }
 // the same product in a FORWARD pass (soft caption rows @ embedding): fixed summation order
 static inline int gemm_nn_fwd(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K,
-                              bool accumulate, hipStream_t st) {
+                              bool accumulate, GemmCtx st) {
     return gemm_nn(A, lda, Bm, ldb, C, ldc, M, N, K, accumulate, st, false);
 }
 // C = A1 B1 + A2 B2 (+C), all B stored [K,N]
 static inline int gemm_nn2(const float* A1, int lda1, const float* B1, int ldb1, int K1, const float* A2, int lda2,
                            const float* B2, int ldb2, int K2, float* C, int ldc, int M, int N, bool accumulate,
-                           hipStream_t st, bool c_is_zero = false) {
+                           GemmCtx st, bool c_is_zero = false) {
     cic_gemm_args g = {};
     g.M = M; g.N = N; g.K = K1;
     g.A = A1; g.lda = lda1; g.a_kc = 1;
     g.B = B1; g.ldb = ldb1; g.b_kc = 0;
     g.K2 = K2; g.A2 = A2; g.lda2 = lda2; g.B2 = B2; g.ldb2 = ldb2;
     g.C = C; g.ldc = ldc; g.accumulate = accumulate; g.sum_order_free = 1; g.c_is_zero = c_is_zero;
-    return cic_gemm_f32(&g, st);
+    g.precision = st.precision;
+    return cic_gemm_f32(&g, st.st);
 }
 // C[M,N] = At[K,M]^T Bm[K,N] (+C)                 — dW = dY^T X
 static inline int gemm_tn(const float* At, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K,
-                          bool accumulate, hipStream_t st, float* bias_grad = nullptr, float* bias_grad2 = nullptr) {
+                          bool accumulate, GemmCtx st, float* bias_grad = nullptr, float* bias_grad2 = nullptr) {
     cic_gemm_args g = {};
     g.M = M; g.N = N; g.K = K;
     g.A = At; g.lda = lda; g.a_kc = 0;
     g.B = Bm; g.ldb = ldb; g.b_kc = 0;
     g.C = C; g.ldc = ldc; g.accumulate = accumulate; g.sum_order_free = 1;   // weight gradients
     g.colsum_A = bias_grad; g.colsum_A2 = bias_grad2;                        // db += colsum(dY), a by-product of the A tiles
-    return cic_gemm_f32(&g, st);
+    g.precision = st.precision;
+    return cic_gemm_f32(&g, st.st);
 }

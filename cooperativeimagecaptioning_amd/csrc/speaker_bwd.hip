@@ -701,7 +701,7 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     const int phase = bio->phase;
     CIC_REQUIRE(phase == CIC_BWD_ALL || ((phase == CIC_BWD_LOGIT || phase == CIC_BWD_REST) && !ps));
     const bool do_logit = phase != CIC_BWD_REST, do_rest = phase != CIC_BWD_LOGIT;
-    hipStream_t st = cic_s(s);
+    GemmCtx st(cic_s(s), d.compute_dtype == CIC_DTYPE_BF16 ? CIC_PRECISION_BF16 : CIC_PRECISION_F32);
     const int B = d.B, K = d.K, H = d.H, E = d.E, A = d.A, T = d.T, V1 = d.V + 1, D = d.D;
     const float scale = 1.0f / (1.0f - d.p_drop);
     const cic_speaker_params* gr = bio->grads;

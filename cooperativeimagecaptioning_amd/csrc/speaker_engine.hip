@@ -93,6 +93,8 @@ SpkWs spk_carve(const cic_speaker_dims& d, void* base) {
     w.it_all = c.i32((T + 1) * B);
     w.unfinished = c.i32(B);
     w.any_unf = c.i32(T + 1);
+    w.att_bf = c.u16(B * K * H);
+    w.p_att_bf = c.u16(B * K * A);
     w.part = c.f32((size_t)CIC_PART_PLANES * CIC_PART_MAX_ENTRIES);
     w.lse_all = c.f32(T * B);
     w.bytes = c.used();
@@ -118,7 +120,7 @@ extern "C" int cic_speaker_att_embed_fwd(const cic_speaker_dims* dp, const cic_s
     if (int rc = check_dims(d)) return rc;
     // relu(att_raw W^T + b): [B*K, D] x [H, D]^T   (models/AttModel.py:82-85 without the dropout)
     return gemm_nt(att_raw, d.D, p->att_embed_w, d.D, att_pre, d.H, d.B * d.K, d.H, d.D, p->att_embed_b, false,
-                   true, cic_s(s));
+                   true, GemmCtx(cic_s(s), d.compute_dtype == CIC_DTYPE_BF16 ? CIC_PRECISION_BF16 : CIC_PRECISION_F32));
 }
 
 static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params* p, const cic_decode_io* const* ios,
@@ -164,7 +166,8 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     CIC_REQUIRE(dp && p && ios && wss && (nb == 1 || nb == 2));
     const cic_speaker_dims& d = *dp;
     if (int rc = check_dims(d)) return rc;
-    hipStream_t st = cic_s(s);
+    const bool bf = d.compute_dtype == CIC_DTYPE_BF16;
+    GemmCtx st(cic_s(s), bf ? CIC_PRECISION_BF16 : CIC_PRECISION_F32);
     const int B = d.B, K = d.K, H = d.H, E = d.E, A = d.A, T = d.T, V1 = d.V + 1;
     const float p_drop = d.p_drop;
     int rc;
@@ -212,6 +215,12 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
                 RUN(cic_apply_keep(io[q]->att_pre, io[q]->att_keep, io[q]->att_keep ? p_drop : 0.f, w[q].att, (int64_t)B * K * H, s));
             }
             RUN(gemm_nt(w[q].att, H, p->ctx2att_w, H, w[q].p_att, A, B * K, A, H, p->ctx2att_b, false, false, st));
+            if (bf) {
+                // bf16 storage: att and p_att are rounded to bf16 (the f32 buffers keep the rounded values for the backward
+                // pass); the per-timestep attention streams the bf16 copies
+                RUN(cic_round_pack_bf16(w[q].att, w[q].att_bf, (int64_t)B * K * H, st));
+                RUN(cic_round_pack_bf16(w[q].p_att, w[q].p_att_bf, (int64_t)B * K * A, st));
+            }
         } else {
             // image step: (h0, c0) = LSTMCore(img_embed(fc_feats), zero state)          (FCModel.py:97-99,121,274-276,315)
             // h = 0, so h2h contributes its bias only (already in bias_ih)
@@ -288,7 +297,9 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
             CIC_TIMED(io[0]->timer, CIC_TIMED_ATTN_FWD, st,
                      rc = cic_attn_fwd2(Dual<const float>{att_h.a, att_h.b}, Dual<const float>{w[0].p_att, w[1].p_att},
                                         Dual<const float>{w[0].att, w[1].att}, p->alpha_w, p->alpha_b, io[0]->att_masks, att_res,
-                                        SLAB(alpha_all, B * K), SLAB(dot_all, B * K), B, nb, K, A, H, st));
+                                        SLAB(alpha_all, B * K), SLAB(dot_all, B * K), B, nb, K, A, H, st, 1,
+                                        Dual<const uint16_t>{bf ? w[0].p_att_bf : nullptr, bf ? w[1].p_att_bf : nullptr},
+                                        Dual<const uint16_t>{bf ? w[0].att_bf : nullptr, bf ? w[1].att_bf : nullptr}));
             if (rc) return rc;
         }
         // all_input_sums = i2h(xt) + h2h(h);  in_transform += a2c(att_res)   (:514,521-522)

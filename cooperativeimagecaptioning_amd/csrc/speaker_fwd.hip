@@ -162,9 +162,23 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const float* __restri
 __device__ unsigned long long* g_attn_stamps = nullptr;   // diagnostics (cic_debug_set_attn_stamps, development build)
 #endif
 
-template <int JMAX, int NCG>   // region groups of 8: K <= 8*JMAX;  NCG 32-column groups per wave
-__global__ __launch_bounds__(1024) void attn_fwd_cols_kernel(Dual<const float> att_h_d, Dual<const float> p_att_d,
-                                                             Dual<const float> att_d, const float* __restrict__ w_alpha,
+// four consecutive features of a region row: f32 storage, or bf16 storage widened to f32 (half the bytes per image)
+template <typename ST>
+__device__ __forceinline__ f32x4 ld_feat4(const ST* __restrict__ base, size_t idx4);
+template <>
+__device__ __forceinline__ f32x4 ld_feat4<float>(const float* __restrict__ base, size_t idx4) {
+    return reinterpret_cast<const f32x4*>(base)[idx4];
+}
+template <>
+__device__ __forceinline__ f32x4 ld_feat4<uint16_t>(const uint16_t* __restrict__ base, size_t idx4) {
+    const uint2 v = reinterpret_cast<const uint2*>(base)[idx4];
+    return f32x4{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                 __uint_as_float(v.y & 0xffff0000u)};
+}
+
+template <int JMAX, int NCG, typename ST = float>   // region groups of 8: K <= 8*JMAX;  NCG 32-column groups per wave
+__global__ __launch_bounds__(1024) void attn_fwd_cols_kernel(Dual<const float> att_h_d, Dual<const ST> p_att_d,
+                                                             Dual<const ST> att_d, const float* __restrict__ w_alpha,
                                                              const float* __restrict__ b_alpha, const float* __restrict__ masks,
                                                              Dual<float> att_res_d, Dual<float> alpha_d, Dual<float> dot_d, int B0,
                                                              int K, int H, int att_div) {
@@ -176,8 +190,8 @@ __global__ __launch_bounds__(1024) void attn_fwd_cols_kernel(Dual<const float> a
     const bool second = (int)blockIdx.x >= B0;
     const int b = second ? blockIdx.x - B0 : blockIdx.x;
     const float* __restrict__ att_h = att_h_d.sel(second);
-    const float* __restrict__ p_att = p_att_d.sel(second);
-    const float* __restrict__ att = att_d.sel(second);
+    const ST* __restrict__ p_att = p_att_d.sel(second);
+    const ST* __restrict__ att = att_d.sel(second);
     float* __restrict__ att_res = att_res_d.sel(second);
     float* __restrict__ alpha_out = alpha_d.sel(second);
     float* __restrict__ dot_out = dot_d.sel(second);
@@ -186,8 +200,8 @@ __global__ __launch_bounds__(1024) void attn_fwd_cols_kernel(Dual<const float> a
     const int c = lane & 7, rg = lane >> 3;
     const int H4 = H >> 2;
     const int bi = b / att_div;                 // image whose regions row b attends to (beam search: att_div rows per image)
-    const f32x4* pa4 = reinterpret_cast<const f32x4*>(p_att + (size_t)bi * K * H);
-    const f32x4* at4 = reinterpret_cast<const f32x4*>(att + (size_t)bi * K * H);
+    const ST* pa4 = p_att + (size_t)bi * K * H;
+    const ST* at4 = att + (size_t)bi * K * H;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     int col4[NCG];
     f32x4 ah[NCG], wa[NCG];
@@ -203,8 +217,8 @@ __global__ __launch_bounds__(1024) void attn_fwd_cols_kernel(Dual<const float> a
 #pragma unroll
         for (int j = 0; j < JMAX; ++j) {
             const int k = 8 * j + rg;
-            pv[i][j] = k < K ? pa4[(size_t)k * H4 + col4[i]] : z4;
-            av[i][j] = k < K ? at4[(size_t)k * H4 + col4[i]] : z4;
+            pv[i][j] = k < K ? ld_feat4<ST>(pa4, (size_t)k * H4 + col4[i]) : z4;
+            av[i][j] = k < K ? ld_feat4<ST>(at4, (size_t)k * H4 + col4[i]) : z4;
         }
 #pragma unroll
     for (int j = 0; j < JMAX; ++j) {
@@ -468,6 +482,17 @@ __global__ __launch_bounds__(256) void att_keep_rows_kernel(const float* __restr
         }
         reinterpret_cast<f32x4*>(y)[idx] = valid ? v : z4;
     }
+}
+
+// compute_dtype bf16: x <- bf16(x) widened back to f32 (in place) and the packed bf16 copy the attention kernel streams
+__global__ __launch_bounds__(256) void round_pack_bf16_kernel(float* __restrict__ x, uint16_t* __restrict__ packed, int64_t n4) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n4) return;
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[idx];
+    const bf16x4_t h = __builtin_convertvector(v, bf16x4_t);          // round to nearest even
+    reinterpret_cast<bf16x4_t*>(packed)[idx] = h;
+    reinterpret_cast<f32x4*>(x)[idx] = __builtin_convertvector(h, f32x4);
 }
 
 // x = dropout(relu(xpre))  — self.relu_dropout on soft_vec @ embed (models/AttModel.py:77-78,396-397)
@@ -1029,8 +1054,11 @@ bool cic_attn_pair_ok(int K, int A, int H) { return A == H && (H & 63) == 0 && H
 
 int cic_attn_fwd2(Dual<const float> att_h_d, Dual<const float> p_att_d, Dual<const float> att_d, const float* w_alpha,
                   const float* b_alpha, const float* masks, Dual<float> att_res_d, Dual<float> alpha_d, Dual<float> dot_d,
-                  int B, int nb, int K, int A, int H, hipStream_t st, int att_div) {
+                  int B, int nb, int K, int A, int H, hipStream_t st, int att_div, Dual<const uint16_t> p_att_bf,
+                  Dual<const uint16_t> att_bf) {
     CIC_REQUIRE(att_div >= 1);
+    const bool bf = p_att_bf.a != nullptr;
+    CIC_REQUIRE(!bf || (att_bf.a && cic_attn_pair_ok(K, A, H) && (nb == 1 || (p_att_bf.b && att_bf.b))));
     const float *att_h = att_h_d.a, *p_att = p_att_d.a, *att = att_d.a;
     float *att_res = att_res_d.a, *alpha = alpha_d.a, *dot = dot_d.a;
     CIC_REQUIRE(att_h && p_att && att && w_alpha && b_alpha && att_res && alpha);
@@ -1044,6 +1072,15 @@ int cic_attn_fwd2(Dual<const float> att_h_d, Dual<const float> p_att_d, Dual<con
         // 6.9 us vs 6.4 us in-kernel span at B = 128.
         const int ncg = 1;
         dim3 blk((H / 32 / ncg) * 64);
+        if (bf) {      // bf16 storage of the region features (compute_dtype bf16): half the bytes per image
+#define GOB(J) hipLaunchKernelGGL((attn_fwd_cols_kernel<J, 1, uint16_t>), grid, blk, 0, st, att_h_d, p_att_bf, att_bf, w_alpha, \
+                                  b_alpha, masks, att_res_d, alpha_d, dot_d, B, K, H, att_div)
+            if (K <= 8) GOB(1); else if (K <= 16) GOB(2); else if (K <= 24) GOB(3); else if (K <= 32) GOB(4);
+            else if (K <= 40) GOB(5); else if (K <= 48) GOB(6); else GOB(8);
+#undef GOB
+            CIC_LAUNCH_CHECK();
+            return 0;
+        }
 #define GOC(J)                                                                                                       \
     do {                                                                                                             \
         if (ncg == 2) hipLaunchKernelGGL((attn_fwd_cols_kernel<J, 2>), grid, blk, 0, st, att_h_d, p_att_d, att_d, w_alpha, \
@@ -1192,6 +1229,13 @@ int cic_att_keep_rows(const float* x, const uint8_t* keep, float p_drop, const f
     CIC_REQUIRE(x && y && masks && B > 0 && K > 0 && H > 0 && (H & 3) == 0);
     hipLaunchKernelGGL(att_keep_rows_kernel, dim3(B * K), dim3(256), 0, st, x, keep, 1.0f / (1.0f - p_drop), masks, y, B, K,
                        H / 4);
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+
+int cic_round_pack_bf16(float* x, uint16_t* packed, int64_t n, hipStream_t st) {
+    CIC_REQUIRE(x && packed && n > 0 && (n & 3) == 0);
+    hipLaunchKernelGGL(round_pack_bf16_kernel, dim3(cic_cdiv(n / 4, 256)), dim3(256), 0, st, x, packed, n / 4);
     CIC_LAUNCH_CHECK();
     return 0;
 }

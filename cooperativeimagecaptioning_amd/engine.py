@@ -55,9 +55,10 @@ def _p(t):
     return t.data_ptr()
 
 
-def speaker_dims(B, K, D, H, E, A, V, T, p_drop):
+def speaker_dims(B, K, D, H, E, A, V, T, p_drop, compute_dtype='f32'):
     d = SpeakerDims()
     d.B, d.K, d.D, d.H, d.E, d.A, d.V, d.T, d.p_drop = B, K, D, H, E, A, V, T, float(p_drop)
+    d.compute_dtype = {'f32': 0, 'bf16': 1}[compute_dtype]
     return d
 
 

@@ -91,6 +91,9 @@ class AttModel(nn.Module):
         self.logit = nn.Linear(self.rnn_size, self.vocab_size + 1)
         self.ctx2att = nn.Linear(self.rnn_size, self.att_hid_size)
         self.decoding_constraint = getattr(opt, 'decoding_constraint', 0)
+        # 'f32': the reference's arithmetic.  'bf16': the reduced-precision variant of BASELINE configs[1] (cic.h,
+        # cic_speaker_dims.compute_dtype): bf16 operands in the batched products, bf16 storage of the region features
+        self.compute_dtype = getattr(opt, 'compute_dtype', 'f32') or 'f32'
         self._loss = {}
         self._flat = None
         self.noise = NoiseSource()
@@ -108,7 +111,7 @@ class AttModel(nn.Module):
 
     def _dims(self, B, K, T):
         return engine.speaker_dims(B, K, self.att_feat_size, self.rnn_size, self.input_encoding_size,
-                                   self.att_hid_size, self.vocab_size, T, self.drop_prob_lm)
+                                   self.att_hid_size, self.vocab_size, T, self.drop_prob_lm, self.compute_dtype)
 
     def _check_inputs(self, att_feats):
         if not att_feats.is_cuda:

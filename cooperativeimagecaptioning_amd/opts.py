@@ -61,6 +61,9 @@ def build_parser():
     p.add_argument('--rank_on_gen_captions', action='store_true')               # opts.py:86-87
     p.add_argument('--continue_from_existing_models', action='store_false')     # opts.py:88-89 (store_false!)
     # additions of this implementation (absent from the reference)
+    p.add_argument('--compute_dtype', type=str, default='f32', choices=['f32', 'bf16'],
+                   help="speaker arithmetic: f32 = the reference's; bf16 = bf16 operands in the batched products and bf16 "
+                        "storage of the region features (f32 accumulation, f32 softmax / losses / optimiser)")
     p.add_argument('--synthetic', type=int, default=0, help='1: COCO-shaped synthetic batches (no dataset needed)')
     p.add_argument('--synthetic_pool', type=int, default=8,
                    help='distinct synthetic batches served round robin (0: draw a fresh batch on every call)')

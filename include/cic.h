@@ -237,7 +237,14 @@ typedef struct {
                                 K = 0: no region features (FCModel decodes, see fc_mode) */
     int T;                   /* seq_length */
     float p_drop;            /* drop_prob_lm */
+    int compute_dtype;       /* CIC_DTYPE_F32 (0): the reference's arithmetic.  CIC_DTYPE_BF16: the reduced-precision variant
+                                (BASELINE configs[1] "bf16") - the batched products run on bf16 operands with f32
+                                accumulation (CIC_PRECISION_BF16), the embedded regions `att` and their projection `p_att`
+                                are rounded to bf16 and the per-timestep attention streams them as bf16 (75,848 instead of
+                                151,696 bytes per image and step); recurrent state, per-timestep products, softmax,
+                                log-softmax, losses and the optimiser stay f32 */
 } cic_speaker_dims;
+enum { CIC_DTYPE_F32 = 0, CIC_DTYPE_BF16 = 1 };
 
 /* Parameter (or gradient) pointers, named as the reference's state dict
  * (models/AttModel.py:74-88,462-463,503-505). */

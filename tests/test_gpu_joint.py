@@ -134,7 +134,7 @@ def test_mle_forward_backward_matches_reference(name):
             np.testing.assert_allclose(d[2:], z[k][2:], rtol=5e-4, atol=5e-4 * scale + 1e-5 * glob, err_msg=k)
 
 
-def _full_size_step(opt, turn, decodes, logged_exact=(), logged_close=()):
+def _full_size_step(opt, turn, decodes, logged_exact=(), logged_close=(), loss_rtol=1e-4, grad_tol=1e-3):
     """One step of the mirrored AlternatingJointModel on the GPU against the CPU oracle: same weights, batch, dropout
     masks and sampler noise.  decodes: {tag: 'u' (Gumbel uniforms) | 'pick' (injected multinomial draws) | None}."""
     from cooperativeimagecaptioning_amd import models, synthetic
@@ -193,12 +193,12 @@ def _full_size_step(opt, turn, decodes, logged_exact=(), logged_close=()):
         assert L == ref_tok.shape[1], (tag, L, ref_tok.shape)
         np.testing.assert_array_equal(got.seq[:, :L].cpu().numpy(), ref_tok.numpy(), err_msg=tag + ' tokens')
         assert int((ref_tok > 0).sum()) > B, tag                  # real captions, not all-EOS
-    np.testing.assert_allclose(float(loss.detach()), float(ref_loss.detach()), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(float(loss.detach()), float(ref_loss.detach()), rtol=loss_rtol, atol=1e-6)
     logged = model.loss()
     for k in logged_exact:
         assert float(logged[k]) == pytest.approx(float(aux[k]), rel=1e-6, abs=1e-9), k     # f64 on both sides
     for k in logged_close:
-        np.testing.assert_allclose(float(logged[k]), float(aux[k]), rtol=1e-4, atol=1e-6, err_msg=k)
+        np.testing.assert_allclose(float(logged[k]), float(aux[k]), rtol=loss_rtol, atol=1e-6, err_msg=k)
     grads = {k: q.grad for k, q in model.named_parameters()}
     checked = 0
     for prefix, P in (('caption_generator.', Ps), ('vse.', Pl)):
@@ -211,7 +211,7 @@ def _full_size_step(opt, turn, decodes, logged_exact=(), logged_close=()):
                 continue
             want = v.grad.double()
             err = float((got.detach().cpu().double() - want).norm() / want.norm())
-            assert err < 1e-3, (k, err)
+            assert err < grad_tol, (k, err)
             checked += 1
     return checked
 
@@ -250,4 +250,17 @@ def test_mle_step_full_size_matches_oracle():
     opt = synthetic.default_opt(batch_size=64, caption_loss_weight=1.0, retrieval_reward_weight=0.0, cider_optimization=0,
                                 is_alternating=0)
     n = _full_size_step(opt, None, {'mle': None}, logged_close=('loss_cap',))
+    assert n >= 16
+
+
+@pytest.mark.timeout(600)
+def test_mle_step_bf16_variant_full_size_vs_f32_oracle():
+    """BASELINE configs[1] in its reduced-precision variant (--compute_dtype bf16; the reference itself is f32 only, so
+    the yardstick is the f32 oracle): bf16 operands in the batched products (f32 accumulation), the embedded regions and
+    their projection stored in bf16, everything else f32.  Stated tolerance: loss within 2e-3 relative, every parameter
+    gradient within 3e-2 of its norm (bf16 keeps 8 mantissa bits: 2^-9 = 2e-3 per rounded operand)."""
+    from cooperativeimagecaptioning_amd import synthetic
+    opt = synthetic.default_opt(batch_size=64, caption_loss_weight=1.0, retrieval_reward_weight=0.0, cider_optimization=0,
+                                is_alternating=0, compute_dtype='bf16')
+    n = _full_size_step(opt, None, {'mle': None}, logged_close=('loss_cap',), loss_rtol=2e-3, grad_tol=3e-2)
     assert n >= 16

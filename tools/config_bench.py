@@ -43,7 +43,7 @@ def run(name, steps, turns, **kw):
             loss = step(turn)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        print(f'{name:34s} turn {str(turn):9s} B {opt.batch_size:4d}: {dt * 1e3:7.2f} ms/step = {opt.batch_size / dt:8.0f} images/s'
+        print(f'{name:40s} turn {str(turn):9s} B {opt.batch_size:4d}: {dt * 1e3:7.2f} ms/step = {opt.batch_size / dt:8.0f} images/s'
               f'   loss {float(loss.detach()):.4f}', flush=True)
 
 
@@ -53,8 +53,10 @@ def main():
         from cooperativeimagecaptioning_amd import engine
         engine.lib.cic_debug_gemm_tail_split(int(os.environ['CIC_GEMM_FLAGS'], 0))
     run('C3 joint gumbel + CIDEr-D', steps, ['speaker'], batch_size=128)
-    run('C2 att2in2 MLE', steps, [None], batch_size=64, is_alternating=0, phase=2, caption_loss_weight=1.0,
+    run('C2 att2in2 MLE (f32)', steps, [None], batch_size=64, is_alternating=0, phase=2, caption_loss_weight=1.0,
         retrieval_reward_weight=0.0, cider_optimization=0, alternating_turn=None)
+    run('C2 att2in2 MLE (--compute_dtype bf16)', steps, [None], batch_size=64, is_alternating=0, phase=2, caption_loss_weight=1.0,
+        retrieval_reward_weight=0.0, cider_optimization=0, alternating_turn=None, compute_dtype='bf16')
     run('C4 joint reinforce(gt) + CIDEr-D', steps, ['speaker', 'listener'], batch_size=256, retrieval_reward='reinforce',
         reinforce_baseline_type='gt', vse_loss_weight=1.0)
 
