@@ -55,6 +55,30 @@ extern "C" int cic_timer_reset(cic_timer* t) {
     t->pairs.clear();
     return 0;
 }
+// What a bracket costs by itself: the average elapsed time of `pairs` event pairs recorded back to back on `s` with
+// nothing between them (the command processor's own time for the two event packets).  A bracketed launch's duration is
+// its elapsed time minus this.
+extern "C" int cic_timer_bracket_overhead(cic_timer* t, int pairs, double* avg_us, cic_stream_t s) {
+    CIC_REQUIRE(t && pairs > 0 && avg_us);
+    hipStream_t st = cic_s(s);
+    std::vector<hipEvent_t> ev(2 * pairs);
+    for (auto& e : ev) { e = t->event(); CIC_REQUIRE(e != nullptr); }
+    CIC_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < pairs; ++i) {
+        CIC_HIP(hipEventRecord(ev[2 * i], st));
+        CIC_HIP(hipEventRecord(ev[2 * i + 1], st));
+    }
+    CIC_HIP(hipEventSynchronize(ev.back()));
+    double tot = 0.0;
+    for (int i = 0; i < pairs; ++i) {
+        float ms = 0.f;
+        CIC_HIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+        tot += ms;
+    }
+    for (auto e : ev) t->pool.push_back(e);
+    *avg_us = tot * 1e3 / pairs;
+    return 0;
+}
 extern "C" int cic_timer_collect(cic_timer* t, int id, double* total_ms, int* launches) {
     CIC_REQUIRE(t && total_ms && launches && id >= 0 && id < CIC_TIMED_COUNT);
     double tot = 0.0;

@@ -320,6 +320,7 @@ lib.cic_timer_destroy.argtypes = [C.c_void_p]
 lib.cic_timer_destroy.restype = None
 lib.cic_timer_reset.argtypes = [C.c_void_p]
 lib.cic_timer_collect.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+lib.cic_timer_bracket_overhead.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_void_p]
 
 
 class KernelTimer:
@@ -342,6 +343,12 @@ class KernelTimer:
             check(lib.cic_timer_collect(self.handle, i, C.byref(ms), C.byref(n)), 'cic_timer_collect')
             out[name] = dict(ms=ms.value, n=n.value)
         return out
+
+    def bracket_overhead_us(self, pairs=200):
+        """Average elapsed time of an event pair with nothing between its events: subtract it from a bracketed launch."""
+        us = C.c_double(0.0)
+        check(lib.cic_timer_bracket_overhead(self.handle, int(pairs), C.byref(us), stream()), 'cic_timer_bracket_overhead')
+        return us.value
 
     def __del__(self):
         h, self.handle = getattr(self, 'handle', None), None

@@ -45,6 +45,9 @@ cic_timer* cic_timer_create(void);
 void cic_timer_destroy(cic_timer* t);
 int cic_timer_reset(cic_timer* t);
 int cic_timer_collect(cic_timer* t, int id, double* total_ms, int* launches);
+/* average elapsed time (us) of `pairs` back-to-back event pairs with nothing between them on stream s: what the bracket
+ * itself adds to every timed launch (synchronises s) */
+int cic_timer_bracket_overhead(cic_timer* t, int pairs, double* avg_us, cic_stream_t s);
 
 /* ---- RNG (replaces torch.rand / nn.Dropout's bernoulli_ draws) ---------------------- */
 /* Philox4x32-10 counter RNG.  u[i] = (r >> 8) * 2^-24 in [0,1), as torch.rand does
