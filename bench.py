@@ -309,7 +309,7 @@ def main():
                        if isinstance(optimizer_dict.get('speaker'), dict) else None},
             # HBM-bound kernel of the path: the per-timestep attention.  achieved = algorithmic bytes of one launch / the
             # average duration of the in-step launches (HIP events of a cic_timer on the step's stream)
-            'roofline': {'bound': 'hbm', 'kernel': 'attn_fwd_cols_kernel<5,1> (per-timestep top-down attention, 2B images per launch)',
+            'roofline': {'bound': 'hbm', 'kernel': 'attn_fwd_cols_kernel<5, 1, float> (per-timestep top-down attention, 2B images per launch)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': pmc_traffic(n_img), 'avg_launch_us': attn_us, 'launches_timed': micro.get('n', 0),
                          'timing': 'HIP events on the step\'s stream over launches of the step\'s geometry interleaved with a '
@@ -321,7 +321,7 @@ def main():
                          'traffic_source': 'profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_summary.py)'},
             # MFMA-bound kernel of the path: the hidden -> vocabulary logit product (with its fused log-softmax / sampler
             # partials), exact-f32 MFMA
-            'roofline_mfma': {'bound': 'mfma', 'kernel': 'gemm_ldsb2_walk_kernel<32,2,true> (logit product [2B,512]x[512,9488] + row partials)',
+            'roofline_mfma': {'bound': 'mfma', 'kernel': 'gemm_ldsb2_walk_kernel<32, 2, 1> (logit product [2B,512]x[512,9488] + row partials)',
                               'achieved': lg_tf, 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s', 'frac': lg_tf / MFMA_F32_PEAK_TF,
                               'flop_per_launch': lg_flop, 'avg_launch_us': lg_us, 'launches_timed': lg['n'],
                               'timing': 'HIP event brackets around every in-step launch (cic_timer), minus an empty event pair',
