@@ -38,7 +38,7 @@ def decode_tags(cfg, turn, n):
 
 CASES = ['joint_gumbel', 'joint_gumbel_dropout', 'joint_gumbel_tau', 'joint_multinomial', 'joint_reinforce_gt',
          'joint_reinforce_greedy', 'joint_reinforce_no', 'joint_reinforce_listener', 'joint_gumbel_mle',
-         'joint_plain_all', 'joint_gumbel_ps', 'joint_multinomial_ps', 'masked_joint_gumbel']
+         'joint_plain_all', 'joint_gumbel_ps', 'joint_multinomial_ps', 'masked_joint_gumbel', 'fullwidth_joint_gumbel']
 
 
 @pytest.mark.parametrize('name', CASES)
@@ -88,6 +88,13 @@ def test_joint_step_matches_reference(name):
     for k, g in grads.items():
         if 'gdig.' + k not in z and g is not None:
             assert float(g.abs().max()) == 0.0, k
+    if 'tokens0' in z:      # full-width case (BASELINE widths, recorded from the reference): token ids bit for bit
+        for tag, key in (('sample', 'tokens0'), ('greedy', 'tokens1')):
+            ref = z[key]
+            got = model.last_decodes[tag].seq[:, :ref.shape[1]].cpu().numpy()
+            np.testing.assert_array_equal(got, ref, err_msg=tag + ' tokens')
+            assert int(model.last_decodes[tag].seq[:, ref.shape[1]:].abs().max().item() if
+                       model.last_decodes[tag].seq.shape[1] > ref.shape[1] else 0) == 0
     # logged side-channel values (model.loss()) that the reference logged too
     logged = model.loss()
     for k in ('loss_cider', 'cider_greedy', 'avg_reward', 'retrieval_sc_loss', 'loss_cap'):

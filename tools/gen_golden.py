@@ -10,6 +10,7 @@ fixtures are data only.  tests/test_oracle_golden.py replays them against oracle
 
 Usage:  python tools/gen_golden.py            (rewrites tests/golden/*.npz)
         python tools/gen_golden.py --only-masks   (the att_masks cases only)
+        python tools/gen_golden.py --only-fullwidth   (the BASELINE-width joint step only)
 """
 import argparse
 import os
@@ -72,6 +73,7 @@ class Recorder:
         self.torch = torch
         self.events = []
         self.on = False
+        self.inject = None                  # torch.Generator: torch.rand draws from it instead of the global generator
         F = torch.nn.functional
         self._dropout = F.dropout
         self._rand = torch.rand
@@ -92,6 +94,8 @@ class Recorder:
             return input * (keep / (1.0 - p))
 
         def rand(*a, **k):
+            if rec.inject is not None:      # a stream of its own, so that a test can regenerate it call by call
+                k = dict(k, generator=rec.inject)
             u = rec._rand(*a, **k)
             if rec.on:
                 rec.events.append(('rand', u.clone()))
@@ -140,7 +144,7 @@ def unpack_rows(torch, packed, att_masks):
     return out
 
 
-def split_decodes(events, T, B, E, H, Vp1, att_masks=None):
+def split_decodes(events, T, B, E, H, Vp1, att_masks=None, want_steps=False):
     """Split a flat event list into per-decode noise dicts (see oracle/speaker.py).
     A 3-D dropout event (att_embed) opens a new decode; 2-D dropout events then
     alternate x_keep[t], out_keep[t]; rand / multinomial / uniform events belong to
@@ -159,7 +163,7 @@ def split_decodes(events, T, B, E, H, Vp1, att_masks=None):
                        out_keep=np.ones((T, B, H), np.float32),
                        gumbel_u=np.full((T, B, Vp1), 0.5, np.float32),
                        pick=np.zeros((T, B), np.int64), ps_u=np.ones((T, B), np.float32),
-                       _nx=0, _no=0, has_u=False, has_pick=False, has_ps=False)
+                       _nx=0, _no=0, _usteps=[], has_u=False, has_pick=False, has_ps=False)
             decs.append(cur)
         elif kind == 'dropout':
             if cur['_nx'] == cur['_no']:
@@ -170,6 +174,7 @@ def split_decodes(events, T, B, E, H, Vp1, att_masks=None):
                 cur['_no'] += 1
         elif kind == 'rand':
             cur['gumbel_u'][cur['_nx']] = t.numpy()
+            cur['_usteps'].append(cur['_nx'])
             cur['has_u'] = True
         elif kind == 'multinomial':
             cur['pick'][cur['_nx']] = t.numpy()
@@ -182,6 +187,8 @@ def split_decodes(events, T, B, E, H, Vp1, att_masks=None):
         o = dict(att_keep=d['att_keep'], x_keep=d['x_keep'], out_keep=d['out_keep'])
         if d['has_u']:
             o['gumbel_u'] = d['gumbel_u']
+            if want_steps:
+                o['gumbel_u_steps'] = np.array(d['_usteps'], np.int64)
         if d['has_pick']:
             o['pick'] = d['pick']
         if d['has_ps']:
@@ -257,13 +264,14 @@ def widen(cg, batch):
         w.data.mul_(3.0)
     cg.logit.weight.data.mul_(6.0)
     B = batch['att_feats'].shape[0]
-    sc = (0.3 + 0.5 * np.arange(B)).astype(np.float32)
+    sc = (0.3 + 0.5 * (np.arange(B) % 6)).astype(np.float32)
     import torch
     batch['att_feats'] = batch['att_feats'] * torch.from_numpy(sc).view(B, 1, 1)
     if batch.get('att_masks') is not None:
         batch['fc_feats'] = batch['att_feats'].sum(1) / batch['att_masks'].sum(1, keepdim=True)
     else:
         batch['fc_feats'] = batch['att_feats'].mean(1)
+    return sc
 
 
 def sd_np(module, prefix=''):
@@ -277,12 +285,15 @@ def flat_noise(prefix, nd):
 _BASES = {}
 
 
-def base_weights(seed, module):
-    """Store the seeded state dict once; later cases reference it by name."""
-    key = f'weights_s{seed}'
+def base_weights(seed, module, store=True):
+    """Store the seeded state dict once; later cases reference it by name.  store=False (full-width case): the weights
+    stay in memory, the fixture carries the seed and per-parameter digests instead (golden_util.load_case redraws them)."""
+    key = f'weights_s{seed}' if store else f'weights_regen_s{seed}'
     sd = sd_np(module)
     if key not in _BASES:
         _BASES[key] = sd
+        if not store:
+            return key
         os.makedirs(OUT, exist_ok=True)
         path = os.path.join(OUT, key + '.npz')
         if os.path.exists(path):            # same seed, same draws: leave an identical file alone
@@ -326,12 +337,15 @@ def save(name, **arrs):
     print('wrote', name, sum(a.nbytes for a in clean.values()) // 1024, 'KiB')
 
 
-def opt_np(opt):
+WIDTH_KEYS = ['input_encoding_size', 'rnn_size', 'fc_feat_size', 'att_feat_size', 'att_hid_size', 'vse_embed_size']
+
+
+def opt_np(opt, widths=False):
     keys = ['vocab_size', 'seq_length', 'drop_prob_lm', 'gumbel_temp', 'multinomial_temp',
             'prob_gumbel_softmax', 'prob_multinomial_soft', 'decoding_constraint', 'vse_margin',
             'vse_max_violation', 'vse_no_imgnorm', 'vse_use_abs', 'retrieval_reward_weight',
             'cider_optimization', 'caption_loss_weight', 'vse_loss_weight', 'use_gen_cider_scores']
-    d = {'cfg.' + k: np.float64(getattr(opt, k)) for k in keys}
+    d = {'cfg.' + k: np.float64(getattr(opt, k)) for k in keys + (WIDTH_KEYS if widths else [])}
     d['cfg.retrieval_reward'] = np.array(opt.retrieval_reward)
     d['cfg.reinforce_baseline_type'] = np.array(opt.reinforce_baseline_type)
     d['cfg.only_one_retrieval'] = np.array(opt.only_one_retrieval)
@@ -453,6 +467,7 @@ def main():
     rec = Recorder(torch)
     torch.set_num_threads(4)
     only_masks = '--only-masks' in sys.argv     # the att_masks cases only (other fixtures untouched)
+    only_full = '--only-fullwidth' in sys.argv  # the BASELINE-width joint step only
     if '--only-retrieval' in sys.argv:
         gen_retrieval(torch)
         return
@@ -463,10 +478,10 @@ def main():
         gen_beam(torch, models, rec)
         return
 
-    def build(opt, seed=0, eos_bias=None):
+    def build(opt, seed=0, eos_bias=None, store=True):
         torch.manual_seed(seed)
         m = models.AlternatingJointModel(opt)
-        m._wkey = base_weights(seed, m)
+        m._wkey = base_weights(seed, m, store)
         if eos_bias is not None:
             m.caption_generator.logit.bias.data[0] = eos_bias
         return m
@@ -668,24 +683,32 @@ def main():
         ('joint_gumbel_mle', dict(retrieval_reward='gumbel', caption_loss_weight=0.5, use_gen_cider_scores=1), 'speaker', 2.5),
         ('joint_plain_all', dict(retrieval_reward='gumbel', caption_loss_weight=1.0, vse_loss_weight=1.0), None, 2.5),
     ]
-    def joint_case(name, kw, turn, eos, masked=False):
+    U_SEED = 4242
+
+    def joint_case(name, kw, turn, eos, masked=False, regen=False, K=7):
+        # regen (the full-width case): nothing large is stored.  Weights are the seeded draw (seed + digests), features
+        # a seeded draw, the Gumbel uniforms come from a generator of their own (Recorder.inject); golden_util.load_case
+        # redraws all three and checks the digests stored here.
         opt = make_opt(**kw)
-        m = build(opt, 5, None)
+        m = build(opt, 5, None, store=not regen)
         m.train()
-        batch = make_batch(torch, opt, K=7, seed=5)
+        batch = make_batch(torch, opt, K=K, seed=5)
         if masked:
             mask_batch(torch, batch)
         am = batch['att_masks']
         cg = m.caption_generator
         # random-init greedy decodes are knife-edge (never EOS / all EOS at t=1, SURVEY.md
         # Appendix A.16): widen the dynamics so the state, and with it EOS, varies per row
-        widen(cg, batch)
+        rowscale = widen(cg, batch)
         shapes = []
         orig_sample = cg.sample
+
+        tokens = []
 
         def spy(*a, **k):
             r = orig_sample(*a, **k)
             shapes.append((r[0].shape[1], sorted(set((r[0] > 0).sum(1).tolist()))))
+            tokens.append(r[0].detach().numpy().astype(np.int64).copy())
             return r
         cg.sample = spy
 
@@ -699,9 +722,10 @@ def main():
         # greedy decode happens) at least one decode that stops early (L < 16)
         found = None
         import contextlib, io
-        for bias in np.linspace(-1.0, 3.0, 81):
+        for bias in (np.linspace(3.0, 13.0, 41) if regen else np.linspace(-1.0, 3.0, 81)):
             cg.logit.bias.data[0] = float(bias)
             torch.manual_seed(13)
+            rec.inject = torch.Generator().manual_seed(U_SEED) if regen else None
             del shapes[:]
             try:
                 with contextlib.redirect_stdout(io.StringIO()):
@@ -719,17 +743,28 @@ def main():
         if hasattr(m, 'prev_vse'):      # drop the reinforce bookkeeping copies made by the scan
             del m.prev_vse, m.prev_caption_generator, m.prev_gradDic
         del shapes[:]
+        del tokens[:]
         torch.manual_seed(13)
+        rec.inject = torch.Generator().manual_seed(U_SEED) if regen else None
         rec.start()
         loss = run()
         print(name, 'eos bias', found, 'decodes (L, lens):', shapes)
         ev = rec.stop()
+        rec.inject = None
         m.zero_grad()
         loss.backward()
         T = opt.seq_length + 1
-        decs = split_decodes(ev, T, opt.batch_size, opt.input_encoding_size, opt.rnn_size, opt.vocab_size + 1, am)
+        decs = split_decodes(ev, T, opt.batch_size, opt.input_encoding_size, opt.rnn_size, opt.vocab_size + 1, am,
+                             want_steps=regen)
         nz = {}
+        calls = 0
         for i, d in enumerate(decs):
+            if regen and 'gumbel_u' in d:       # [seed, calls made before this decode, calls of this decode] + digest
+                u = d.pop('gumbel_u')
+                steps = d['gumbel_u_steps']
+                d['gumbel_u_regen'] = np.array([U_SEED, calls, len(steps)], np.int64)
+                d['gumbel_u_digest'] = GU.digest(u)
+                calls += len(steps)
             nz.update(flat_noise(f'noise{i}', d))
         grads = digests((k, p.grad) for k, p in m.named_parameters()
                         if not k.startswith('prev_') and p.grad is not None)
@@ -741,14 +776,28 @@ def main():
             except Exception:
                 pass
         print(name, 'loss', float(loss), 'ndecodes', len(decs), 'ngrads', len(grads))
-        save(name, **sd, **opt_np(opt), **nz, **grads, **aux, loss=loss, n_decodes=np.int64(len(decs)),
-             turn=np.array(str(turn)), fc=batch['fc_feats'], att_raw=batch['att_feats'], att_masks=am,
-             labels=batch['labels'], masks=batch['masks'],
+        feats = dict(fc=batch['fc_feats'], att_raw=batch['att_feats'])
+        if regen:
+            B_, K_, D_ = batch['att_feats'].shape
+            feats = {'regen.att': np.array([5, B_, K_, D_], np.int64), 'regen.att_rowscale': rowscale,
+                     'dig.att_raw': GU.digest(batch['att_feats'].numpy()), 'dig.fc': GU.digest(batch['fc_feats'].numpy())}
+            feats.update({'wdig.' + k: GU.digest(v) for k, v in _BASES[m._wkey].items()})
+            feats.update({f'tokens{i}': t for i, t in enumerate(tokens)})
+        save(name, **sd, **opt_np(opt, widths=regen), **nz, **grads, **aux, **feats, loss=loss, n_decodes=np.int64(len(decs)),
+             turn=np.array(str(turn)), att_masks=am, labels=batch['labels'], masks=batch['masks'],
              gts_flat=np.concatenate(batch['gts'], 0), gts_count=np.array([len(x) for x in batch['gts']]))
 
+    # BASELINE.json's widths (configs[2]: 36 x 2048 regions, hidden 512, vocabulary 9487, listener 1024), 32 images
+    FULLWIDTH = dict(retrieval_reward='gumbel', drop_prob_lm=0.5, vocab_size=9487, input_encoding_size=512, rnn_size=512,
+                     fc_feat_size=2048, att_feat_size=2048, att_hid_size=512, vse_embed_size=1024, batch_size=32)
+    if only_full:
+        joint_case('fullwidth_joint_gumbel', FULLWIDTH, 'speaker', 2.5, regen=True, K=36)
+        return
     for name, kw, turn, eos in cases:
         if not only_masks:
             joint_case(name, kw, turn, eos)
+    if not only_masks:
+        joint_case('fullwidth_joint_gumbel', FULLWIDTH, 'speaker', 2.5, regen=True, K=36)
 
     # ------------------------------------------------------------------ O1 clamp + Adam
     def clamp_adam_case():

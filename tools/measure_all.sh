@@ -18,7 +18,7 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_AC
 cd $R
 kt=$(find $out/trace -name '*kernel_trace.csv' | head -1)
 ks=$(find $out/trace -name '*kernel_stats.csv' | head -1)
-python tools/trace_summary.py $kt 10 $out/step_breakdown.md > $out/trace_summary.log
+python tools/trace_summary.py $kt 10 $out/step_breakdown.md $out/step_sequence.txt > $out/trace_summary.log
 cp $ks $out/kernel_stats.csv
 fc=$(find $out/pmc_fetch -name '*counter_collection.csv' | head -1)
 wc=$(find $out/pmc_write -name '*counter_collection.csv' | head -1)

@@ -10,7 +10,7 @@ cd /tmp
 rocprofv3 --kernel-trace --output-format csv -d $out/trace -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --profile-steps 0 > $out/bench_rocprof.json 2> $out/trace.err
 cd $R
 kt=$(find $out/trace -name '*kernel_trace.csv' | head -1)
-python tools/trace_summary.py $kt 10 $out/step_breakdown.md > $out/trace_summary.log
+python tools/trace_summary.py $kt 10 $out/step_breakdown.md $out/step_sequence.txt > $out/trace_summary.log
 rm -rf $out/trace
 python bench.py --steps 30 --warmup 5 --no-cpu-baseline > $out/bench.json 2>/dev/null
 grep -o 'ms_per_step": [0-9.]*' $out/bench.json

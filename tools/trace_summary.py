@@ -3,7 +3,8 @@
 clamp_adam launches (two per step), the last `steps` steps are kept (warm-up and the roofline timing loop after the
 timed region are left out), and the attention kernel is reported separately for the in-step launches.
 
-usage: trace_summary.py <kernel_trace.csv> <steps> [out.md]"""
+usage: trace_summary.py <kernel_trace.csv> <steps> [out.md] [sequence.txt]
+sequence.txt: every launch of the last step in order (start offset, duration, gap since the previous kernel ended)."""
 import collections
 import csv
 import sys
@@ -40,6 +41,13 @@ def main():
     print(text)
     if len(sys.argv) > 3:
         open(sys.argv[3], 'w').write(text + '\n')
+    if len(sys.argv) > 4:
+        last = ev[adam[-3] + 1:adam[-1] + 1]
+        with open(sys.argv[4], 'w') as f:
+            prev = last[0][0]
+            for e in last:
+                f.write(f'{(e[0] - last[0][0]) / 1e3:9.1f} us  dur {(e[1] - e[0]) / 1e3:7.1f}  gap {(e[0] - prev) / 1e3:6.1f}  grid {e[3]:8d}  {e[2][:110]}\n')
+                prev = e[1]
 
 
 if __name__ == '__main__':
