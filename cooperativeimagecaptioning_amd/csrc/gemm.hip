@@ -1234,6 +1234,125 @@ __global__ __launch_bounds__(KS * 64) void gemm_walk16_kernel(cic_gemm_args g, i
     }
 }
 
+// The 16-wide strip walker on bf16 parts (f32 results, see split_bf16 / gemm_bfx_kernel): v_mfma_f32_16x16x32_bf16 runs
+// 16x the K per instruction of the f32 MFMA, six part products replace one f32 product (2.67x the MFMA rate), and the
+// split of a B fragment (13 VALU instructions per two floats) frees its raw registers at once, so the next tile's
+// loads are in flight under this tile's MFMAs AND the cross-wave sum.  Same work split and output order as
+// gemm_walk16_kernel<8, 8, false>; K slice per wave = 128 = 4 k-steps of 32 (Kt == 1024, K1 % 32 == 0: no K padding).
+//   operand layout: lane l -> (i = l & 15, q = l >> 4); A: row i, k = 32 j + 8 q + 0..7 for k-step j (two dwordx4);
+//   B: column i likewise; D: 4 registers v: row 4q + v, column i.
+template <int KS>
+__global__ __launch_bounds__(KS * 64) void gemm_walk16bf_kernel(cic_gemm_args g, int strips) {
+    static_assert(KS == 8, "8 accumulator registers (2 row tiles x 4) dealt one per wave");
+    constexpr int JS = 4;                                   // k-steps per wave
+    __shared__ float red[2 * KS * 8 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, ks = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
+    const int li = lane & 15, lq = lane >> 4;
+    const int tiles_n = (g.N + 15) / 16;
+    const int step = gridDim.x / strips;                     // walkers per strip, a multiple of 8 (XCD sharing)
+    const int first = blockIdx.x % step, strip = blockIdx.x / step;
+    int m0 = strip * 32;
+    const bool blk2 = g.rows_blk > 0 && m0 >= g.rows_blk;   // row blocks: see gemm_rega_kernel
+    const float* __restrict__ gA = blk2 ? g.A_b : g.A;
+    const float* __restrict__ gA2 = blk2 ? g.A2_b : g.A2;
+    float* __restrict__ gC = blk2 ? g.C_b : g.C;
+    const int Mloc = g.rows_blk > 0 ? (blk2 ? g.M - g.rows_blk : min(g.M, g.rows_blk)) : g.M;
+    if (blk2) m0 -= g.rows_blk;
+    const int K1 = g.K;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    auto parts8 = [](const f32x4 lo, const f32x4 hi, bf16x8 (&dst)[3][JS], int j) {
+        bf16x4 pl[3], ph[3];
+        split_bf16<3>(lo, pl);
+        split_bf16<3>(hi, ph);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) dst[p][j] = __builtin_shufflevector(pl[p], ph[p], 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    bf16x8 ap[2][3][JS];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int m = m0 + 16 * rt + li;
+        const bool mok = m < Mloc;
+        const int mc = mok ? m : Mloc - 1;
+#pragma unroll
+        for (int j = 0; j < JS; ++j) {
+            const int k0 = 32 * (ks * JS + j);             // wave-uniform
+            const bool second = k0 >= K1;
+            const float* src = (second ? gA2 : gA) + (size_t)mc * (second ? g.lda2 : g.lda) + (second ? k0 - K1 : k0) + 8 * lq;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+            parts8(mok ? lo : z4, mok ? hi : z4, ap[rt], j);
+        }
+    }
+    f32x4 raw[2 * JS];
+    // column split (see cic.h): tiles at or beyond n_split take the second operand pair only, from B2_tail
+    const int split_t = g.n_split > 0 ? g.n_split / 16 : tiles_n;
+    auto load_raw = [&](int t) {
+        const int tt = t < tiles_n ? t : tiles_n - 1;
+        const int n = tt * 16 + li;
+        const bool nok = t < tiles_n && n < g.N;
+        const int nc = n < g.N ? n : g.N - 1;
+        const bool tail = tt >= split_t;
+#pragma unroll
+        for (int j = 0; j < JS; ++j) {
+            const int k0 = 32 * (ks * JS + j);             // wave-uniform: the operand choice stays in scalar registers
+            const bool second = k0 >= K1;
+            const float* B = second ? (tail ? g.B2_tail : g.B2) : g.B;
+            const int ldb = second ? (tail ? g.ldb2_tail : g.ldb2) : g.ldb;
+            const int row = tail ? nc - g.n_split : nc;
+            const bool use = nok && (second || !tail);
+            // unused fragments (padding, and the first pair's K slices of tail tiles) read a block of zeros
+            const float* pb = use ? B + (size_t)row * ldb + (second ? k0 - K1 : k0) + 8 * lq : g_zero16;
+            raw[2 * j] = *reinterpret_cast<const f32x4*>(pb);
+            raw[2 * j + 1] = *reinterpret_cast<const f32x4*>(pb + 4);
+        }
+    };
+    load_raw(first);
+    // the output this wave finishes: accumulator register ks of the 8 -> row tile ks >> 2, register ks & 3
+    const int mm = m0 + 16 * (ks >> 2) + 4 * lq + (ks & 3);
+    const int mcl = mm < Mloc ? mm : Mloc - 1;
+    int buf = 0;
+#pragma unroll 1
+    for (int t = first; t < tiles_n; t += step) {
+        const int n = t * 16 + li;
+        const int ncl = n < g.N ? n : g.N - 1;
+        float bias_v = 0.f, cold = 0.f;                 // epilogue operands fetched before the barrier
+        const bool tail = t >= split_t;
+        if (tail) { if (g.bias_tail) bias_v = g.bias_tail[ncl - g.n_split]; }
+        else if (g.bias) bias_v = g.bias[ncl];
+        if (g.accumulate && !tail) cold = gC[(size_t)mcl * g.ldc + ncl];
+        bf16x8 bp[3][JS];
+#pragma unroll
+        for (int j = 0; j < JS; ++j) parts8(raw[2 * j], raw[2 * j + 1], bp, j);
+        load_raw(t + step);                             // next tile in flight under the MFMAs and the cross-wave sum
+        f32x4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        // part products with pa + pb <= 2, smallest first (parts 0 / 1 / 2 carry bits 1-8 / 9-16 / 17-24)
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+#pragma unroll
+            for (int j = 0; j < JS; ++j) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[0][PA[c]][j], bp[PB[c]][j], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[1][PA[c]][j], bp[PB[c]][j], acc1, 0, 0, 0);
+            }
+        float* rb = red + buf * (KS * 8 * 64);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            rb[(ks * 8 + v) * 64 + lane] = acc0[v];
+            rb[(ks * 8 + 4 + v) * 64 + lane] = acc1[v];
+        }
+        __syncthreads();
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < KS; ++w) v += rb[(w * 8 + ks) * 64 + lane];
+        v += bias_v + cold;
+        if (g.relu) v = fmaxf(v, 0.f);
+        if (mm < Mloc && n < g.N) {
+            if (tail) (blk2 ? g.C_tail_b : g.C_tail)[(size_t)mm * g.ldc_tail + (n - g.n_split)] = v;
+            else gC[(size_t)mm * g.ldc + n] = v;
+        }
+        buf ^= 1;
+    }
+}
+
 // Column walker with the weight tile in LDS (the logit product, K = 16*NG = 512): NO K split, so no cross-wave sum.
 // A workgroup of 4 waves (one per SIMD) owns 64 rows: wave w keeps the MFMA A fragments of its 16 rows for the WHOLE
 // K in registers (K/4 VGPRs per lane) and the workgroup walks 16-column weight tiles.  A tile [16 x K] is staged in LDS
@@ -1723,7 +1842,12 @@ int launch_rega(const cic_gemm_args& g, hipStream_t st) {
         if (nb > t16) nb = t16;
         if (nb >= 8) nb &= ~7;
         if (nb < 1) nb = 1;
-        hipLaunchKernelGGL((gemm_walk16_kernel<8, 8, false>), dim3(strips * nb), dim3(512), 0, st, g, strips);
+        // f32 results either way: three bf16 parts per operand (2.67x the MFMA rate) unless the caller asks for the
+        // f32-input instruction
+        if (g_bfx && g.precision != CIC_PRECISION_F32_MFMA && (g.K % 32) == 0)
+            hipLaunchKernelGGL((gemm_walk16bf_kernel<8>), dim3(strips * nb), dim3(512), 0, st, g, strips);
+        else
+            hipLaunchKernelGGL((gemm_walk16_kernel<8, 8, false>), dim3(strips * nb), dim3(512), 0, st, g, strips);
         CIC_LAUNCH_CHECK();
         return 0;
     }

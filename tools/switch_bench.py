@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""A/B timing of the bench step under a dispatch switch word of the development build (include/cic_dev.h,
+cic_debug_gemm_tail_split): usage: switch_bench.py <word> [<word> ...]   e.g. 1  0x8000001 (bit 27: no fused epilogue)."""
+import ctypes as C
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _devlib  # noqa: F401,E402
+import torch
+from cooperativeimagecaptioning_amd import models, optimizer as optim, synthetic
+from cooperativeimagecaptioning_amd._lib import lib
+from cooperativeimagecaptioning_amd.misc import rewards
+
+
+def main():
+    words = [int(w, 0) for w in sys.argv[1:]] or [1]
+    opt = synthetic.default_opt(batch_size=128)
+    torch.manual_seed(0)
+    rewards.init_scorer('corpus')
+    model = models.AlternatingJointModel(opt).cuda().train()
+    od = optim.load_optimizer(model, opt)
+    o = od['speaker']
+    b = synthetic.make_batch(opt, seed=1, device='cuda')
+    lib.cic_debug_gemm_tail_split.argtypes = [C.c_int]
+
+    def run(n):
+        for _ in range(n):
+            optim.zeroing_optimizer(opt, od, o)
+            loss = model(b['fc_feats'], b['labels'], b['masks'], b, b['att_feats'], b['att_masks'], is_alternating=True,
+                         alternating_turn='speaker')
+            loss.backward()
+            optim.update_optimizer(od, o, opt)
+    for rep in range(2):
+        for w in words:
+            lib.cic_debug_gemm_tail_split(w)
+            run(5)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(30)
+            torch.cuda.synchronize()
+            print(f'switch word {w:#x}: {(time.perf_counter() - t0) / 30 * 1e3:.3f} ms/step', flush=True)
+
+
+if __name__ == '__main__':
+    main()
