@@ -153,7 +153,7 @@ def pmc_mfma_util():
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE ... of this same command), or None before that pass exists."""
     doc = _profile_doc(['r02_pmc_mfma.json'])
     for k in (doc or {}).get('kernels', []):
-        if k['kernel'].startswith('gemm_ldsb2_walk_kernel'):
+        if k['kernel'].startswith('gemm_ldsb2'):
             return k.get('mfma_util')
     return None
 
@@ -321,7 +321,8 @@ def main():
                          'traffic_source': 'profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_summary.py)'},
             # MFMA-bound kernel of the path: the hidden -> vocabulary logit product (with its fused log-softmax / sampler
             # partials), exact-f32 MFMA
-            'roofline_mfma': {'bound': 'mfma', 'kernel': 'gemm_ldsb2_walk_kernel<32, 2, 1> (logit product [2B,512]x[512,9488] + row partials)',
+            'roofline_mfma': {'bound': 'mfma', 'kernel': 'gemm_ldsb2bf_walk_kernel<32, 1> (logit product [2B,512]x[512,9488] + row partials; f32 results from six '
+                                        'bf16-part products per k on v_mfma_f32_16x16x32_bf16, priced against the f32 MFMA peak)',
                               'achieved': lg_tf, 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s', 'frac': lg_tf / MFMA_F32_PEAK_TF,
                               'flop_per_launch': lg_flop, 'avg_launch_us': lg_us, 'launches_timed': lg['n'],
                               'timing': 'HIP event brackets around every in-step launch (cic_timer), minus an empty event pair',

@@ -1753,6 +1753,268 @@ __global__ __launch_bounds__(256 * KH) __attribute__((amdgpu_waves_per_eu(KH, KH
     }
 }
 
+// The eight-wave logit walker on bf16 parts (f32 results: split_bf16, six part products per k-step on
+// v_mfma_f32_16x16x32_bf16, 2.67x the MFMA rate of the f32-input instruction).  Same work split, roles, epilogue and
+// output order as gemm_ldsb2_walk_kernel<NG, 2, EPI>; what changes is the operand path: the staged weight tile is split
+// on its way into LDS (three bf16 images of [16 columns][K + 8], rows 1040 bytes apart: conflict-free ds_read_b128), a
+// wave reads the three parts of a k-step (32 k) one step ahead of the MFMAs that use them, and its A fragments are the
+// three parts of its K half (96 VGPRs).  Terms of like magnitude share an accumulator chain (parts 0x2, 2x0, 1x1 | 0x1,
+// 1x0 | 0x0), the chains are added smallest first.
+template <int NG, int EPI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_ldsb2bf_walk_kernel(
+    cic_gemm_args g, int row_groups, int walkers, cic_logit_epilogue epi) {
+    constexpr int KH = 2, K = 16 * NG, NT = 512;
+    constexpr int LDBH = K + 8, PART = 16 * LDBH, TILEH = 3 * PART;   // bf16 per staged row / part / tile
+    constexpr int JS = K / KH / 32;                        // k-steps of 32 per wave
+    constexpr int F4 = 16 * (K / 4) / NT;                  // float4 per thread and staged tile
+    static_assert(F4 <= JS && (TILEH % 8) == 0, "the staged float4 ride behind the last k-steps of a tile");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __bf16* ldsh = reinterpret_cast<__bf16*>(lds);
+    float* pairbuf = lds + TILEH;                          // (2 tiles of TILEH bf16 = TILEH floats) [2 parities][4 row tiles][1 upper part][4 registers][64 lanes]
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
+    const int rt = w & 3, kh = w >> 2;                     // row tile, K half
+    const int li = lane & 15, lq = lane >> 4;
+    const int per_xcd = gridDim.x / 8;
+    const int wg = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * per_xcd + blockIdx.x / 8 : blockIdx.x;
+    const int rg = wg % row_groups, first = wg / row_groups;
+    if (first >= walkers) return;                          // whole workgroup: no barrier is skipped by a part of it
+    const int tiles_n = (g.N + 15) / 16;
+    const int rg_a = g.rows_blk > 0 ? (g.rows_blk + 63) / 64 : row_groups;
+    const bool blk2 = rg >= rg_a;
+    const int m0 = (blk2 ? rg - rg_a : rg) * 64;
+    const float* __restrict__ gA = blk2 ? g.A_b : g.A;
+    float* __restrict__ gC = blk2 ? g.C_b : g.C;
+    const int Mloc = g.rows_blk > 0 ? (blk2 ? g.M - g.rows_blk : min(g.M, g.rows_blk)) : g.M;
+    const int m = m0 + 16 * rt + li;
+    const int mc = m < Mloc ? m : Mloc - 1;                // rows beyond M re-read row M-1: never stored
+    f32x4 stg[F4];
+    auto load_tile = [&](int t) {
+        const int tt = t < tiles_n ? t : tiles_n - 1;
+#pragma unroll
+        for (int e = 0; e < F4; ++e) {
+            const int j = tid + NT * e;
+            const int r = j / (K / 4), c4 = j % (K / 4);
+            const int n = tt * 16 + r;
+            const int nc = n < g.N ? n : g.N - 1;
+            stg[e] = *reinterpret_cast<const f32x4*>(g.B + (size_t)nc * g.ldb + 4 * c4);
+        }
+    };
+    auto store_piece = [&](__bf16* dst, int e) {          // four k of one column -> the three bf16 images
+        const int j = tid + NT * e;
+        const int r = j / (K / 4), c4 = j % (K / 4);
+        bf16x4 parts[3];
+        split_bf16<3>(stg[e], parts);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x4*>(dst + p * PART + r * LDBH + 4 * c4) = parts[p];
+    };
+    load_tile(first);
+    bf16x8 ap[3][JS];
+    {
+        const float* arow = gA + (size_t)mc * g.lda + (K / KH) * kh + 8 * lq;
+#pragma unroll
+        for (int j = 0; j < JS; ++j) {
+            bf16x4 pl[3], ph[3];
+            split_bf16<3>(*reinterpret_cast<const f32x4*>(arow + 32 * j), pl);
+            split_bf16<3>(*reinterpret_cast<const f32x4*>(arow + 32 * j + 4), ph);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) ap[p][j] = __builtin_shufflevector(pl[p], ph[p], 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < F4; ++e) store_piece(ldsh, e);
+    __syncthreads();
+    int buf = 0;
+    float prev[4];                                         // the previous tile's sums of this wave's K half
+    int prev_n = -1;
+    float prev_bias = 0.f;
+    // ---- fused epilogue (EPI).  Two software pipelines ride in the 16 slots between the MFMA groups of a tile:
+    //   upper-half wave (kh == 1): the Gumbel noise of THIS tile's 4 rows x 1 column per lane - one Philox call per lane
+    //     (lane c of a quad draws the four uniforms of row 4*lq + c at the quad's four columns, one round per slot), a 4x4
+    //     transpose inside the quad (DPP), -log(-log u) - parked in LDS for the lower-half wave (tests inject U instead);
+    //   lower-half wave (kh == 0): finishes the PREVIOUS tile's logits (lower + upper + bias, stored raw) and feeds them,
+    //     with that noise, to the running partial of their row: one (row, column) per slot group, straight-line code.
+    const cic_logit_epi_rows er = epi.blk[blk2 ? 1 : 0];
+    float* noisebuf = pairbuf + 2 * 4 * (KH - 1) * 4 * 64;  // [2 parities][4 row tiles][4 registers][64 lanes]
+    RowPart rp[4];
+    int cons[4];
+    float gprev[4] = {0.f, 0.f, 0.f, 0.f};
+    PhiloxState phs;
+    float uq[4] = {0.5f, 0.5f, 0.5f, 0.5f}, u4[4] = {0.5f, 0.5f, 0.5f, 0.5f};
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { rp[v].init(); cons[v] = -1; }
+    phs.init(0, 0);
+    if (EPI && kh == 0 && er.cons_seq) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int mm = m0 + 16 * rt + 4 * lq + v;
+            cons[v] = er.cons_seq[(size_t)(mm < Mloc ? mm : Mloc - 1) * er.cons_ld + er.cons_col];
+        }
+    }
+    // ROLE: 0 = no epilogue (every wave; the lower halves store their rows); with EPI: 1 = lower-half wave (MODE = its rows'
+    // sampling mode), 2 / 3 = upper-half wave making the noise from the Philox stream / from injected uniforms, 4 = an upper
+    // wave with nothing to add.  One straight-line loop body per role: no wave-uniform branch inside the MFMA stream.
+    auto walk = [&](auto role_, auto mode_) {
+        constexpr int ROLE = decltype(role_)::value, MODE = decltype(mode_)::value;
+        auto noise_slot = [&](int sl, int n) {             // slot sl of 16, tile column n of this lane
+            if (ROLE == 3) {                               // injected uniforms (tests)
+                if (sl == 0) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int mm = m0 + 16 * rt + 4 * lq + v;
+                        uq[v] = er.U[(size_t)(mm < Mloc ? mm : Mloc - 1) * er.ldu + (n < g.N ? n : g.N - 1)];
+                    }
+                }
+            } else if (sl == 0) {
+                const int c = li & 3;
+                const int qrow = m0 + 16 * rt + 4 * lq + c;
+                phs.init((er.elem0 + (uint64_t)qrow * (uint64_t)er.ldu + (uint64_t)(n - c)) >> 2, er.seed);   // the quad's 4 columns
+            } else if (sl <= 5) {
+                phs.round();
+                phs.round();
+            } else if (sl <= 9) {
+                // 4x4 transpose inside the quad, one destination register per slot: lane c takes element c of quad lane V
+                const int c = li & 3;
+                if (sl == 6) { u4[0] = u32_to_unit(phs.c0); u4[1] = u32_to_unit(phs.c1); u4[2] = u32_to_unit(phs.c2); u4[3] = u32_to_unit(phs.c3); }
+#define QB(x, V) dpp_f32<(V) * 0x55>(x)                        /* quad_perm [V,V,V,V]: lane V of the quad to all four */
+#define PICK(V) { const float b0 = QB(u4[0], V), b1 = QB(u4[1], V), b2 = QB(u4[2], V), b3 = QB(u4[3], V);          \
+                  uq[V] = c == 0 ? b0 : (c == 1 ? b1 : (c == 2 ? b2 : b3)); }
+                if (sl == 6) PICK(0)
+                if (sl == 7) PICK(1)
+                if (sl == 8) PICK(2)
+                if (sl == 9) PICK(3)
+#undef PICK
+#undef QB
+            }
+            if (sl >= 10 && sl <= 13) noisebuf[((buf * 4 + rt) * 4 + (sl - 10)) * 64 + lane] = gumbel_from_u(uq[sl - 10]);
+        };
+        auto finish_row = [&](int v) {                     // lower-half waves: output register v of the previous tile
+            const int mm = m0 + 16 * rt + 4 * lq + v;
+            if ((ROLE == 1 || kh == 0) && prev_n >= 0) {
+                float x = prev[v];
+#pragma unroll
+                for (int u = 0; u < KH - 1; ++u) x += pairbuf[((((buf ^ 1) * 4 + rt) * (KH - 1) + u) * 4 + v) * 64 + lane];
+                x += prev_bias;
+                if (mm < Mloc && prev_n < g.N) {
+                    gC[(size_t)mm * g.ldc + prev_n] = x;
+                    if (ROLE == 1) {
+                        const float xe = prev_n == cons[v] ? -INFINITY : x;      // decoding constraint, AttModel.py:438-442
+                        rowpart_add_m<MODE>(rp[v], er.inv_temp, xe, gprev[v], prev_n);
+                    }
+                }
+            }
+        };
+        auto load_noise = [&]() {
+            if (er.noise && prev_n >= 0) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) gprev[v] = noisebuf[(((buf ^ 1) * 4 + rt) * 4 + v) * 64 + lane];
+            }
+        };
+#pragma unroll 1
+        for (int t = first; t < tiles_n; t += walkers) {
+            load_tile(t + walkers);                        // next tile's rows in flight under this tile's MFMAs
+            const int n = t * 16 + li;
+            const int ncl = n < g.N ? n : g.N - 1;
+            float bias_v = 0.f;
+            if (g.bias) bias_v = g.bias[ncl];
+            const __bf16* bt = ldsh + buf * TILEH + li * LDBH + (K / KH) * kh + 8 * lq;
+            __bf16* nxt = ldsh + (buf ^ 1) * TILEH;        // every wave left this buffer before the last barrier
+            f32x4acc aS = {0.f, 0.f, 0.f, 0.f}, aM = {0.f, 0.f, 0.f, 0.f}, aB = {0.f, 0.f, 0.f, 0.f};
+            bf16x8 bq[2][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bq[0][p] = *reinterpret_cast<const bf16x8*>(bt + p * PART);
+#pragma unroll
+            for (int j = 0; j < JS; ++j) {
+                if (j + 1 < JS) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bq[(j + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(bt + p * PART + 32 * (j + 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 b0 = bq[j & 1][0], b1 = bq[j & 1][1], b2 = bq[j & 1][2];
+                aS = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[0][j], b2, aS, 0, 0, 0);
+                aM = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[0][j], b1, aM, 0, 0, 0);
+                aB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[0][j], b0, aB, 0, 0, 0);
+                aS = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[2][j], b0, aS, 0, 0, 0);
+                aM = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[1][j], b0, aM, 0, 0, 0);
+                aS = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[1][j], b1, aS, 0, 0, 0);
+                if (ROLE == 0) {
+                    if (j < 4) { finish_row(j); __builtin_amdgcn_sched_barrier(0); }
+                } else if (ROLE != 4) {
+                    // 16 slots spread over the JS k-steps of the tile
+#pragma unroll
+                    for (int sl = j * 16 / JS; sl < (j + 1) * 16 / JS; ++sl) {
+                        if (ROLE == 1) {
+                            if (sl == 0) load_noise();
+                            if ((sl & 3) == 1) finish_row(sl >> 2);
+                        } else {
+                            noise_slot(sl, n);
+                        }
+                    }
+                    if (ROLE == 1) __builtin_amdgcn_sched_barrier(0);   // the lower wave's slots stay between the k-steps
+                }
+                if (j >= JS - F4) { store_piece(nxt, j - (JS - F4)); __builtin_amdgcn_sched_barrier(0); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) prev[v] = (aS[v] + aM[v]) + aB[v];
+            if (kh >= 1) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) pairbuf[(((buf * 4 + rt) * (KH - 1) + (kh - 1)) * 4 + v) * 64 + lane] = prev[v];
+            }
+            prev_n = n;
+            prev_bias = bias_v;
+            __syncthreads();
+            buf ^= 1;
+        }
+        if (ROLE == 1) load_noise();
+        if (ROLE == 0 || ROLE == 1) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) finish_row(v);
+        }
+    };
+    using std::integral_constant;
+    if (!EPI) {
+        walk(integral_constant<int, 0>{}, integral_constant<int, 0>{});
+    } else if (kh == 0) {
+        switch (er.mode) {
+            case CIC_SAMPLE_NONE: walk(integral_constant<int, 1>{}, integral_constant<int, CIC_SAMPLE_NONE>{}); break;
+            case CIC_SAMPLE_GREEDY: walk(integral_constant<int, 1>{}, integral_constant<int, CIC_SAMPLE_GREEDY>{}); break;
+            case CIC_SAMPLE_GUMBEL_ST: walk(integral_constant<int, 1>{}, integral_constant<int, CIC_SAMPLE_GUMBEL_ST>{}); break;
+            case CIC_SAMPLE_MULTINOMIAL_ST: walk(integral_constant<int, 1>{}, integral_constant<int, CIC_SAMPLE_MULTINOMIAL_ST>{}); break;
+            default: walk(integral_constant<int, 1>{}, integral_constant<int, CIC_SAMPLE_MULTINOMIAL>{}); break;   // + TEACHER
+        }
+    } else if (kh == 1 && er.noise) {
+        if (er.U) walk(integral_constant<int, 3>{}, integral_constant<int, 0>{});
+        else walk(integral_constant<int, 2>{}, integral_constant<int, 0>{});
+    } else {
+        walk(integral_constant<int, 4>{}, integral_constant<int, 0>{});
+    }
+    if (EPI && kh == 0) {
+        // the 16 lanes of a row group (same lq: one DPP row) hold the 16 columns of every tile: all-reduce them with DPP
+        // lane exchanges (xor 1, xor 2, mirror within 8, mirror within 16 - no LDS crossbar), lane li == 0 writes
+#define RP_STEP(CTRL)                                                                                              \
+    {                                                                                                              \
+        RowPart q;                                                                                                 \
+        q.m1 = dpp_f32<CTRL>(rp[v].m1); q.s1 = dpp_f32<CTRL>(rp[v].s1);                                              \
+        q.kbest = dpp_f32<CTRL>(rp[v].kbest); q.xbest = dpp_f32<CTRL>(rp[v].xbest);                                  \
+        q.kidx = __float_as_int(dpp_f32<CTRL>(__int_as_float(rp[v].kidx))); q.s2 = dpp_f32<CTRL>(rp[v].s2);         \
+        rowpart_merge(rp[v], er.mode, er.inv_temp, q);                                                             \
+    }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            RP_STEP(DPP_QUAD_XOR1) RP_STEP(DPP_QUAD_XOR2) RP_STEP(DPP_ROW_HALF_MIRROR) RP_STEP(DPP_ROW_MIRROR)
+            const int mm = m0 + 16 * rt + 4 * lq + v;
+            if (li == 0 && mm < Mloc && er.part) {
+                const size_t plane = (size_t)er.part_rows * walkers;
+                float* pp = er.part + (size_t)mm * walkers + first;
+                pp[0] = rp[v].m1; pp[plane] = rp[v].s1; pp[2 * plane] = rp[v].kbest; pp[3 * plane] = rp[v].xbest;
+                pp[4 * plane] = __int_as_float(rp[v].kidx); pp[5 * plane] = rp[v].s2;
+            }
+        }
+#undef RP_STEP
+    }
+}
+
 bool ldsb_walk_ok(const cic_gemm_args& g) {
     return g.a_kc && g.b_kc && g.K2 == 0 && g.K == 512 && g.N >= 2048 && !g.accumulate && !g.relu &&
            (g.lda & 3) == 0 && (g.ldb & 3) == 0 && aligned16(g.A) && aligned16(g.B) && (g.rows_blk == 0 || aligned16(g.A_b));
@@ -1794,6 +2056,24 @@ int launch_ldsb_walk(const cic_gemm_args& g, hipStream_t st) {
         }
         cic_logit_epilogue epi = {};
         if (g.epi) epi = *g.epi;
+        if (g_ldsb2 == 2 && g_bfx && g.precision != CIC_PRECISION_F32_MFMA) {
+            // bf16-part form (f32 results): two tiles of three bf16 images + the two hand-off buffers
+            constexpr size_t bf_bytes = 2 * 3 * 16 * (16 * NG + 8) * 2 + 2 * 4 * 1 * 4 * 64 * sizeof(float) + 2 * 4 * 4 * 64 * sizeof(float);
+            static bool attr3_set = false;
+            if (!attr3_set) {
+                CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2bf_walk_kernel<NG, 0>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf_bytes));
+                CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2bf_walk_kernel<NG, 1>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf_bytes));
+                attr3_set = true;
+            }
+            if (g.epi)
+                hipLaunchKernelGGL((gemm_ldsb2bf_walk_kernel<NG, 1>), dim3(grid), dim3(512), bf_bytes, st, g, row_groups, walkers, epi);
+            else
+                hipLaunchKernelGGL((gemm_ldsb2bf_walk_kernel<NG, 0>), dim3(grid), dim3(512), bf_bytes, st, g, row_groups, walkers, epi);
+            CIC_LAUNCH_CHECK();
+            return 0;
+        }
         if (g.epi) {
             if (g_ldsb2 == 2)
                 hipLaunchKernelGGL((gemm_ldsb2_walk_kernel<NG, 2, 1>), dim3(grid), dim3(512), lds2_bytes, st, g, row_groups, walkers, epi);
