@@ -258,10 +258,16 @@ __global__ void reward_kernel(const double* __restrict__ scores, int B, float* _
     }
 }
 
-__global__ void ref_img_kernel(const int32_t* __restrict__ ref_off, int n_images, int32_t* __restrict__ ref_img) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_images) return;
-    for (int r = ref_off[i]; r < ref_off[i + 1]; ++r) ref_img[r] = i;
+// one launch readies the step's tables: empty hash table (keys all ones, document frequencies 0), the bad-token flag,
+// and the image of every reference
+__global__ __launch_bounds__(256) void cider_init_kernel(const int32_t* __restrict__ ref_off, int n_images,
+                                                         int32_t* __restrict__ ref_img, uint64_t* __restrict__ ht_keys,
+                                                         int32_t* __restrict__ ht_df, uint32_t ht_size, int32_t* __restrict__ bad) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ht_size) { ht_keys[i] = ~0ull; ht_df[i] = 0; }
+    if (i == 0) *bad = 0;
+    if (i < (uint32_t)n_images)
+        for (int r = ref_off[i]; r < ref_off[i + 1]; ++r) ref_img[r] = i;
 }
 
 struct CidWs {
@@ -312,11 +318,8 @@ extern "C" int cic_ciderd_reward(const cic_ciderd_args* a, void* ws, size_t ws_b
     hipStream_t st = cic_s(s);
     const int B = a->B, R = a->R, S = 2 * B + R;
     Sents sn = {a->gen, a->greedy, a->refs, a->L_gen, a->L_greedy, B, a->T, R, a->Tr};
-    CIC_HIP(hipMemsetAsync(w.ht_keys, 0xFF, sizeof(uint64_t) * w.ht_size, st));
-    CIC_HIP(hipMemsetAsync(w.ht_df, 0, sizeof(int32_t) * w.ht_size, st));
-    CIC_HIP(hipMemsetAsync(w.bad, 0, sizeof(int32_t), st));
-    hipLaunchKernelGGL(ref_img_kernel, dim3(cic_cdiv(a->n_images, 256)), dim3(256), 0, st, a->ref_off, a->n_images,
-                       w.ref_img);
+    hipLaunchKernelGGL(cider_init_kernel, dim3(cic_cdiv((int)(w.ht_size > (uint32_t)a->n_images ? w.ht_size : (uint32_t)a->n_images), 256)),
+                       dim3(256), 0, st, a->ref_off, a->n_images, w.ref_img, w.ht_keys, w.ht_df, w.ht_size, w.bad);
     hipLaunchKernelGGL(ngram_kernel, dim3(cic_cdiv(S, 4)), dim3(256), 0, st, sn, S, a->vocab_size + 1, w.keys, w.cnt, w.nuniq,
                        w.blen, w.bad);
     // every image's reference set is seen by 2*spi hypothesis entries (sampled + greedy halves, rewards.py:53-56)

@@ -121,12 +121,50 @@ __global__ __launch_bounds__(256) void keep_kernel(uint8_t* __restrict__ keep, i
     for (int j = 0; j < 4 && i + j < n; ++j) keep[i + j] = u32_to_unit(r.v[j]) >= p ? 1 : 0;
 }
 
+struct KeepSegs {
+    uint8_t* keep[CIC_KEEP_MAX_SEGMENTS];
+    int64_t n[CIC_KEEP_MAX_SEGMENTS];
+    uint64_t offset[CIC_KEEP_MAX_SEGMENTS];
+    int first_block[CIC_KEEP_MAX_SEGMENTS + 1];     // blocks of segment i: [first_block[i], first_block[i + 1])
+    int count;
+};
+
+__global__ __launch_bounds__(256) void keep_multi_kernel(KeepSegs sg, float p, uint64_t seed) {
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < CIC_KEEP_MAX_SEGMENTS; ++k)
+        if (k < sg.count && (int)blockIdx.x >= sg.first_block[k]) i = k;
+    const int64_t q = (int64_t)(blockIdx.x - sg.first_block[i]) * blockDim.x + threadIdx.x;
+    const int64_t e = q * 4, n = sg.n[i];
+    if (e >= n) return;
+    uint8_t* keep = sg.keep[i];
+    Philox4 r = philox4x32_10(sg.offset[i] + (uint64_t)q, seed);
+    for (int j = 0; j < 4 && e + j < n; ++j) keep[e + j] = u32_to_unit(r.v[j]) >= p ? 1 : 0;
+}
+
 }  // namespace
 
 extern "C" int cic_uniform_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, cic_stream_t s) {
     CIC_REQUIRE(out && n > 0);
     const int64_t q = (n + 3) / 4;
     hipLaunchKernelGGL(uniform_kernel, dim3(cic_cdiv(q, 256)), dim3(256), 0, cic_s(s), out, n, seed, offset);
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cic_dropout_keep_u8_multi(uint8_t* const* keep, const int64_t* n, const uint64_t* offset, int count,
+                                         float p, uint64_t seed, cic_stream_t s) {
+    CIC_REQUIRE(keep && n && offset && count >= 1 && count <= CIC_KEEP_MAX_SEGMENTS && p >= 0.f && p < 1.f);
+    KeepSegs sg = {};
+    sg.count = count;
+    int blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        CIC_REQUIRE(keep[i] && n[i] > 0);
+        sg.keep[i] = keep[i]; sg.n[i] = n[i]; sg.offset[i] = offset[i]; sg.first_block[i] = blocks;
+        blocks += (int)cic_cdiv((n[i] + 3) / 4, 256);
+    }
+    sg.first_block[count] = blocks;
+    hipLaunchKernelGGL(keep_multi_kernel, dim3(blocks), dim3(256), 0, cic_s(s), sg, p, seed);
     CIC_LAUNCH_CHECK();
     return 0;
 }

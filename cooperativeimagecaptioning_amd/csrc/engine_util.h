@@ -57,6 +57,7 @@ int cic_a2c_cell_fused(Dual<const float> att_res, const float* Wa, const float* 
                        int nb, int H, hipStream_t st);
 int cic_logsoftmax_sample2(const cic_sampler_args* a, const cic_sampler_args* b, hipStream_t st);
 // the sampler on the row partials of the step's logits (no pass over the vocabulary); writes the rows' lse
+int cic_finalize_len2(Dual<const int> any_unfinished, int T, Dual<int> L, int nb, hipStream_t st);
 int cic_sample_finish2(const cic_sampler_args* a, const float* part_a, int part_rows_a, float* lse_a,
                        const cic_sampler_args* b, const float* part_b, int part_rows_b, float* lse_b, int np, hipStream_t st);
 // dropout of the embedded regions with ragged region counts: rows beyond an image's own regions become 0

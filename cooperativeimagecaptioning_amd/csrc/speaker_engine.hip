@@ -402,11 +402,15 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     }
 #undef SLAB
 #undef CSLAB
-    for (int q = 0; q < nb; ++q) {
-        if (io[q]->first_token) {
-            RUN(cic_fill_i32(io[q]->L, 1, T, st));      // teacher forcing: every step carries a target
-        } else {
-            RUN(cic_finalize_len(w[q].any_unf, T, io[q]->L, s));
+    if (nb == 2 && !io[0]->first_token && !io[1]->first_token) {
+        RUN(cic_finalize_len2(Dual<const int>{w[0].any_unf, w[1].any_unf}, T, Dual<int>{io[0]->L, io[1]->L}, 2, st));
+    } else {
+        for (int q = 0; q < nb; ++q) {
+            if (io[q]->first_token) {
+                RUN(cic_fill_i32(io[q]->L, 1, T, st));      // teacher forcing: every step carries a target
+            } else {
+                RUN(cic_finalize_len(w[q].any_unf, T, io[q]->L, s));
+            }
         }
     }
     if (ps) RUN(cic_soft_mask(io[0]->soft_raw, io[0]->seq, io[0]->L, io[0]->soft_out, T, B, V1, st));

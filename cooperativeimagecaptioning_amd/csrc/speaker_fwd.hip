@@ -1021,15 +1021,17 @@ __global__ __launch_bounds__(256) void sample_finish_kernel(FinishArgs a0, Finis
 
 // L = number of appended columns: the reference breaks at the first t >= 1 whose unfinished
 // sum is 0 (AttModel.py:407-408); otherwise seq_length.
-__global__ void finalize_len_kernel(const int* __restrict__ any_unf, int T, int* __restrict__ L) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+// (block q = decode q of a pair)
+__global__ void finalize_len_kernel(Dual<const int> any_unf_d, int T, Dual<int> L_d) {
+    if (threadIdx.x == 0) {
+        const int* __restrict__ any_unf = any_unf_d.sel(blockIdx.x == 1);
         int l = T;
         for (int t = 1; t <= T; ++t)
             if (any_unf[t] == 0) {
                 l = t - 1;
                 break;
             }
-        *L = l;
+        *L_d.sel(blockIdx.x == 1) = l;
     }
 }
 
@@ -1328,8 +1330,11 @@ static int check_sampler_args(const cic_sampler_args* a, bool noise_in_partials)
 }
 
 extern "C" int cic_finalize_len(const int* any_unfinished, int T, int* L, cic_stream_t s) {
-    CIC_REQUIRE(any_unfinished && L && T > 0);
-    hipLaunchKernelGGL(finalize_len_kernel, dim3(1), dim3(64), 0, cic_s(s), any_unfinished, T, L);
+    return cic_finalize_len2(dual1(any_unfinished), T, dual1(L), 1, cic_s(s));
+}
+int cic_finalize_len2(Dual<const int> any_unfinished, int T, Dual<int> L, int nb, hipStream_t st) {
+    CIC_REQUIRE(any_unfinished.a && L.a && T > 0 && (nb == 1 || (nb == 2 && any_unfinished.b && L.b)));
+    hipLaunchKernelGGL(finalize_len_kernel, dim3(nb), dim3(64), 0, st, any_unfinished, T, L);
     CIC_LAUNCH_CHECK();
     return 0;
 }

@@ -60,10 +60,11 @@ class NoiseSource:
             return out
         out = {}
         if p > 0.0:
-            for key, shape in (('att_keep', (B, K, H)), ('x_keep', (T + 1, B, E)), ('out_keep', (T + 1, B, H))):
-                t = self._get((tag, key), shape, torch.uint8, device)
-                ops.dropout_keep_(t, p, self.seed, self._next_offset())
-                out[key] = t
+            # the three masks of the decode in one launch, each from its own Philox sub-stream
+            keys = (('att_keep', (B, K, H)), ('x_keep', (T + 1, B, E)), ('out_keep', (T + 1, B, H)))
+            masks = [self._get((tag, key), shape, torch.uint8, device) for key, shape in keys]
+            ops.dropout_keep_multi_(masks, p, self.seed, [self._next_offset() for _ in keys])
+            out.update({key: t for (key, _), t in zip(keys, masks)})
         if need_u and u_in_kernel:
             out['u_stream'] = (self.seed, self._next_offset())
         elif need_u:

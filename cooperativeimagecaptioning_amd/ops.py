@@ -19,6 +19,7 @@ def _sig(name, argtypes):
 
 _uniform = _sig('cic_uniform_f32', [P, L64, U64, U64, P])
 _keep = _sig('cic_dropout_keep_u8', [P, L64, F, U64, U64, P])
+_keep_multi = _sig('cic_dropout_keep_u8_multi', [C.POINTER(P), C.POINTER(L64), C.POINTER(U64), I, F, U64, P])
 _gemm = _sig('cic_gemm_f32', [C.POINTER(GemmArgs), P])
 _colsum = _sig('cic_colsum_f32', [P, I, I, I, P, I, P])
 _attn_fwd = _sig('cic_attn_fwd', [P] * 9 + [I] * 4 + [P])
@@ -43,6 +44,17 @@ def dropout_keep_(keep, p, seed, offset=0):
     assert keep.dtype == torch.uint8
     check(_keep(ptr(_dev(keep)), keep.numel(), float(p), seed, offset, stream()), 'cic_dropout_keep_u8')
     return keep
+
+
+def dropout_keep_multi_(keeps, p, seed, offsets):
+    """Several keep masks in one launch; mask i is what dropout_keep_(keeps[i], p, seed, offsets[i]) writes."""
+    k = len(keeps)
+    assert k == len(offsets) and all(t.dtype == torch.uint8 for t in keeps)
+    ptrs = (P * k)(*[ptr(_dev(t)) for t in keeps])
+    ns = (L64 * k)(*[t.numel() for t in keeps])
+    offs = (U64 * k)(*offsets)
+    check(_keep_multi(ptrs, ns, offs, k, float(p), seed, stream()), 'cic_dropout_keep_u8_multi')
+    return keeps
 
 
 def gemm(A, B, C_, a_kc=True, b_kc=True, bias=None, accumulate=False, relu=False, A2=None, B2=None,

@@ -56,6 +56,12 @@ int cic_uniform_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, cic_s
 /* keep[i] = u[i] >= p  (1 = keep), nn.Dropout in training mode (models/AttModel.py:74-85,506). */
 int cic_dropout_keep_u8(uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset,
                         cic_stream_t s);
+/* The same draws for up to CIC_KEEP_MAX_SEGMENTS tensors in ONE launch (the three masks of a decode: att_embed, the
+ * token embeddings, the LSTM outputs).  Segment i is exactly what cic_dropout_keep_u8(keep[i], n[i], p, seed,
+ * offset[i]) writes; the arrays are host arrays. */
+#define CIC_KEEP_MAX_SEGMENTS 8
+int cic_dropout_keep_u8_multi(uint8_t* const* keep, const int64_t* n, const uint64_t* offset, int count, float p,
+                              uint64_t seed, cic_stream_t s);
 
 /* ---- dense contraction on the f32 MFMA (v_mfma_f32_32x32x2_f32) --------------------- */
 /* C[M,N] = op(A)[M,K] * op(B)[K,N] (+ A2*B2 over K2) (+ bias[N]) (+ C if accumulate), then

@@ -150,6 +150,14 @@ def test_rng(ops):
     assert abs(float(keep.float().mean()) - 0.5) < 3e-3
     ops.dropout_keep_(keep, 0.2, seed=3)
     assert abs(float(keep.float().mean()) - 0.8) < 3e-3
+    # several masks in one launch: each equals its own single launch (ragged sizes, own sub-streams)
+    sizes, offs = [128 * 36 * 512, 17 * 128 * 512 + 3, 1001], [1 << 32, 2 << 32, 77]
+    many = [dev(torch.zeros(k, dtype=torch.uint8)) for k in sizes]
+    ops.dropout_keep_multi_(many, 0.5, 3, offs)
+    for t, k, o in zip(many, sizes, offs):
+        one = dev(torch.zeros(k, dtype=torch.uint8))
+        ops.dropout_keep_(one, 0.5, seed=3, offset=o)
+        assert torch.equal(t, one)
     # independent reference of Philox4x32-10 on the host for a few counters
     def philox(counter, seed):
         M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
