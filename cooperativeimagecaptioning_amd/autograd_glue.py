@@ -13,6 +13,8 @@ class EngineLoss(torch.autograd.Function):
     def forward(ctx, loss_value, anchor, backward_fn):
         # anchor: any tensor that requires grad (a flat parameter buffer) — ties the node into the graph
         ctx.backward_fn = backward_fn
+        if getattr(loss_value, '_cic_fresh', False):      # engine.loss_combine: a tensor of this step, not a workspace slot
+            return loss_value.detach()
         return loss_value.detach().clone()
 
     @staticmethod

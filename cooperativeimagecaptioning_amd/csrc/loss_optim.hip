@@ -103,7 +103,34 @@ __global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, 
     }
 }
 
+struct LossTerms {
+    const float* term[CIC_LOSS_MAX_TERMS];
+    float weight[CIC_LOSS_MAX_TERMS];
+    int count;
+};
+__global__ void loss_combine_kernel(LossTerms lt, float* __restrict__ total) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < lt.count; ++i) t += lt.weight[i] * lt.term[i][0];
+        total[0] = t;
+    }
+}
+
 }  // namespace
+
+extern "C" int cic_loss_combine(const float* const* term, const float* weight, int count, float* total, cic_stream_t s) {
+    CIC_REQUIRE(term && weight && total && count >= 1 && count <= CIC_LOSS_MAX_TERMS);
+    LossTerms lt = {};
+    lt.count = count;
+    for (int i = 0; i < count; ++i) {
+        CIC_REQUIRE(term[i]);
+        lt.term[i] = term[i];
+        lt.weight[i] = weight[i];
+    }
+    hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(64), 0, cic_s(s), lt, total);
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int cic_seq_loss(const float* slp, const int32_t* seq, const int32_t* L, const float* coef, float coef_sign,
                             float weight, int B, int T, float* loss_out, float* dslp, int accumulate, cic_stream_t s) {

@@ -40,6 +40,8 @@ lib.cic_ciderd_reward.argtypes = [C.POINTER(CiderdArgs), P, C.c_size_t, P]
 lib.cic_ciderd_reward.restype = C.c_int
 lib.cic_seq_loss.argtypes = [P, P, P, P, C.c_float, C.c_float, C.c_int, C.c_int, P, P, C.c_int, P]
 lib.cic_seq_loss.restype = C.c_int
+lib.cic_loss_combine.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_float), C.c_int, P, P]
+lib.cic_loss_combine.restype = C.c_int
 lib.cic_masked_nll.argtypes = [P, P, C.c_int, C.c_float, C.c_int, C.c_int, P, P, P]
 lib.cic_masked_nll.restype = C.c_int
 lib.cic_clamp_adam.argtypes = [P, P, P, P, C.c_int64] + [C.c_double] * 6 + [C.c_int, C.c_double, P]
@@ -297,6 +299,20 @@ def seq_loss(slp, seq, L, coef, coef_sign, weight, dslp=None, accumulate=False, 
     check(lib.cic_seq_loss(_p(slp), _p(seq), _p(L), _p(coef), float(coef_sign), float(weight), B, T, _p(loss_out),
                            _p(dslp), int(accumulate), stream()), 'cic_seq_loss')
     return loss_out
+
+
+def loss_combine(weighted_terms):
+    """[(weight, device scalar tensor f32[>=1])] -> 0-dim tensor sum_i weight_i * term_i[0], one launch."""
+    k = len(weighted_terms)
+    terms = [t for _, t in weighted_terms]
+    assert all(t.dtype == torch.float32 and t.is_cuda for t in terms)
+    total = torch.empty(1, device=terms[0].device)
+    ptrs = (C.c_void_p * k)(*[_p(t) for t in terms])
+    ws = (C.c_float * k)(*[float(w) for w, _ in weighted_terms])
+    check(lib.cic_loss_combine(ptrs, ws, k, _p(total), stream()), 'cic_loss_combine')
+    out = total[0]
+    out._cic_fresh = True          # autograd_glue.EngineLoss need not copy it
+    return out
 
 
 def masked_nll(slp, mask, weight, dslp=None, loss_out=None):

@@ -253,7 +253,9 @@ class AlternatingJointModel(nn.Module):
                 dslp = cg._buf.get('dslp', (B, T), torch.float32, dev)
             lc = engine.seq_loss(sample.slp, sample.seq, sample.L, coef, -1.0, ciw, dslp=dslp, accumulate=not fresh)
             terms.append((ciw, lc))
-            self._loss['avg_reward'] = coef.mean().detach()
+            # mean of coef from the reward kernel's own sums (stats = mean sampled score, mean greedy score): no launch here
+            st = rw['stats']
+            self._loss['avg_reward'] = (lambda st=st: st[0]) if self.use_gen_cider_scores else (lambda st=st: st[0] - st[1])
             self._loss['cider_greedy'] = rw['stats'][1].detach()
             self._loss['loss_cider'] = lc.detach()[0]
         # the decodes of this step (DecodeResult or None), for callers that want the generated tokens (evaluation, tests)
@@ -269,7 +271,7 @@ class AlternatingJointModel(nn.Module):
 
         if not terms:
             return self._zero_loss(dev)
-        loss = sum(w * t[0] for w, t in terms)
+        loss = engine.loss_combine(terms)          # sum_i weight_i * term_i, one launch
         anchor = next((p for p in self.parameters() if p.requires_grad), None)
         if anchor is None or not torch.is_grad_enabled() or not bwd_steps:
             return loss.detach()
@@ -342,7 +344,7 @@ class AlternatingJointModel(nn.Module):
     def loss(self):
         """:562-568."""
         out = {}
-        out.update(self._loss)
+        out.update({k: (v() if callable(v) else v) for k, v in self._loss.items()})   # lazily computed logging values
         out.update({'cap_' + k: v for k, v in self.caption_generator._loss.items()})
         if self.vse is not None:
             out.update({'vse_' + k: v for k, v in self.vse._loss.items()})

@@ -21,6 +21,12 @@ _uniform = _sig('cic_uniform_f32', [P, L64, U64, U64, P])
 _keep = _sig('cic_dropout_keep_u8', [P, L64, F, U64, U64, P])
 _keep_multi = _sig('cic_dropout_keep_u8_multi', [C.POINTER(P), C.POINTER(L64), C.POINTER(U64), I, F, U64, P])
 _gemm = _sig('cic_gemm_f32', [C.POINTER(GemmArgs), P])
+# every entry point gets its signature here or in engine.py: ctypes would pass an undeclared Python int as a 32-bit int
+_sig('cic_gemm_logit_parts', [C.POINTER(GemmArgs)])
+_sig('cic_gemm_split_ok', [C.POINTER(GemmArgs)])
+_sig('cic_gemm_f32_timed', [C.POINTER(GemmArgs), I, C.POINTER(C.c_double), P])
+_sig('cic_logit_partials', [P, I, I, I, P, I, P])
+_sig('cic_attn_fwd_timed', [P] * 7 + [I] * 5 + [P, L64, C.POINTER(C.c_double), P])
 _colsum = _sig('cic_colsum_f32', [P, I, I, I, P, I, P])
 _attn_fwd = _sig('cic_attn_fwd', [P] * 9 + [I] * 4 + [P])
 _cell_fwd = _sig('cic_cell_fwd', [P, P, P, F, P, P, P, I, I, P])

@@ -453,6 +453,11 @@ int cic_seq_loss(const float* slp, const int32_t* seq, const int32_t* L, const f
  * dslp = weight * d loss / d slp. */
 int cic_masked_nll(const float* slp, const float* mask, int mask_ld, float weight, int B, int T,
                    float* loss_out, float* dslp, cic_stream_t s);
+/* The step's loss as the reference assembles it (AlternatingJointModel.py:470-503: loss = sum_i weight_i * term_i):
+ * total[0] = sum over the `count` <= CIC_LOSS_MAX_TERMS device scalars term[i][0] of weight[i] * term[i][0], added in
+ * index order.  `term` and `weight` are host arrays. */
+#define CIC_LOSS_MAX_TERMS 8
+int cic_loss_combine(const float* const* term, const float* weight, int count, float* total, cic_stream_t s);
 /* clip_gradient (elementwise clamp to +-grad_clip, misc/utils.py:65-69) followed by one
  * torch.optim.Adam step (optimizer.py:25-27,233-242) over a flat buffer of n floats.  The gradient is
  * first multiplied by grad_scale (1/world_size after a sum all-reduce).  step >= 1 is Adam's t. */

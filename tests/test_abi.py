@@ -14,6 +14,21 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib.cic_last_error() is not None
 
 
+def test_every_bound_entry_point_declares_its_argument_types():
+    """ctypes passes an undeclared Python int as a C int: a 64-bit device pointer or stream handle would be cut to 32
+    bits.  Every entry point of the header that takes arguments must have argtypes once the binding modules are loaded."""
+    from cooperativeimagecaptioning_amd import _lib, ops, engine, eval_utils  # noqa: F401  (they declare the signatures)
+    hdr = open(os.path.join(ROOT, 'include', 'cic.h')).read()
+    code = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    missing = []
+    for name in _lib.declared_symbols():
+        m = re.search(r'\b' + name + r'\s*\(([^)]*)\)', code)
+        takes_args = m is not None and m.group(1).strip() not in ('', 'void')
+        if takes_args and getattr(_lib.lib, name).argtypes is None:
+            missing.append(name)
+    assert not missing, missing
+
+
 def test_header_is_plain_c_abi():
     src = open(os.path.join(ROOT, 'include', 'cic.h')).read()
     assert 'extern "C"' in src
