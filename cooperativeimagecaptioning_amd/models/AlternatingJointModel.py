@@ -130,20 +130,14 @@ class AlternatingJointModel(nn.Module):
         spk_grad = any(p.requires_grad for p in cg.parameters()) and torch.is_grad_enabled()
         lst_grad = vse is not None and any(p.requires_grad for p in vse.parameters()) and torch.is_grad_enabled()
         from .FCModel import FCModel
-        if isinstance(cg, FCModel):
-            # BASELINE configs[0]: the fc-feature speaker.  Its sample() returns (seq, logprobs) only, so the reference
-            # can drive it with the MLE / VSE terms (and REINFORCE); the MLE + VSE terms are what run here.
-            if self.retrieval_reward_weight > 0 or self.cider_optimization:
-                raise NotImplementedError("caption_model 'fc': only the MLE and VSE terms are on the MI355X path")
-            loss = None
-            if self.caption_loss_weight > 0:                          # ce_loss :196-207
-                loss = self.caption_loss_weight * cg(fc_feats, att_feats, att_masks, seq, masks)
-                self._loss['loss_cap'] = cg._loss['xe']
-            if self.vse_loss_weight > 0:                              # vse_loss :209-224
-                lv = vse(fc_feats, att_feats, seq, masks, only_one_retrieval=oor)
-                self._loss['loss_vse'] = lv.detach()
-                loss = self.vse_loss_weight * lv if loss is None else loss + self.vse_loss_weight * lv
-            return loss if loss is not None else self._zero_loss(dev)
+        fc_speaker = isinstance(cg, FCModel)
+        if fc_speaker:
+            # BASELINE configs[0]: the fc-feature speaker.  Its sample() returns (seq, logprobs) only, so the reference can
+            # drive it with the MLE, VSE, REINFORCE (reinforce_disc :226-247) and CIDEr terms, not the straight-through ones
+            if self.retrieval_reward_weight > 0 and rr != 'reinforce':
+                raise NotImplementedError(f"caption_model 'fc' under retrieval_reward {rr!r}: FCModel.sample returns two "
+                                          "values, the reference's straight-through path unpacks three (:346)")
+            cg._step_fc = fc_feats
         B = fc_feats.shape[0]
         T = cg.seq_length
         terms = []          # (weight, device scalar)
@@ -186,7 +180,7 @@ class AlternatingJointModel(nn.Module):
 
         def sampled_with_greedy(**spec):
             """The sampled decode of the step, together with the greedy decode when the step needs one."""
-            if need_greedy and greedy is None and self.pair_decodes:
+            if need_greedy and greedy is None and self.pair_decodes and not fc_speaker:
                 return cg.decode_pair(att_feats, att_masks, spec, dict(mode='greedy', tag='greedy'), att_pre=att_pre)
             return cg.decode(att_feats, att_masks, att_pre=att_pre, **spec), greedy
         if dw > 0:                                                     # DISC loss :455-488

@@ -65,6 +65,7 @@ class FCModel(nn.Module):
         self.noise = NoiseSource()
         self._ws = {}
         self._buf = BufCache()
+        self._step_fc = None                           # the fc features of the joint step in flight (AlternatingJointModel)
 
     def init_weights(self):                                            # :74-78
         initrange = 0.1
@@ -138,6 +139,31 @@ class FCModel(nn.Module):
         # img_embed backward: dW += d_x0^T fc, db += colsum(d_x0)         (:99)
         ops.gemm(d_x0, res.fc, grads['img_embed.weight'], False, False, accumulate=True, sum_order_free=True)
         ops.colsum(d_x0, grads['img_embed.bias'], accumulate=True)
+
+    # ---- the decode interface AlternatingJointModel drives (same names as AttModel's) ---------------------------
+    def att_embed_pre(self, att_feats):
+        return None                                    # no region features in this speaker
+
+    def decode(self, att_feats, att_masks, mode, temp=1.0, att_pre=None, grad=False, T=None, pick=None, first_token=None,
+               tag='sample', decoding_constraint=None, want_stv=None, ss_prob=0.0, ps_prob=0.0, fc_feats=None):
+        """One FCModel.sample / FCModel.forward pass -> DecodeResult.  FCModel.sample returns (seq, logprobs) only
+        (FCModel.py:324-325), so the reference can run it under the MLE, REINFORCE and CIDEr terms: greedy, multinomial
+        and teacher-forced decodes; the straight-through modes have no FCModel form."""
+        if mode not in ('greedy', 'multinomial', 'teacher'):
+            raise NotImplementedError(f"caption_model 'fc' has no {mode!r} decode: FCModel.sample returns (seq, logprobs) "
+                                      'only, the straight-through retrieval rewards need the one-hot output of AttModel')
+        if ss_prob:
+            raise NotImplementedError('scheduled sampling is supported for att2in2 only')
+        fc_feats = self._step_fc if fc_feats is None else fc_feats
+        dc = self.decoding_constraint if decoding_constraint is None else decoding_constraint
+        return self._decode(fc_feats, mode, temp, T=T, pick=pick, first_token=first_token, grad=grad, tag=tag,
+                            decoding_constraint=dc)
+
+    def decode_backward(self, res, d_onehot=None, dslp=None, logit_grads_ready=None):
+        assert d_onehot is None and dslp is not None, 'the fc speaker receives gradient through its log-probabilities only'
+        self._decode_backward(res, dslp=dslp.contiguous())
+        if logit_grads_ready is not None:
+            logit_grads_ready()
 
     # ---- reference API ---------------------------------------------------------------------
     def forward(self, fc_feats, att_feats, att_masks, seq, masks):

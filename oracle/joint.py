@@ -16,9 +16,31 @@ in oracle/listener.py); gradients come from torch autograd on the CPU.
 import numpy as np
 import torch
 
-from . import speaker as S
+from . import speaker as _att_speaker
+from . import fc as FC
 from . import listener as Lst
 from . import ciderd
+
+
+class _Speaker:
+    """The caption generator of the step: att2in2 (oracle/speaker.py) or, with cfg['caption_model'] == 'fc', the
+    fc-feature FCModel (oracle/fc.py), whose sample() returns (seq, logprobs) only - the reference can drive it with the
+    MLE, REINFORCE and CIDEr terms (reinforce_disc :226-247 unpacks two values), not with the straight-through ones."""
+
+    def __init__(self, cfg):
+        self.fc = cfg.get('caption_model', 'att2in2') == 'fc'
+
+    def sample(self, P, cfg, fc, att, att_masks, opt, noise, rr):
+        if not self.fc:
+            return _att_speaker.sample(P, cfg, fc, att, att_masks, opt, noise, rr)
+        if opt.get('use_one_hot'):
+            raise ValueError('FCModel.sample returns two values: the straight-through modes cannot run on it')
+        return FC.fc_sample(P, cfg, fc, opt, noise)
+
+    def mle_forward(self, P, cfg, fc, att, att_masks, seq, masks, noise, ss_prob):
+        if not self.fc:
+            return _att_speaker.mle_forward(P, cfg, fc, att, att_masks, seq, masks, noise, ss_prob)
+        return FC.fc_forward(P, cfg, fc, seq, masks, noise)
 
 
 def gen_masks_from(word_index):
@@ -36,6 +58,7 @@ def joint_forward(Ps, Pl, cfg, batch, noise=None, turn='speaker', is_alternating
     seq, masks = batch['labels'], batch['masks']
     fc, att, att_masks = batch['fc_feats'], batch['att_feats'], batch['att_masks']
     V = cfg['vocab_size']
+    S = _Speaker(cfg)
     if is_alternating:
         if turn == 'speaker':                                          # :508-526
             flags['vse'] = 0
@@ -52,6 +75,7 @@ def joint_forward(Ps, Pl, cfg, batch, noise=None, turn='speaker', is_alternating
 def _forward_plain(Ps, Pl, cfg, flags, fc, att, att_masks, seq, masks, gts, noise):
     """The non-alternating branch, AlternatingJointModel.py:443-504."""
     aux = {}
+    S = _Speaker(cfg)
     rr = cfg['retrieval_reward']
     oor = cfg.get('only_one_retrieval', 'off')
     V = cfg['vocab_size']
@@ -129,6 +153,7 @@ def _forward_plain(Ps, Pl, cfg, flags, fc, att, att_masks, seq, masks, gts, nois
         aux.update(avg_reward=float(reward.mean()), cider_greedy=float(cider_greedy),
                    loss_cider=loss_cider.detach(), reward=reward, greedy_res=greedy_res)
     aux['gen_result'] = gen_result
+    aux.setdefault('greedy_res', greedy_res)
     return loss, aux
 
 

@@ -354,23 +354,83 @@ def opt_np(opt, widths=False):
 
 
 # ----------------------------------------------------------------------------
+def fc_noise(events, n, B, H, prefix='noise'):
+    """The draws of one FCModel pass: one dropout mask per loop iteration (the LSTM output), multinomial picks."""
+    keep = np.ones((n, B, H), np.float32)
+    pick = np.zeros((n, B), np.int64)
+    has_pick, i = False, 0
+    for kind, t in events:
+        if kind == 'dropout':
+            keep[i] = t.numpy()
+            i += 1
+        elif kind == 'multinomial':
+            pick[i] = t.numpy()          # drawn at iteration i (before that iteration's core call)
+            has_pick = True
+    o = {prefix + '.out_keep': keep}
+    if has_pick:
+        o[prefix + '.pick'] = pick
+    return o
+
+
+FC_JOINT = (  # the fc-feature speaker under the terms its two-value sample() can drive (reinforce_disc, CIDEr)
+    ('fc_joint_reinforce_gt', dict(retrieval_reward='reinforce', reinforce_baseline_type='gt', drop_prob_lm=0.5), 0.8),
+    ('fc_joint_reinforce_greedy', dict(retrieval_reward='reinforce', reinforce_baseline_type='greedy',
+                                       cider_optimization=0), 0.6),
+)
+
+
+def gen_fc_joint(torch, models, rec):
+    for name, kw, bias0 in FC_JOINT:
+        opt = make_opt(caption_model='fc', **kw)
+        torch.manual_seed(21)
+        m = models.AlternatingJointModel(opt)
+        m.train()
+        cg = m.caption_generator
+        for w in (cg.core.i2h.weight, cg.core.h2h.weight, cg.embed.weight, cg.img_embed.weight):
+            w.data.mul_(3.0)
+        cg.logit.weight.data.mul_(6.0)
+        cg.logit.bias.data[0] = bias0
+        batch = make_batch(torch, opt, K=7, seed=21)
+        marks, tokens = [], []
+        orig_sample = cg.sample
+
+        def spy(*a, **k):
+            marks.append(len(rec.events))           # where this decode's draws begin
+            r = orig_sample(*a, **k)
+            tokens.append(r[0].detach().numpy().astype(np.int64).copy())
+            return r
+        cg.sample = spy
+        torch.manual_seed(13)
+        rec.start()
+        loss = m(batch['fc_feats'], batch['labels'], batch['masks'], {'gts': batch['gts']}, batch['att_feats'], None,
+                 is_alternating=True, alternating_turn='speaker')
+        ev = rec.stop()
+        m.zero_grad()
+        loss.backward()
+        bounds = marks + [len(ev)]
+        nz = {}
+        for i in range(len(marks)):
+            nz.update(fc_noise(ev[bounds[i]:bounds[i + 1]], opt.seq_length + 2, opt.batch_size, opt.rnn_size, f'noise{i}'))
+        grads = digests((k, p.grad) for k, p in m.named_parameters() if not k.startswith('prev_') and p.grad is not None)
+        aux = {}
+        for k, v in m.loss().items():
+            try:
+                aux['aux.' + k] = np.float64(float(v))
+            except Exception:
+                pass
+        cfg = opt_np(opt)
+        cfg['cfg.caption_model'] = np.array('fc')
+        print(name, 'loss', float(loss), 'decodes', [(t.shape[1], sorted(set((t > 0).sum(1).tolist()))) for t in tokens],
+              'ngrads', len(grads))
+        save(name, **{'w.' + k: v for k, v in sd_np(m).items() if not k.startswith('prev_')}, **cfg, **nz, **grads, **aux,
+             **{f'tokens{i}': t for i, t in enumerate(tokens)}, loss=loss, n_decodes=np.int64(len(marks)),
+             turn=np.array('speaker'), fc=batch['fc_feats'], att_raw=batch['att_feats'], labels=batch['labels'],
+             masks=batch['masks'], gts_flat=np.concatenate(batch['gts'], 0),
+             gts_count=np.array([len(x) for x in batch['gts']]))
+
+
 def gen_fc(torch, models, rec):
     """FCModel (the fc-feature speaker of BASELINE configs[0]): MLE forward/backward and greedy / multinomial decodes."""
-    def fc_noise(events, n, B, H):
-        keep = np.ones((n, B, H), np.float32)
-        pick = np.zeros((n, B), np.int64)
-        has_pick, i = False, 0
-        for kind, t in events:
-            if kind == 'dropout':
-                keep[i] = t.numpy()
-                i += 1
-            elif kind == 'multinomial':
-                pick[i] = t.numpy()          # drawn at iteration i (before that iteration's core call)
-                has_pick = True
-        o = {'noise.out_keep': keep}
-        if has_pick:
-            o['noise.pick'] = pick
-        return o
 
     for name, pdrop, seed in (('fc_mle', 0.0, 11), ('fc_mle_dropout', 0.5, 12)):
         opt = make_opt(caption_model='fc', drop_prob_lm=pdrop)
@@ -473,6 +533,10 @@ def main():
         return
     if '--only-fc' in sys.argv:
         gen_fc(torch, models, rec)
+        return
+    if '--only-fc-joint' in sys.argv:
+        rewards.init_scorer('corpus')
+        gen_fc_joint(torch, models, rec)
         return
     if '--only-beam' in sys.argv:
         gen_beam(torch, models, rec)
@@ -825,6 +889,7 @@ def main():
         cider_cases()
         clamp_adam_case()
         gen_fc(torch, models, rec)
+        gen_fc_joint(torch, models, rec)
         gen_beam(torch, models, rec)
         gen_retrieval(torch)
     # ------------------------------------------------------------------ att_masks (ragged region counts)
