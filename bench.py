@@ -299,7 +299,7 @@ def main():
                                    'tau=1 + self-critical CIDEr-D, 36x2048 att_feats, vocab 9487, seq_len 16, '
                                    'dropout 0.5, clamp 0.1 + Adam both agents (BASELINE configs[2])',
                        'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': f'dp{world}',
-                       'resident_batches': len(batches),
+                       'paired_decodes': bool(getattr(model.caption_generator, 'last_pair_fused', False)), 'resident_batches': len(batches),
                        'excluded': 'host packing + upload of the reference captions (once per resident batch, the loader\'s job)',
                        'final_loss': final_loss,
                        'world': world, 'backend': (args.backend if world > 1 else None),

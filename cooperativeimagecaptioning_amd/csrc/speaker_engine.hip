@@ -142,6 +142,10 @@ static bool pair_ok(const cic_speaker_dims& d, const cic_decode_io* a, const cic
     return cic_attn_pair_ok(d.K, d.A, d.H);
 }
 
+extern "C" int cic_speaker_decode_pair_fused(const cic_speaker_dims* d, const cic_decode_io* io_a, const cic_decode_io* io_b) {
+    return (d && io_a && io_b && pair_ok(*d, io_a, io_b)) ? 1 : 0;
+}
+
 extern "C" int cic_speaker_decode_fwd_pair(const cic_speaker_dims* dp, const cic_speaker_params* p,
                                            const cic_decode_io* io_a, void* ws_a, size_t ws_a_bytes,
                                            const cic_decode_io* io_b, void* ws_b, size_t ws_b_bytes, cic_stream_t s) {

@@ -85,6 +85,8 @@ def speaker_att_embed_fwd(dims, params, att_raw, att_pre=None):
 lib.cic_speaker_decode_fwd_pair.argtypes = [C.POINTER(SpeakerDims), C.POINTER(SpeakerParams), C.POINTER(DecodeIO), P,
                                             C.c_size_t, C.POINTER(DecodeIO), P, C.c_size_t, P]
 lib.cic_speaker_decode_fwd_pair.restype = C.c_int
+lib.cic_speaker_decode_pair_fused.argtypes = [C.POINTER(SpeakerDims), C.POINTER(DecodeIO), C.POINTER(DecodeIO)]
+lib.cic_speaker_decode_pair_fused.restype = C.c_int
 
 
 def speaker_decode_fwd(dims, params, att_pre, mode, temp=1.0, *args, **kw):
@@ -105,6 +107,11 @@ def speaker_decode_fwd_pair(dims, params, a, b):
                                           a['ws'].numel(), C.byref(b['io']), b['ws'].data_ptr(), b['ws'].numel(),
                                           stream()), 'cic_speaker_decode_fwd_pair')
     return a, b
+
+
+def speaker_decode_pair_fused(dims, a, b):
+    """True when the pair goes through shared launches (else the library runs the two decodes one after the other)."""
+    return bool(lib.cic_speaker_decode_pair_fused(C.byref(dims), C.byref(a['io']), C.byref(b['io'])))
 
 
 def speaker_decode_io(dims, params, att_pre, mode, temp=1.0, att_masks=None, att_keep=None, x_keep=None,

@@ -147,6 +147,7 @@ class AttModel(nn.Module):
         (dims, params, ia, (ma, att_raw, ga, _)), (dims_b, _, ib, (mb, _, gb, _)) = ra, rb
         assert (dims.B, dims.K, dims.T) == (dims_b.B, dims_b.K, dims_b.T), 'paired decodes share their shapes'
         engine.speaker_decode_fwd_pair(dims, params, ia, ib)
+        self.last_pair_fused = engine.speaker_decode_pair_fused(dims, ia, ib)   # reported by bench.py / train.py
         return DecodeResult(ia, ma, dims, params, att_raw, ga), DecodeResult(ib, mb, dims_b, params, att_raw, gb)
 
     def _decode_io(self, att_feats, att_masks, mode, temp=1.0, att_pre=None, grad=False, T=None, pick=None,

@@ -201,6 +201,7 @@ def train(opt, loader=None):
         overlap_gradient_exchange(model, optimizer_dict)
     update_lr_flag = True
     epoch, epoch_start, iteration = load_from_infos(infos, None, opt)
+    reported_path = False
     loss_history = {}
     num_turns = len(opt.alternating_turn) if opt.is_alternating else 1
     init_scorer(opt.cached_tokens)
@@ -224,6 +225,11 @@ def train(opt, loader=None):
             loader.prefetch()                                   # batch i+1 travels to HBM while step i computes
         train_loss = float(loss.detach())                       # the step's one host sync (train.py:533-535)
         end = time.time()
+        if rank == 0 and not reported_path and hasattr(model, 'caption_generator'):
+            fused = getattr(model.caption_generator, 'last_pair_fused', None)
+            if fused is not None:      # which decode path this batch size gets (B % 32 == 0 and B <= 128: shared launches)
+                print('sampled + greedy decodes: ' + ('one launch chain over 2B rows' if fused else 'two launch chains'))
+                reported_path = True
         if rank == 0:
             extra = ' '.join(f'{k} = {float(v):.3f}' for k, v in model.loss().items())
             print(f'iter {iteration} (epoch {epoch}) [{curr_turn}], train_loss = {train_loss:.4f}, '

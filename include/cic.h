@@ -334,6 +334,9 @@ int cic_speaker_decode_fwd(const cic_speaker_dims* d, const cic_speaker_params* 
 int cic_speaker_decode_fwd_pair(const cic_speaker_dims* d, const cic_speaker_params* p,
                                 const cic_decode_io* io_a, void* ws_a, size_t ws_a_bytes,
                                 const cic_decode_io* io_b, void* ws_b, size_t ws_b_bytes, cic_stream_t s);
+/* 1 if cic_speaker_decode_fwd_pair runs these two decodes through shared launches, 0 if it runs them one after the other
+ * (B not a multiple of 32 or above 128, partial-sampling modes, the fc speaker, widths outside the paired kernels) */
+int cic_speaker_decode_pair_fused(const cic_speaker_dims* d, const cic_decode_io* io_a, const cic_decode_io* io_b);
 
 typedef struct {
     const float* d_onehot;   /* [T,B,V+1] gradient w.r.t. the ST one-hot rows / the soft rows io->soft_out (from
