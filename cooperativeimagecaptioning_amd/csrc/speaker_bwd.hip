@@ -40,7 +40,7 @@ __device__ __forceinline__ float block_max4(float v, float* sh) {
 //   overwritten by the constant EOS one-hot, AttModel.py:416-420)
 //   d logits_j = unf * y_j (G_j - sum_i y_i G_i) / tau + dslp * ([j == it] - exp(logp_j))
 template <int RV>
-__global__ __launch_bounds__(SNW * 64) void sampler_bwd_kernel(const float* __restrict__ logp_all,   // [T,B,V1]
+__global__ __launch_bounds__(SNW * 64) __attribute__((amdgpu_waves_per_eu(RV <= 3 ? 8 : 4))) void sampler_bwd_kernel(const float* __restrict__ logp_all,   // [T,B,V1]
                                                           const float* __restrict__ U,          // [T+1,B,V1] or null
                                                           const float* __restrict__ G,          // [T,B,V1] or null
                                                           const int32_t* __restrict__ it_all,   // [T+1,B]
