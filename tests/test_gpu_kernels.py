@@ -93,6 +93,34 @@ def test_gemm_precisions(ops, M, N, K, a_kc, b_kc):
     assert torch.equal(C1, C2)
 
 
+@pytest.mark.parametrize('M,N,K,K2', [(256, 9488, 512, 0), (100, 9488, 512, 0), (256, 2560, 512, 512), (37, 3072, 512, 512),
+                                      (200, 2048, 1024, 0)])
+def test_walker_products_on_bf16_parts_are_f32_accurate(ops, M, N, K, K2):
+    """The per-timestep walkers (logit product: K = 512, N >= 2048; gate product: K + K2 = 1024, N >= 2048) in their
+    default form - operands cut into three bf16 parts - against an f64 product of the same f32 operands, next to their
+    f32-input MFMA form: both within a few 2^-24 of sum |a b|; rows beyond M (ragged strips) are never written."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g) * torch.logspace(-2, 2, K, base=2.0)
+    W = torch.randn(N, K, generator=g) * 0.05
+    A2 = torch.randn(M, K2, generator=g) if K2 else None
+    W2 = torch.randn(N, K2, generator=g) * 0.05 if K2 else None
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ W.double().t() + bias.double()
+    mag = A.double().abs() @ W.double().abs().t() + bias.double().abs()
+    if K2:
+        ref += A2.double() @ W2.double().t()
+        mag += A2.double().abs() @ W2.double().abs().t()
+    err = {}
+    for name, prec in (('f32', 0), ('f32_mfma', 1)):
+        Cd = dev(torch.full((M + 2, N), 7.0))
+        ops.gemm(dev(A), dev(W), Cd[:M], True, True, bias=dev(bias), A2=dev(A2) if K2 else None,
+                 B2=dev(W2) if K2 else None, precision=prec)
+        torch.cuda.synchronize()
+        err[name] = float(np.max(np.abs(Cd[:M].cpu().double().numpy() - ref.numpy()) / mag.numpy()))
+        assert float((Cd[M:] - 7.0).abs().max()) == 0.0, name
+    assert err['f32'] < 4e-7 and err['f32_mfma'] < 4e-7, err
+
+
 def test_gemm_dual_and_strided(ops):
     # pre = x W_i2h^T + h W_h2h^T + b, written into a column window of a wider buffer
     g = torch.Generator().manual_seed(5)
