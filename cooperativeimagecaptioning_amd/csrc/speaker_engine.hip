@@ -246,6 +246,20 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         return cic_gemm_f32(&g, st);
     };
 
+    // Teacher forcing without scheduled sampling (AttModel.forward :103-148 with ss_prob = 0): the fed tokens are the
+    // targets, so nothing in the recurrence waits for a logit.  The token columns and every step's input embedding are
+    // written before the loop, and the logit product + log-sum-exp + gathered log-probabilities run once over all T*B
+    // rows after it (one LDS-tiled GEMM instead of T walker launches and T sampler launches).
+    const bool teacher_batched = nb == 1 && !fc && !ps && io[0]->mode == CIC_SAMPLE_TEACHER && io[0]->pick &&
+                                 !(io[0]->ss_u && io[0]->ss_prob > 0.f) && (int64_t)T * B <= CIC_PART_MAX_ENTRIES;
+    if (teacher_batched) {
+        RUN(cic_teacher_tokens(io[0]->pick, w[0].it_all, w[0].unfinished, w[0].any_unf, io[0]->seq, T, B, st));
+        if (T > 1) {
+            const uint8_t* xk1 = io[0]->x_keep ? io[0]->x_keep + (size_t)B * E : nullptr;
+            RUN(cic_embed_fwd2(p->embed_w, Dual<const int32_t>{w[0].it_all + B, nullptr}, Dual<const uint8_t>{xk1, nullptr},
+                               xk1 ? p_drop : 0.f, Dual<float>{w[0].x_all + (size_t)B * E, nullptr}, (T - 1) * B, 1, E, st, 0));
+        }
+    }
     for (int t = 0; t < T; ++t) {
         const Dual<float> x = SLAB(x_all, B * E), att_h = SLAB(att_h_all, B * A), att_res = SLAB(att_res_all, B * H),
                           pre = SLAB(pre_all, B * 5 * H), out = SLAB(out_all, B * H), logp = SLAB(logp_all, B * V1);
@@ -328,6 +342,7 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
             RUN(cic_cell_fwd2(Dual<const float>{pre.a, pre.b}, c, ok, ok.a ? p_drop : 0.f, h_new, c_new, out, B, nb, H, st,
                               fc ? 1 : 0));
         }
+        if (teacher_batched) continue;                  // logits of all steps at once, after the loop
         // logprobs = log_softmax(logit(output)); choose the input of step t+1   (:328-365,444)
         // Row-wise modes: the logits stay RAW in the workspace (+ their log-sum-exp per row); the vocabulary is reduced
         // to row partials by the logit product's own epilogue (or, for shapes that kernel does not take, by a pass over
@@ -406,6 +421,15 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     }
 #undef SLAB
 #undef CSLAB
+    if (teacher_batched) {
+        const int R = T * B;
+        RUN(gemm_nt(w[0].out_all, H, p->logit_w, H, w[0].logp_all, V1, R, V1, H, p->logit_b, false, false, st));
+        int np = CIC_PART_MAX_ENTRIES / R < 32 ? CIC_PART_MAX_ENTRIES / R : 32;
+        cic_logit_epi_rows e = {};
+        e.mode = CIC_SAMPLE_NONE; e.inv_temp = 1.0f; e.ldu = V1; e.part = w[0].part; e.part_rows = R;
+        RUN(cic_logit_partials(w[0].logp_all, R, V1, V1, &e, np, s));
+        RUN(cic_teacher_finish_all(w[0].part, np, R, w[0].logp_all, V1, io[0]->pick, w[0].lse_all, io[0]->slp, T, B, st));
+    }
     if (nb == 2 && !io[0]->first_token && !io[1]->first_token) {
         RUN(cic_finalize_len2(Dual<const int>{w[0].any_unf, w[1].any_unf}, T, Dual<int>{io[0]->L, io[1]->L}, 2, st));
     } else {

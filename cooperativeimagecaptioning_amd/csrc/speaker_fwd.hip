@@ -1019,6 +1019,54 @@ __global__ __launch_bounds__(256) void sample_finish_kernel(FinishArgs a0, Finis
     }
 }
 
+// ---- teacher forcing without scheduled sampling: the fed tokens are the targets, known before the loop ------------------
+// (AttModel.forward, models/AttModel.py:103-148).  The token columns, the unfinished chain and the caption matrix are
+// written up front; the logit product, the log-sum-exp and the gathered log-probabilities run ONCE over all T*B rows
+// after the recurrence (cic_speaker_decode_fwd).
+__global__ __launch_bounds__(256) void teacher_tokens_kernel(const int64_t* __restrict__ pick, int32_t* __restrict__ it_all,
+                                                             int32_t* __restrict__ unfinished, int32_t* __restrict__ any_unf,
+                                                             int32_t* __restrict__ seq, int T, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int unf = 1;
+    for (int t = 1; t <= T; ++t) {
+        const int it = (int)pick[(size_t)t * B + b];
+        unf = (t > 1 ? unf : 1) & (it > 0 ? 1 : 0);             // sample_finish_kernel's bookkeeping, step by step
+        it_all[(size_t)t * B + b] = it;
+        seq[(size_t)b * T + (t - 1)] = unf ? it : 0;
+        if (unf) atomicOr(any_unf + t, 1);
+    }
+    unfinished[b] = unf;
+}
+
+// one wave per row r = t*B + b of the raw logits: lse from the row's partials, slp[b, t] = logit[target] - lse
+__global__ __launch_bounds__(256) void teacher_finish_all_kernel(const float* __restrict__ part, int np, int part_rows,
+                                                                 const float* __restrict__ logits, int ld,
+                                                                 const int64_t* __restrict__ pick, float* __restrict__ lse_all,
+                                                                 float* __restrict__ slp, int T, int B) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= T * B) return;
+    const int t = r / B, b = r % B;
+    const size_t plane = (size_t)part_rows * np;
+    RowPart rp;
+    rp.init();
+    for (int p = lane; p < np; p += 64) {
+        const float* pp = part + (size_t)r * np + p;
+        RowPart q;
+        q.init();
+        q.m1 = pp[0]; q.s1 = pp[plane];
+        rowpart_merge(rp, CIC_SAMPLE_NONE, 1.0f, q);
+    }
+    rp = wave_merge_rowpart(rp, CIC_SAMPLE_NONE, 1.0f);
+    if (lane == 0) {
+        const float lse = rp.m1 + logf(rp.s1);
+        lse_all[r] = lse;
+        const int it = (int)pick[(size_t)(t + 1) * B + b];
+        slp[(size_t)b * T + t] = logits[(size_t)r * ld + it] - lse;
+    }
+}
+
 // L = number of appended columns: the reference breaks at the first t >= 1 whose unfinished
 // sum is 0 (AttModel.py:407-408); otherwise seq_length.
 // (block q = decode q of a pair)
@@ -1289,6 +1337,22 @@ extern "C" int cic_logit_partials(const float* logits, int M, int N, int ld, con
     const int chunk = cic_cdiv(N, nparts);
     hipLaunchKernelGGL(logit_partials_kernel, dim3(cic_cdiv((int64_t)M * nparts, 4)), dim3(256), 0, cic_s(s), logits, M, N, ld, *e,
                        nparts, chunk);
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+
+int cic_teacher_tokens(const int64_t* pick, int32_t* it_all, int32_t* unfinished, int32_t* any_unf, int32_t* seq, int T, int B,
+                       hipStream_t st) {
+    CIC_REQUIRE(pick && it_all && unfinished && any_unf && seq && T > 0 && B > 0);
+    hipLaunchKernelGGL(teacher_tokens_kernel, dim3(cic_cdiv(B, 256)), dim3(256), 0, st, pick, it_all, unfinished, any_unf, seq, T, B);
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+int cic_teacher_finish_all(const float* part, int np, int part_rows, const float* logits, int ld, const int64_t* pick,
+                           float* lse_all, float* slp, int T, int B, hipStream_t st) {
+    CIC_REQUIRE(part && np > 0 && part_rows >= T * B && logits && pick && lse_all && slp && T > 0 && B > 0);
+    hipLaunchKernelGGL(teacher_finish_all_kernel, dim3(cic_cdiv(T * B, 4)), dim3(256), 0, st, part, np, part_rows, logits, ld,
+                       pick, lse_all, slp, T, B);
     CIC_LAUNCH_CHECK();
     return 0;
 }
