@@ -158,6 +158,13 @@ def pmc_mfma_util():
     return None
 
 
+def _rccl_version():
+    try:
+        return '.'.join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:                      # reporting only: never lose the measured line over it
+        return f'unknown ({type(e).__name__})'
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -303,8 +310,7 @@ def main():
                        'excluded': 'host packing + upload of the reference captions (once per resident batch, the loader\'s job)',
                        'final_loss': final_loss,
                        'world': world, 'backend': (args.backend if world > 1 else None),
-                       'rccl': ('.'.join(str(v) for v in torch.cuda.nccl.version())
-                                if world > 1 and args.backend == 'nccl' else None),
+                       'rccl': _rccl_version() if world > 1 and args.backend == 'nccl' else None,
                        'gradient_buckets': {a: list(o.buckets()) for a, o in optimizer_dict.get('speaker', {}).items()}
                        if isinstance(optimizer_dict.get('speaker'), dict) else None},
             # HBM-bound kernel of the path: the per-timestep attention.  achieved = algorithmic bytes of one launch / the
