@@ -854,14 +854,18 @@ def main():
     # BASELINE.json's widths (configs[2]: 36 x 2048 regions, hidden 512, vocabulary 9487, listener 1024), 32 images
     FULLWIDTH = dict(retrieval_reward='gumbel', drop_prob_lm=0.5, vocab_size=9487, input_encoding_size=512, rnn_size=512,
                      fc_feat_size=2048, att_feat_size=2048, att_hid_size=512, vse_embed_size=1024, batch_size=32)
+    # ... and one step with every term on (MLE + VSE on the labels + ST-Gumbel + CIDEr-D, both agents), not alternating
+    FULLWIDTH_ALL = dict(FULLWIDTH, caption_loss_weight=1.0, vse_loss_weight=1.0)
     if only_full:
         joint_case('fullwidth_joint_gumbel', FULLWIDTH, 'speaker', 2.5, regen=True, K=36)
+        joint_case('fullwidth_plain_all', FULLWIDTH_ALL, None, 2.5, regen=True, K=36)
         return
     for name, kw, turn, eos in cases:
         if not only_masks:
             joint_case(name, kw, turn, eos)
     if not only_masks:
         joint_case('fullwidth_joint_gumbel', FULLWIDTH, 'speaker', 2.5, regen=True, K=36)
+        joint_case('fullwidth_plain_all', FULLWIDTH_ALL, None, 2.5, regen=True, K=36)
 
     # ------------------------------------------------------------------ O1 clamp + Adam
     def clamp_adam_case():
