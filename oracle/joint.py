@@ -69,7 +69,10 @@ def joint_forward(Ps, Pl, cfg, batch, noise=None, turn='speaker', is_alternating
             _seqs = _seqs.detach()
             masks = gen_masks_from(_seqs)
             seq = torch.cat([torch.full((_seqs.shape[0], 1), V + 1, dtype=torch.long), _seqs], 1)
-    return _forward_plain(Ps, Pl, cfg, flags, fc, att, att_masks, seq, masks, batch.get('gts'), noise)
+    loss, aux = _forward_plain(Ps, Pl, cfg, flags, fc, att, att_masks, seq, masks, batch.get('gts'), noise)
+    if is_alternating and turn == 'listener':
+        aux['gen_result'] = _seqs                                       # the captions the listener was trained on
+    return loss, aux
 
 
 def _forward_plain(Ps, Pl, cfg, flags, fc, att, att_masks, seq, masks, gts, noise):

@@ -856,9 +856,12 @@ def main():
                      fc_feat_size=2048, att_feat_size=2048, att_hid_size=512, vse_embed_size=1024, batch_size=32)
     # ... and one step with every term on (MLE + VSE on the labels + ST-Gumbel + CIDEr-D, both agents), not alternating
     FULLWIDTH_ALL = dict(FULLWIDTH, caption_loss_weight=1.0, vse_loss_weight=1.0)
+    # ... and the listener's turn of the REINFORCE configuration (BASELINE configs[3]): multinomial captions -> VSE loss
+    FULLWIDTH_LST = dict(FULLWIDTH, retrieval_reward='reinforce', vse_loss_weight=1.0)
     if only_full:
         joint_case('fullwidth_joint_gumbel', FULLWIDTH, 'speaker', 2.5, regen=True, K=36)
         joint_case('fullwidth_plain_all', FULLWIDTH_ALL, None, 2.5, regen=True, K=36)
+        joint_case('fullwidth_reinforce_listener', FULLWIDTH_LST, 'listener', 2.5, regen=True, K=36)
         return
     for name, kw, turn, eos in cases:
         if not only_masks:
@@ -866,6 +869,7 @@ def main():
     if not only_masks:
         joint_case('fullwidth_joint_gumbel', FULLWIDTH, 'speaker', 2.5, regen=True, K=36)
         joint_case('fullwidth_plain_all', FULLWIDTH_ALL, None, 2.5, regen=True, K=36)
+        joint_case('fullwidth_reinforce_listener', FULLWIDTH_LST, 'listener', 2.5, regen=True, K=36)
 
     # ------------------------------------------------------------------ O1 clamp + Adam
     def clamp_adam_case():
