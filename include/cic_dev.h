@@ -12,6 +12,11 @@ extern "C" {
 /* diagnostics: shader clock in MHz (out2[0]) measured over `spin` dependent FMAs; an empty launch */
 int cic_debug_clock_mhz(float* out2, int spin, cic_stream_t s);
 int cic_debug_empty(int grid, int block, cic_stream_t s);
+/* diagnostics: fill-rate probe.  `wgs` workgroups (512 threads, a multiple of 8) each stream floats_per_wg floats out of one
+ * of `regions` regions of region_floats floats; `share` workgroups of one XCD read the same region.  avg_us = average launch
+ * duration over `iters` back-to-back launches. */
+int cic_debug_stream_probe(const float* src, int64_t region_floats, int regions, int wgs, int floats_per_wg, int share,
+                           float* sink, int iters, double* avg_us, cic_stream_t s);
 /* diagnostics: per-workgroup phase stamps of the register-streaming GEMM (NULL = off) */
 int cic_debug_set_stamps(unsigned long long* buf);
 int cic_debug_set_attn_stamps(unsigned long long* buf);
