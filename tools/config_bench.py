@@ -53,6 +53,7 @@ def main():
         from cooperativeimagecaptioning_amd import engine
         engine.lib.cic_debug_gemm_tail_split(int(os.environ['CIC_GEMM_FLAGS'], 0))
     run('C3 joint gumbel + CIDEr-D', steps, ['speaker'], batch_size=128)
+    run('C3 joint gumbel (--compute_dtype bf16)', steps, ['speaker'], batch_size=128, compute_dtype='bf16')
     run('C2 att2in2 MLE (f32)', steps, [None], batch_size=64, is_alternating=0, phase=2, caption_loss_weight=1.0,
         retrieval_reward_weight=0.0, cider_optimization=0, alternating_turn=None)
     run('C2 att2in2 MLE (--compute_dtype bf16)', steps, [None], batch_size=64, is_alternating=0, phase=2, caption_loss_weight=1.0,
