@@ -9,7 +9,12 @@ What the reference does                                  what happens here
   np.stack / np.zeros batch assembly, then .cuda()        images are written straight into PINNED batch buffers (three
                                                           rotating sets): the assembly copy is the staging copy, and
                                                           prefetch.PrefetchLoader's upload is a true asynchronous DMA
-lmdb feature stores are not supported (the library is not in the image)."""
+lmdb feature stores are not supported (the library is not in the image).
+
+Per-image files cannot feed a 4 ms step (128 images x 295 KB through zip / np.load per batch): a PACKED store - one
+`.npy` array [N, ...] per feature kind next to `<file>.index.json` {image key: row}, written once by
+tools/pack_features.py from the per-image files - is memory-mapped instead, and a batch is then 128 row copies out of the
+page cache, done by the reader threads in parallel straight into the pinned batch buffer."""
 import json
 import os
 import random
@@ -24,12 +29,22 @@ class HybridLoader:
 
     def __init__(self, db_path, ext):
         self.db_path, self.ext = db_path, ext
+        self.packed = None
+        if db_path.endswith('.npy') and os.path.isfile(db_path):
+            # packed store (this repository's extension): one memory-mapped array, rows named by the index file
+            self._mmap = np.load(db_path, mmap_mode='r')
+            self.packed = self._mmap.view(np.ndarray)      # plain views of the mapping: np.memmap's per-slice bookkeeping costs ~10 us
+            with open(db_path + '.index.json') as f:
+                self.index = {str(k): int(v) for k, v in json.load(f).items()}
+            return
         if db_path.endswith('.lmdb'):
             raise NotImplementedError('lmdb feature stores need the lmdb package, which is not available here: '
                                       'use a directory of per-image .npy / .npz files')
         self.loader = (lambda x: np.load(x)) if ext == '.npy' else (lambda x: np.load(x)['feat'])
 
     def get(self, key):
+        if self.packed is not None:
+            return self.packed[self.index[key]]            # a view of the mapping: copied when the batch is assembled
         return self.loader(os.path.join(self.db_path, key + self.ext))
 
 
@@ -100,6 +115,8 @@ class DataLoader:
             print('assigned %d images to split %s' % (len(self.split_ix[s]), s))
         self.iterators = {'train': 0, 'val': 0, 'test': 0}
         self._pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix='cic-reader')
+        self._workers = workers
+        self._packed = self.att_loader.packed is not None and self.fc_loader.packed is not None
         self._window = window or 2 * self.batch_size
         self._queue = {s: [] for s in self.split_ix}      # [(ix, wrapped, future)] read ahead, in hand-out order
         self._cursor = dict(self.iterators)               # position of the read-ahead (>= iterators)
@@ -118,7 +135,8 @@ class DataLoader:
 
     def reset_iterator(self, split):
         for _, _, fut in self._queue[split]:
-            fut.cancel()
+            if fut is not None:
+                fut.cancel()
         self._queue[split] = []
         self.iterators[split] = 0
         self._cursor[split] = 0
@@ -133,7 +151,8 @@ class DataLoader:
     def load_state_dict(self, st):
         for s in self.split_ix:
             for _, _, fut in self._queue[s]:
-                fut.cancel()
+                if fut is not None:
+                    fut.cancel()
             self._queue[s] = []
         self.iterators.update(st.get('iterators', {}))
         if st.get('split_ix'):
@@ -192,7 +211,8 @@ class DataLoader:
             if q and q[-1][1]:
                 break                                       # the epoch ended: the next one is scheduled after its shuffle
             ix, wrapped = self._advance(split)
-            q.append((ix, wrapped, self._pool.submit(self.__getitem__, ix)))
+            # per-image files are read ahead by the pool; rows of a packed store are views of the mapping: nothing to read yet
+            q.append((ix, wrapped, None if self._packed else self._pool.submit(self.__getitem__, ix)))
 
     def _next(self, split):
         self._fill(split, 1)
@@ -200,7 +220,7 @@ class DataLoader:
         if wrapped and split == 'train':
             random.shuffle(self.split_ix[split])            # :352-353: shuffled when the epoch wraps
         self.iterators[split] = 0 if wrapped else self.iterators[split] + 1
-        fc, att, ix2 = fut.result()
+        fc, att, ix2 = fut.result() if fut is not None else self.__getitem__(ix)
         assert ix2 == ix, 'ix not equal'
         return fc, att, ix, wrapped
 
@@ -211,8 +231,18 @@ class DataLoader:
             b = self._buffers[key] = pinned_empty(shape, dtype, pin=getattr(self.opt, 'pin_memory', 1))
         return b
 
-    # ---- the batch (:174-248)
+    # ---- the batch (:174-248), in two phases so that a prefetcher can keep the large copies off the training thread:
+    # begin_batch() does the bookkeeping (which images, captions, labels, masks) and hands the feature copies into the
+    # pinned buffers to the reader threads; end_batch() waits for them.  get_batch() = both, the reference's call.
     def get_batch(self, split, batch_size=None):
+        return self.end_batch(self.begin_batch(split, batch_size))
+
+    def end_batch(self, handle):
+        for f in handle['copies']:
+            f.result()
+        return handle['data']
+
+    def begin_batch(self, split, batch_size=None):
         batch_size = batch_size or self.batch_size
         spi = self.seq_per_img
         self._fill(split, min(self._window + batch_size, len(self.split_ix[split])))
@@ -236,17 +266,21 @@ class DataLoader:
         self._turn += 1
         data = {}
         fcb = self._buffer('fc', (batch_size * spi,) + tuple(fcs[0].shape), torch.float32)
-        for i, f in enumerate(fcs):
-            fcb[i * spi:(i + 1) * spi] = f
         data['fc_feats'] = fcb
         max_att_len = max(a.shape[0] for a in atts)
         attb = self._buffer('att', (batch_size * spi, max_att_len, atts[0].shape[1]), torch.float32)
         masks_att = np.zeros(attb.shape[:2], dtype='float32')
         for i, a in enumerate(atts):
+            masks_att[i * spi:(i + 1) * spi, :a.shape[0]] = 1
+
+        def place(i):                                       # numpy releases the GIL inside these copies
+            a = atts[i]
+            fcb[i * spi:(i + 1) * spi] = fcs[i]
             attb[i * spi:(i + 1) * spi, :a.shape[0]] = a
             if a.shape[0] < max_att_len:
                 attb[i * spi:(i + 1) * spi, a.shape[0]:] = 0
-            masks_att[i * spi:(i + 1) * spi, :a.shape[0]] = 1
+        # the feature rows go into the pinned buffers on the reader threads, a slice of the batch per worker (rows of a
+        # packed store come out of the page cache here; per-image files were read ahead and are only copied)
         data['att_feats'] = attb
         data['att_masks'] = None if masks_att.sum() == masks_att.size else masks_att      # :228-229
         labels = self._buffer('labels', (batch_size * spi, self.seq_length + 2), torch.int64)
@@ -259,7 +293,10 @@ class DataLoader:
         data['gts'] = gts
         data['bounds'] = {'it_pos_now': self.iterators[split], 'it_max': len(self.split_ix[split]), 'wrapped': wrapped}
         data['infos'] = infos
-        return data
+        # submitted last: the bookkeeping above does not then share the interpreter with the copy threads
+        n, w = len(atts), self._workers
+        copies = [self._pool.submit(lambda c=c: [place(i) for i in range(c, n, w)]) for c in range(min(w, n))]
+        return {'data': data, 'copies': copies}
 
     def close(self):
         self._pool.shutdown(wait=False, cancel_futures=True)

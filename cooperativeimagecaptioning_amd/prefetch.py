@@ -12,7 +12,10 @@ pipelines the hand-over from the training thread itself:
                   computes step i) and packs the reference captions for the CIDEr-D kernels.
 
 No staging thread: the training thread is a tight loop of short GIL-holding launch calls, and a Python thread
-beside it was measured to cost 10-27 ms per iteration in GIL hand-overs (tools/loader_bench.py)."""
+beside it was measured to cost 10-27 ms per iteration in GIL hand-overs (tools/loader_bench.py).  What does run beside
+it are the loader's reader threads inside numpy copies (no GIL): a loader with begin_batch() / end_batch()
+(dataloader.DataLoader) is driven two batches ahead - batch i+2 is being copied into its pinned buffers while batch i+1
+uploads and step i computes."""
 import numpy as np
 import torch
 
@@ -32,11 +35,14 @@ class PrefetchLoader:
         self.seq_length = getattr(loader, 'seq_length', None)
         self._stream = torch.cuda.Stream(device=self.device)
         self._next = None
+        self._assembling = None   # begin_batch() handle of the batch after the uploaded one (two-phase loaders)
+        self._uploads = []        # completion events of the last two uploads
+        self._two_phase = hasattr(loader, 'begin_batch') and hasattr(loader, 'end_batch')
         self.pageable_bytes = 0   # bytes uploaded from pageable memory (0 with a pinning loader, but for the packed captions)
 
     def ahead(self):
         """Batches pulled from the wrapped loader but not handed to the trainer yet (a resume replays them)."""
-        return 0 if self._next is None else 1
+        return (0 if self._next is None else 1) + (0 if self._assembling is None else 1)
 
     def _pinned(self, key, t):
         if not t.is_pinned():
@@ -47,7 +53,16 @@ class PrefetchLoader:
         """Pull the next batch and upload it on the copy stream (call after the current step is enqueued)."""
         if self._next is not None:
             return
-        data = self.loader.get_batch(self.split)
+        if self._two_phase:
+            handle = self._assembling if self._assembling is not None else self.loader.begin_batch(self.split)
+            data = self.loader.end_batch(handle)                   # copied while the previous step was computing
+            # the loader rotates three sets of pinned buffers: the set the next assembly writes was the source of the
+            # upload issued two calls ago - that DMA has long finished, but nothing may overwrite it before it has
+            if len(self._uploads) >= 2:
+                self._uploads[-2].synchronize()
+            self._assembling = self.loader.begin_batch(self.split)  # the batch after it: its copies start now
+        else:
+            data = self.loader.get_batch(self.split)
         out = dict(data)
         with torch.cuda.stream(self._stream):
             for k in _TENSOR_KEYS:
@@ -63,6 +78,7 @@ class PrefetchLoader:
                                     self._pinned('ref_off', torch.from_numpy(off)).to(self.device, non_blocking=True))   # see AlternatingJointModel._refs
             ev = torch.cuda.Event()
             ev.record(self._stream)
+        self._uploads = (self._uploads + [ev])[-2:]
         self._next = (out, ev)
 
     def get_batch(self, split=None):
@@ -81,4 +97,6 @@ class PrefetchLoader:
         return data
 
     def close(self):
-        self._next = None
+        if self._assembling is not None:
+            self.loader.end_batch(self._assembling)                # let the reader threads finish with the pinned buffers
+        self._next = self._assembling = None

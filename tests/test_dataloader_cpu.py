@@ -83,3 +83,37 @@ def test_val_split_and_unsupported_stores(tmp_path):
     dl.close()
     with pytest.raises(NotImplementedError):
         HybridLoader('features.lmdb', '.npy')
+
+
+def test_packed_store_hands_out_the_same_batches(tmp_path):
+    """tools/pack_features.py -> one memory-mapped .npy per feature kind: the loader reads rows of the mapping instead of
+    per-image files and must hand out, batch for batch, what the per-image loader hands out."""
+    import subprocess
+    import sys
+    from cooperativeimagecaptioning_amd.dataloader import DataLoader
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    opt, images, feats, labels, start, end = _dataset(str(tmp_path), ragged=False)
+    packed = {}
+    for kind, src in (('fc', opt.input_fc_dir), ('att', opt.input_att_dir)):
+        out = os.path.join(str(tmp_path), kind + '_packed.npy')
+        r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'pack_features.py'), src, out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        packed[kind] = out
+    opt_p = argparse.Namespace(**vars(opt))
+    opt_p.input_fc_dir, opt_p.input_att_dir = packed['fc'], packed['att']
+    random.seed(5)
+    a = DataLoader(opt, workers=2)
+    random.seed(5)
+    b = DataLoader(opt_p, workers=2)
+    assert b.att_loader.packed is not None and b.fc_loader.packed is not None
+    for _ in range(4):                                   # over an epoch boundary (9 training images, 4 per batch)
+        random.seed(11)
+        da = a.get_batch('train')
+        random.seed(11)
+        db = b.get_batch('train')
+        for k in ('fc_feats', 'att_feats', 'labels', 'masks'):
+            np.testing.assert_array_equal(da[k], db[k], err_msg=k)
+        assert da['att_masks'] is None and db['att_masks'] is None
+        assert [i['ix'] for i in da['infos']] == [i['ix'] for i in db['infos']]
+    a.close()
+    b.close()
