@@ -76,7 +76,7 @@ class DataLoader:
 
     N_BUFFERS = 3        # batch i is consumed by the step, i+1 is uploading, i+2 is being filled
 
-    def __init__(self, opt, workers=4, window=None):
+    def __init__(self, opt, workers=None, window=None):
         self.opt = opt
         self.batch_size = opt.batch_size
         self.seq_per_img = opt.seq_per_img
@@ -114,6 +114,8 @@ class DataLoader:
         for s in ('train', 'val', 'test'):
             print('assigned %d images to split %s' % (len(self.split_ix[s]), s))
         self.iterators = {'train': 0, 'val': 0, 'test': 0}
+        if workers is None:                                 # the reference runs 4 loader processes (:337); threads are cheaper
+            workers = max(2, min(8, (os.cpu_count() or 4) // 2))
         self._pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix='cic-reader')
         self._workers = workers
         self._packed = self.att_loader.packed is not None and self.fc_loader.packed is not None
