@@ -858,10 +858,13 @@ def main():
     FULLWIDTH_ALL = dict(FULLWIDTH, caption_loss_weight=1.0, vse_loss_weight=1.0)
     # ... and the listener's turn of the REINFORCE configuration (BASELINE configs[3]): multinomial captions -> VSE loss
     FULLWIDTH_LST = dict(FULLWIDTH, retrieval_reward='reinforce', vse_loss_weight=1.0)
+    # ... and its speaker's turn: REINFORCE with the ground-truth baseline + self-critical CIDEr-D
+    FULLWIDTH_RF = dict(FULLWIDTH, retrieval_reward='reinforce', reinforce_baseline_type='gt')
     if only_full:
         joint_case('fullwidth_joint_gumbel', FULLWIDTH, 'speaker', 2.5, regen=True, K=36)
         joint_case('fullwidth_plain_all', FULLWIDTH_ALL, None, 2.5, regen=True, K=36)
         joint_case('fullwidth_reinforce_listener', FULLWIDTH_LST, 'listener', 2.5, regen=True, K=36)
+        joint_case('fullwidth_reinforce_speaker', FULLWIDTH_RF, 'speaker', 2.5, regen=True, K=36)
         return
     for name, kw, turn, eos in cases:
         if not only_masks:
@@ -870,6 +873,7 @@ def main():
         joint_case('fullwidth_joint_gumbel', FULLWIDTH, 'speaker', 2.5, regen=True, K=36)
         joint_case('fullwidth_plain_all', FULLWIDTH_ALL, None, 2.5, regen=True, K=36)
         joint_case('fullwidth_reinforce_listener', FULLWIDTH_LST, 'listener', 2.5, regen=True, K=36)
+        joint_case('fullwidth_reinforce_speaker', FULLWIDTH_RF, 'speaker', 2.5, regen=True, K=36)
 
     # ------------------------------------------------------------------ O1 clamp + Adam
     def clamp_adam_case():
