@@ -860,11 +860,14 @@ def main():
     FULLWIDTH_LST = dict(FULLWIDTH, retrieval_reward='reinforce', vse_loss_weight=1.0)
     # ... and its speaker's turn: REINFORCE with the ground-truth baseline + self-critical CIDEr-D
     FULLWIDTH_RF = dict(FULLWIDTH, retrieval_reward='reinforce', reinforce_baseline_type='gt')
+    # ... and BASELINE configs[2] itself: the headline step at its own batch size
+    FULLSIZE = dict(FULLWIDTH, batch_size=128)
     if only_full:
         joint_case('fullwidth_joint_gumbel', FULLWIDTH, 'speaker', 2.5, regen=True, K=36)
         joint_case('fullwidth_plain_all', FULLWIDTH_ALL, None, 2.5, regen=True, K=36)
         joint_case('fullwidth_reinforce_listener', FULLWIDTH_LST, 'listener', 2.5, regen=True, K=36)
         joint_case('fullwidth_reinforce_speaker', FULLWIDTH_RF, 'speaker', 2.5, regen=True, K=36)
+        joint_case('fullsize_joint_gumbel', FULLSIZE, 'speaker', 2.5, regen=True, K=36)
         return
     for name, kw, turn, eos in cases:
         if not only_masks:
@@ -874,6 +877,7 @@ def main():
         joint_case('fullwidth_plain_all', FULLWIDTH_ALL, None, 2.5, regen=True, K=36)
         joint_case('fullwidth_reinforce_listener', FULLWIDTH_LST, 'listener', 2.5, regen=True, K=36)
         joint_case('fullwidth_reinforce_speaker', FULLWIDTH_RF, 'speaker', 2.5, regen=True, K=36)
+        joint_case('fullsize_joint_gumbel', FULLSIZE, 'speaker', 2.5, regen=True, K=36)
 
     # ------------------------------------------------------------------ O1 clamp + Adam
     def clamp_adam_case():
