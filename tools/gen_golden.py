@@ -798,6 +798,8 @@ def main():
                 continue
             ok = all(len(sh[1]) >= 2 for sh in shapes) and any(len(sh[1]) >= 3 for sh in shapes)
             early = any(sh[0] < opt.seq_length for sh in shapes)
+            if not shapes:                      # a step without sampled decodes (MLE only): nothing to scan for
+                ok = early = True
             if ok and (early or found is None):
                 found = float(bias)
                 if early:
@@ -862,12 +864,15 @@ def main():
     FULLWIDTH_RF = dict(FULLWIDTH, retrieval_reward='reinforce', reinforce_baseline_type='gt')
     # ... and BASELINE configs[2] itself: the headline step at its own batch size
     FULLSIZE = dict(FULLWIDTH, batch_size=128)
+    # ... and BASELINE configs[1]: the MLE step at B = 64
+    FULLSIZE_MLE = dict(FULLWIDTH, batch_size=64, caption_loss_weight=1.0, retrieval_reward_weight=0.0, cider_optimization=0)
     if only_full:
         joint_case('fullwidth_joint_gumbel', FULLWIDTH, 'speaker', 2.5, regen=True, K=36)
         joint_case('fullwidth_plain_all', FULLWIDTH_ALL, None, 2.5, regen=True, K=36)
         joint_case('fullwidth_reinforce_listener', FULLWIDTH_LST, 'listener', 2.5, regen=True, K=36)
         joint_case('fullwidth_reinforce_speaker', FULLWIDTH_RF, 'speaker', 2.5, regen=True, K=36)
         joint_case('fullsize_joint_gumbel', FULLSIZE, 'speaker', 2.5, regen=True, K=36)
+        joint_case('fullsize_mle', FULLSIZE_MLE, None, 2.5, regen=True, K=36)
         return
     for name, kw, turn, eos in cases:
         if not only_masks:
@@ -878,6 +883,7 @@ def main():
         joint_case('fullwidth_reinforce_listener', FULLWIDTH_LST, 'listener', 2.5, regen=True, K=36)
         joint_case('fullwidth_reinforce_speaker', FULLWIDTH_RF, 'speaker', 2.5, regen=True, K=36)
         joint_case('fullsize_joint_gumbel', FULLSIZE, 'speaker', 2.5, regen=True, K=36)
+        joint_case('fullsize_mle', FULLSIZE_MLE, None, 2.5, regen=True, K=36)
 
     # ------------------------------------------------------------------ O1 clamp + Adam
     def clamp_adam_case():
