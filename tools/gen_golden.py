@@ -865,6 +865,8 @@ def main():
     # ... and BASELINE configs[2] itself: the headline step at its own batch size
     FULLSIZE = dict(FULLWIDTH, batch_size=128)
     # ... and BASELINE configs[1]: the MLE step at B = 64
+    # ... and BASELINE configs[3]: the speaker's turn of the REINFORCE configuration at B = 256
+    FULLSIZE_RF = dict(FULLWIDTH_RF, batch_size=256)
     FULLSIZE_MLE = dict(FULLWIDTH, batch_size=64, caption_loss_weight=1.0, retrieval_reward_weight=0.0, cider_optimization=0)
     if only_full:
         joint_case('fullwidth_joint_gumbel', FULLWIDTH, 'speaker', 2.5, regen=True, K=36)
@@ -873,6 +875,7 @@ def main():
         joint_case('fullwidth_reinforce_speaker', FULLWIDTH_RF, 'speaker', 2.5, regen=True, K=36)
         joint_case('fullsize_joint_gumbel', FULLSIZE, 'speaker', 2.5, regen=True, K=36)
         joint_case('fullsize_mle', FULLSIZE_MLE, None, 2.5, regen=True, K=36)
+        joint_case('fullsize_reinforce_speaker', FULLSIZE_RF, 'speaker', 2.5, regen=True, K=36)
         return
     for name, kw, turn, eos in cases:
         if not only_masks:
@@ -884,6 +887,7 @@ def main():
         joint_case('fullwidth_reinforce_speaker', FULLWIDTH_RF, 'speaker', 2.5, regen=True, K=36)
         joint_case('fullsize_joint_gumbel', FULLSIZE, 'speaker', 2.5, regen=True, K=36)
         joint_case('fullsize_mle', FULLSIZE_MLE, None, 2.5, regen=True, K=36)
+        joint_case('fullsize_reinforce_speaker', FULLSIZE_RF, 'speaker', 2.5, regen=True, K=36)
 
     # ------------------------------------------------------------------ O1 clamp + Adam
     def clamp_adam_case():
