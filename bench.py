@@ -180,6 +180,9 @@ def main():
     ap.add_argument('--same-device', action='store_true', help='rehearsal: every rank uses cuda:0 (gloo backend only)')
     args = ap.parse_args()
 
+    if os.environ.get('CIC_HANG_DUMP'):          # diagnostics: Python stacks of every thread after N seconds, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['CIC_HANG_DUMP']), exit=True)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

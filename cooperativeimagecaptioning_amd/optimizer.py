@@ -82,6 +82,11 @@ class FlatAdam:
                 raise RuntimeError(f'gradient bucket "{name}" was already exchanged in this step: begin_all_reduce() '
                                    f'runs once per bucket between zero_grad() and step()')
             self._pending[name] = dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, async_op=True)
+            # RCCL queues its collectives on one stream in issue order; gloo (rehearsals on CPU or on a shared GPU) runs them
+            # on worker threads, and several large exchanges in flight deadlocked it at 4 ranks (2 were fine): with gloo each
+            # exchange completes before the next is issued.  The handle stays in _pending (waiting again is a no-op).
+            if dist.get_backend() == 'gloo':
+                self._pending[name].wait()
 
     def all_reduce_grads(self):
         """Every bucket summed over the ranks (one collective per bucket); returns the 1/world scale that is folded
