@@ -157,8 +157,14 @@ def train(opt, loader=None):
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        # RCCL over xGMI, one rank per GPU.  CIC_DIST_BACKEND=gloo CIC_SAME_DEVICE=1 rehearses the multi-process loop on a
+        # box with fewer GPUs than ranks (every rank on cuda:0, exchanges through the host)
+        backend = os.environ.get('CIC_DIST_BACKEND', 'nccl')
+        if os.environ.get('CIC_SAME_DEVICE') == '1':
+            assert backend == 'gloo', 'CIC_SAME_DEVICE is a gloo rehearsal (RCCL wants one GPU per rank)'
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl')                      # RCCL over xGMI: one rank per GPU
+        dist.init_process_group(backend)
     device = torch.device('cuda', local_rank)
     opt.use_att = utils.if_use_att(opt)
     made_synthetic = False
