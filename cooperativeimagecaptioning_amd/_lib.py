@@ -46,7 +46,8 @@ class GemmArgs(C.Structure):
                 ('n_split', C.c_int), ('B2_tail', c_ptr), ('ldb2_tail', C.c_int), ('bias_tail', c_ptr),
                 ('C_tail', c_ptr), ('C_tail_b', c_ptr), ('ldc_tail', C.c_int),
                 ('epi', c_ptr),        # fused vocabulary epilogue (the decode engine's logit product); NULL here
-                ('precision', C.c_int)]   # 0 f32 accuracy (default), 1 f32-input MFMA only, 2 bf16 operands
+                ('precision', C.c_int),   # 0 f32 accuracy (default), 1 f32-input MFMA only, 2 bf16 operands
+                ('B_parts', c_ptr)]       # B pre-split by cic_split_bf16x3 (the logit weights), or NULL
 
 
 class SamplerArgs(C.Structure):

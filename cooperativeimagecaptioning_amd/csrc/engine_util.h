@@ -32,6 +32,7 @@ struct SpkWs {
     int32_t *it_all, *unfinished, *any_unf;   // [T+1,B], [B], [T+1]
     uint16_t *att_bf, *p_att_bf;              // bf16 copies of att / p_att (compute_dtype bf16 only)
     float *part, *lse_all;                    // row partials of one step's logits [6][B][nparts]; [T,B] log-sum-exp rows
+    uint16_t* logit_parts;                    // [3][V+1][H] bf16: the logit weights cut into their parts once per decode
     size_t bytes;
 };
 SpkWs spk_carve(const cic_speaker_dims& d, void* base);

@@ -1760,14 +1760,15 @@ __global__ __launch_bounds__(256 * KH) __attribute__((amdgpu_waves_per_eu(KH, KH
 // wave reads the three parts of a k-step (32 k) one step ahead of the MFMAs that use them, and its A fragments are the
 // three parts of its K half (96 VGPRs).  Terms of like magnitude share an accumulator chain (parts 0x2, 2x0, 1x1 | 0x1,
 // 1x0 | 0x0), the chains are added smallest first.
-template <int NG, int EPI>
+template <int NG, int EPI, int PRE>   // PRE: the weights arrive already split (three bf16 images [3][N][K], cic_split_bf16x3)
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_ldsb2bf_walk_kernel(
-    cic_gemm_args g, int row_groups, int walkers, cic_logit_epilogue epi) {
+    cic_gemm_args g, int row_groups, int walkers, cic_logit_epilogue epi, const __bf16* __restrict__ wparts) {
     constexpr int KH = 2, K = 16 * NG, NT = 512;
     constexpr int LDBH = K + 8, PART = 16 * LDBH, TILEH = 3 * PART;   // bf16 per staged row / part / tile
     constexpr int JS = K / KH / 32;                        // k-steps of 32 per wave
     constexpr int F4 = 16 * (K / 4) / NT;                  // float4 per thread and staged tile
-    static_assert(F4 <= JS && (TILEH % 8) == 0, "the staged float4 ride behind the last k-steps of a tile");
+    constexpr int NPC = PRE ? 3 * 16 * (K / 8) / NT : F4;  // staged pieces per thread and tile (PRE: 16-byte pieces of the images)
+    static_assert(NPC <= JS && (TILEH % 8) == 0, "the staged pieces ride behind the last k-steps of a tile");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __bf16* ldsh = reinterpret_cast<__bf16*>(lds);
     float* pairbuf = lds + TILEH;                          // (2 tiles of TILEH bf16 = TILEH floats) [2 parities][4 row tiles][1 upper part][4 registers][64 lanes]
@@ -1788,8 +1789,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int m = m0 + 16 * rt + li;
     const int mc = m < Mloc ? m : Mloc - 1;                // rows beyond M re-read row M-1: never stored
     f32x4 stg[F4];
+    bf16x8 stp[PRE ? NPC : 1];
     auto load_tile = [&](int t) {
         const int tt = t < tiles_n ? t : tiles_n - 1;
+        if (PRE) {
+#pragma unroll
+            for (int e = 0; e < NPC; ++e) {
+                const int j = tid + NT * e;
+                const int p = j / (16 * (K / 8)), rem = j % (16 * (K / 8));
+                const int r = rem / (K / 8), c8 = rem % (K / 8);
+                const int n = tt * 16 + r;
+                const int nc = n < g.N ? n : g.N - 1;
+                stp[e] = *reinterpret_cast<const bf16x8*>(wparts + ((size_t)p * g.N + nc) * K + 8 * c8);
+            }
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < F4; ++e) {
             const int j = tid + NT * e;
@@ -1800,6 +1814,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
     auto store_piece = [&](__bf16* dst, int e) {          // four k of one column -> the three bf16 images
+        if (PRE) {                                         // a 16-byte piece of one image, as it is
+            const int j = tid + NT * e;
+            const int p = j / (16 * (K / 8)), rem = j % (16 * (K / 8));
+            const int r = rem / (K / 8), c8 = rem % (K / 8);
+            *reinterpret_cast<bf16x8*>(dst + p * PART + r * LDBH + 8 * c8) = stp[e];
+            return;
+        }
         const int j = tid + NT * e;
         const int r = j / (K / 4), c4 = j % (K / 4);
         bf16x4 parts[3];
@@ -1822,7 +1843,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int e = 0; e < F4; ++e) store_piece(ldsh, e);
+    for (int e = 0; e < NPC; ++e) store_piece(ldsh, e);
     __syncthreads();
     int buf = 0;
     float prev[4];                                         // the previous tile's sums of this wave's K half
@@ -1952,7 +1973,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                     if (ROLE == 1) __builtin_amdgcn_sched_barrier(0);   // the lower wave's slots stay between the k-steps
                 }
-                if (j >= JS - F4) { store_piece(nxt, j - (JS - F4)); __builtin_amdgcn_sched_barrier(0); }
+                if (j >= JS - NPC) { store_piece(nxt, j - (JS - NPC)); __builtin_amdgcn_sched_barrier(0); }
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -2015,6 +2036,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const f32x4* __restrict__ x, int64_t n4, bf16x4* __restrict__ parts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    bf16x4 p[3];
+    split_bf16<3>(x[i], p);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) parts[(int64_t)q * n4 + i] = p[q];
+}
+
 bool ldsb_walk_ok(const cic_gemm_args& g) {
     return g.a_kc && g.b_kc && g.K2 == 0 && g.K == 512 && g.N >= 2048 && !g.accumulate && !g.relu &&
            (g.lda & 3) == 0 && (g.ldb & 3) == 0 && aligned16(g.A) && aligned16(g.B) && (g.rows_blk == 0 || aligned16(g.A_b));
@@ -2061,16 +2091,25 @@ int launch_ldsb_walk(const cic_gemm_args& g, hipStream_t st) {
             constexpr size_t bf_bytes = 2 * 3 * 16 * (16 * NG + 8) * 2 + 2 * 4 * 1 * 4 * 64 * sizeof(float) + 2 * 4 * 4 * 64 * sizeof(float);
             static bool attr3_set = false;
             if (!attr3_set) {
-                CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2bf_walk_kernel<NG, 0>),
+                CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2bf_walk_kernel<NG, 0, 0>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf_bytes));
-                CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2bf_walk_kernel<NG, 1>),
+                CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2bf_walk_kernel<NG, 1, 0>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf_bytes));
+                CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2bf_walk_kernel<NG, 0, 1>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf_bytes));
+                CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2bf_walk_kernel<NG, 1, 1>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf_bytes));
                 attr3_set = true;
             }
-            if (g.epi)
-                hipLaunchKernelGGL((gemm_ldsb2bf_walk_kernel<NG, 1>), dim3(grid), dim3(512), bf_bytes, st, g, row_groups, walkers, epi);
+            const __bf16* wparts = reinterpret_cast<const __bf16*>(g.B_parts);
+            if (wparts && g.epi)
+                hipLaunchKernelGGL((gemm_ldsb2bf_walk_kernel<NG, 1, 1>), dim3(grid), dim3(512), bf_bytes, st, g, row_groups, walkers, epi, wparts);
+            else if (wparts)
+                hipLaunchKernelGGL((gemm_ldsb2bf_walk_kernel<NG, 0, 1>), dim3(grid), dim3(512), bf_bytes, st, g, row_groups, walkers, epi, wparts);
+            else if (g.epi)
+                hipLaunchKernelGGL((gemm_ldsb2bf_walk_kernel<NG, 1, 0>), dim3(grid), dim3(512), bf_bytes, st, g, row_groups, walkers, epi, wparts);
             else
-                hipLaunchKernelGGL((gemm_ldsb2bf_walk_kernel<NG, 0>), dim3(grid), dim3(512), bf_bytes, st, g, row_groups, walkers, epi);
+                hipLaunchKernelGGL((gemm_ldsb2bf_walk_kernel<NG, 0, 0>), dim3(grid), dim3(512), bf_bytes, st, g, row_groups, walkers, epi, wparts);
             CIC_LAUNCH_CHECK();
             return 0;
         }
@@ -2437,6 +2476,14 @@ extern "C" int cic_gemm_f32(const cic_gemm_args* a, cic_stream_t s) {
 }
 
 // Average duration of one cic_gemm_f32 launch: `iters` back-to-back launches between two HIP events on `s`.
+extern "C" int cic_split_bf16x3(const float* x, int64_t n, uint16_t* parts, cic_stream_t s) {
+    CIC_REQUIRE(x && parts && n > 0 && (n & 3) == 0 && aligned16(x) && ((uintptr_t)parts & 7) == 0);
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3(cic_cdiv(n / 4, 256)), dim3(256), 0, cic_s(s), reinterpret_cast<const f32x4*>(x),
+                       n / 4, reinterpret_cast<bf16x4*>(parts));
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int cic_gemm_f32_timed(const cic_gemm_args* a, int iters, double* avg_us, cic_stream_t s) {
     CIC_REQUIRE(a && iters > 0 && avg_us);
     hipEvent_t e0, e1;

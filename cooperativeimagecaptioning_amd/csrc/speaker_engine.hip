@@ -97,6 +97,7 @@ SpkWs spk_carve(const cic_speaker_dims& d, void* base) {
     w.p_att_bf = c.u16(B * K * A);
     w.part = c.f32((size_t)CIC_PART_PLANES * CIC_PART_MAX_ENTRIES);
     w.lse_all = c.f32(T * B);
+    w.logit_parts = c.u16(3 * V1 * H);
     w.bytes = c.used();
     return w;
 }
@@ -260,6 +261,10 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
                                xk1 ? p_drop : 0.f, Dual<float>{w[0].x_all + (size_t)B * E, nullptr}, (T - 1) * B, 1, E, st, 0));
         }
     }
+    // The logit weights are read unchanged by every step's logit product: cut them into their three bf16 parts once per
+    // decode (8 us) instead of once per weight tile and workgroup inside the walker (cic_gemm_args.B_parts; bit-identical)
+    const bool presplit_logit = !teacher_batched && !ps && H == 512 && V1 >= 2048 && ((size_t)V1 * H) % 4 == 0;   // the walker's shapes
+    if (presplit_logit) RUN(cic_split_bf16x3(p->logit_w, (int64_t)V1 * H, w[0].logit_parts, s));
     for (int t = 0; t < T; ++t) {
         const Dual<float> x = SLAB(x_all, B * E), att_h = SLAB(att_h_all, B * A), att_res = SLAB(att_res_all, B * H),
                           pre = SLAB(pre_all, B * 5 * H), out = SLAB(out_all, B * H), logp = SLAB(logp_all, B * V1);
@@ -351,6 +356,7 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         cic_gemm_args lg = {};
         lg.M = M; lg.N = V1; lg.K = H; lg.A = out.a; lg.lda = H; lg.a_kc = 1; lg.B = p->logit_w; lg.ldb = H; lg.b_kc = 1;
         lg.C = logp.a; lg.ldc = V1; lg.bias = p->logit_b;
+        if (presplit_logit) lg.B_parts = w[0].logit_parts;
         if (nb == 2) { lg.rows_blk = B; lg.A_b = out.b; lg.C_b = logp.b; }
         cic_logit_epilogue epi = {};
         int np = 0;

@@ -24,6 +24,7 @@ _gemm = _sig('cic_gemm_f32', [C.POINTER(GemmArgs), P])
 # every entry point gets its signature here or in engine.py: ctypes would pass an undeclared Python int as a 32-bit int
 _sig('cic_gemm_logit_parts', [C.POINTER(GemmArgs)])
 _sig('cic_gemm_split_ok', [C.POINTER(GemmArgs)])
+_split3 = _sig('cic_split_bf16x3', [P, L64, P, P])
 _sig('cic_gemm_f32_timed', [C.POINTER(GemmArgs), I, C.POINTER(C.c_double), P])
 _sig('cic_logit_partials', [P, I, I, I, P, I, P])
 _sig('cic_attn_fwd_timed', [P] * 7 + [I] * 5 + [P, L64, C.POINTER(C.c_double), P])
@@ -61,6 +62,12 @@ def dropout_keep_multi_(keeps, p, seed, offsets):
     offs = (U64 * k)(*offsets)
     check(_keep_multi(ptrs, ns, offs, k, float(p), seed, stream()), 'cic_dropout_keep_u8_multi')
     return keeps
+
+
+def split_bf16x3_(x, parts):
+    """parts (int16 / uint16 view, 3 * x.numel() elements) <- the three bf16 parts of f32 x."""
+    check(_split3(ptr(_dev(x)), x.numel(), ptr(_dev(parts)), stream()), 'cic_split_bf16x3')
+    return parts
 
 
 def gemm(A, B, C_, a_kc=True, b_kc=True, bias=None, accumulate=False, relu=False, A2=None, B2=None,

@@ -120,6 +120,10 @@ typedef struct {
      *   CIC_PRECISION_F32_MFMA: the f32-input MFMA only (bitwise a k-ordered f32 fma chain per output);
      *   CIC_PRECISION_BF16: operands rounded to bf16 once, f32 accumulation (reduced precision, ~3e-3 relative). */
     int precision;
+    /* Optional: B already cut into its three bf16 parts (cic_split_bf16x3: uint16 images [3][N][K], K-contiguous), for a B
+     * that many launches read unchanged (the logit weights: T launches per decode).  Used by the logit walker only; the
+     * results are those of the launch without it, bit for bit.  NULL elsewhere. */
+    const uint16_t* B_parts;
 } cic_gemm_args;
 enum { CIC_PRECISION_F32 = 0, CIC_PRECISION_F32_MFMA = 1, CIC_PRECISION_BF16 = 2 };
 /* Row partials of the vocabulary: the columns of a row are dealt to `nparts` parts; a part reduces its columns
@@ -147,6 +151,9 @@ typedef struct cic_logit_epilogue {
 } cic_logit_epilogue;
 enum { CIC_PART_PLANES = 6, CIC_PART_MAX_ENTRIES = 16384 };   /* rows * nparts never exceeds 16384 per row block */
 int cic_gemm_f32(const cic_gemm_args* a, cic_stream_t s);
+/* x[i] = p0 + p1 + p2 with p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1) (round to nearest even; the residuals
+ * are exact): parts[0..n), [n..2n), [2n..3n) - the split every bf16-part kernel applies to its operands on the fly. */
+int cic_split_bf16x3(const float* x, int64_t n, uint16_t* parts, cic_stream_t s);
 /* number of parts per row the fused epilogue of cic_gemm_f32 writes for these arguments; 0: not fused for them */
 int cic_gemm_logit_parts(const cic_gemm_args* a);
 /* the same partials from logits already in memory (any shape): rows of `logits` [M, ld], nparts parts of contiguous

@@ -138,8 +138,11 @@ def test_paired_decodes_equal_sequential_decodes(B, dims):
     engine.speaker_decode_fwd_pair(d, params, a1, b1)
     torch.cuda.synchronize()
     assert 0 < int(a0['L']) <= T and 0 < int(b0['L']) <= T
-    # the workspace ends with the row partials of the last step and the [T,B] log-sum-exp rows (engine_util.h: SpkWs)
-    tail = 6 * 16384 * 4 + (T * B * 4 + 255) // 256 * 256
+    # the workspace ends with the row partials of the last step, the [T,B] log-sum-exp rows and the pre-split logit weights
+    # (engine_util.h: SpkWs; a pair keeps those in decode a's workspace only)
+    lse_b = (T * B * 4 + 255) // 256 * 256
+    parts_b = (3 * (d.V + 1) * d.H * 2 + 255) // 256 * 256
+    tail = 6 * 16384 * 4 + lse_b + parts_b
     for x, y in ((a0, a1), (b0, b1)):
         for k in ('seq', 'L'):
             assert torch.equal(x[k], y[k]), k
@@ -147,8 +150,8 @@ def test_paired_decodes_equal_sequential_decodes(B, dims):
             if x[k] is not None:
                 np.testing.assert_allclose(x[k].cpu().numpy(), y[k].cpu().numpy(), rtol=0, atol=2e-6, err_msg=k)
         assert torch.equal(x['ws'][:-tail], y['ws'][:-tail]), 'saved activations'
-        lse_x = x['ws'][-(tail - 6 * 16384 * 4):][:T * B * 4].view(torch.float32)
-        lse_y = y['ws'][-(tail - 6 * 16384 * 4):][:T * B * 4].view(torch.float32)
+        lse_x = x['ws'][-(lse_b + parts_b):][:T * B * 4].view(torch.float32)
+        lse_y = y['ws'][-(lse_b + parts_b):][:T * B * 4].view(torch.float32)
         np.testing.assert_allclose(lse_x.cpu().numpy(), lse_y.cpu().numpy(), rtol=0, atol=4e-6)
 
 

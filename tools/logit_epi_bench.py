@@ -68,6 +68,16 @@ def main():
     run('epilogue: gumbel-ST (U in memory) / greedy', epi(3, 1, False))
     run('epilogue: gumbel-ST (Philox) / greedy', epi(3, 1, True))
     run('epilogue: multinomial (Philox) / greedy', epi(2, 1, True))
+    # the weights already cut into their three bf16 parts (cic_split_bf16x3, once per training step)
+    from cooperativeimagecaptioning_amd import ops
+    ref_a = la.clone()
+    parts = torch.empty(3 * W.numel(), dtype=torch.int16, device=dev)
+    ops.split_bf16x3_(W, parts)
+    g.B_parts = parts.data_ptr()
+    run('pre-split W: no epilogue', None)
+    run('pre-split W: gumbel-ST (Philox) / greedy', epi(3, 1, True))
+    torch.cuda.synchronize()
+    print('pre-split logits equal the on-the-fly ones bit for bit:', bool(torch.equal(ref_a, la)))
 
 
 if __name__ == '__main__':
