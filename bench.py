@@ -165,6 +165,22 @@ def _rccl_version():
         return f'unknown ({type(e).__name__})'
 
 
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` started directly: run the N ranks under torch.distributed.run as a CHILD process (the parent has
+    not touched the GPU and never does), pass its stdout through (rank 0 prints the one JSON line) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -183,6 +199,10 @@ def main():
     if os.environ.get('CIC_HANG_DUMP'):          # diagnostics: Python stacks of every thread after N seconds, then exit
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ['CIC_HANG_DUMP']), exit=True)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process makes NO GPU call; it starts the N ranks as a child
+        # (`python -m torch.distributed.run ... bench.py <same flags>`), relays rank 0's JSON line and the exit code
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

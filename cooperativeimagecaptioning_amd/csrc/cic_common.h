@@ -26,6 +26,19 @@ void cic_set_error(const char* fmt, ...);
 
 #define CIC_LAUNCH_CHECK() CIC_HIP(hipGetLastError())
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) holds PER DEVICE: a process that drives several GPUs has to set it on
+// each of them.  first() is true once per device (a bit per device ordinal, set atomically; idempotent work behind it).
+#include <atomic>
+struct DeviceOnce {
+    std::atomic<uint64_t> done{0};
+    bool first() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return true;
+        const uint64_t bit = 1ull << (dev & 63);
+        return (done.fetch_or(bit, std::memory_order_relaxed) & bit) == 0;
+    }
+};
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -226,9 +239,9 @@ __device__ __forceinline__ void rowpart_add_m(RowPart& p, float inv_t, float x, 
     osm_add(p.m1, p.s1, x);
     if (MODE == CIC_SAMPLE_NONE) return;
     if (MODE == CIC_SAMPLE_MULTINOMIAL_ST) {
-        // s2 = sum exp((x - m1) * inv_t), re-based whenever the running maximum moves
-        const float r1 = p.m1 * inv_t;
-        p.s2 = p.s2 * __expf(m_old * inv_t - r1) + __expf(x * inv_t - r1);
+        // s2 = sum exp((x - m1) * inv_t), re-based whenever the running maximum moves.  The DIFFERENCE is scaled, never
+        // the operands: an empty side (m = -FLT_MAX) times inv_t > 1 would overflow to -inf and (-inf) - (-inf) = NaN
+        p.s2 = p.s2 * __expf((m_old - p.m1) * inv_t) + __expf((x - p.m1) * inv_t);
     }
     const bool gum = MODE == CIC_SAMPLE_GUMBEL_ST;
     const float k = MODE == CIC_SAMPLE_GREEDY ? x : (gum ? (x + g) * inv_t : x * inv_t + g);
@@ -250,8 +263,8 @@ __device__ __forceinline__ void rowpart_add(RowPart& p, int mode, float inv_t, f
 }
 __device__ __forceinline__ void rowpart_merge(RowPart& p, int mode, float inv_t, const RowPart& q) {
     if (mode == CIC_SAMPLE_MULTINOMIAL_ST) {
-        const float r = fmaxf(p.m1, q.m1) * inv_t;
-        p.s2 = p.s2 * __expf(p.m1 * inv_t - r) + q.s2 * __expf(q.m1 * inv_t - r);
+        const float M = fmaxf(p.m1, q.m1);      // (m - M) is 0 or about -FLT_MAX for an empty side: finite, exp -> 1 or 0
+        p.s2 = p.s2 * __expf((p.m1 - M) * inv_t) + q.s2 * __expf((q.m1 - M) * inv_t);
     }
     if (mode == CIC_SAMPLE_GUMBEL_ST) {
         float kb = p.kbest, s = p.s2;

@@ -626,11 +626,10 @@ int launch_skinny(const cic_gemm_args& g, bool vec, hipStream_t st) {
         using TB = Tile<32, KB, V, WM * 64>;                                                                  \
         constexpr int GF = (TA::LDS_FLOATS + TB::LDS_FLOATS) * KS, RF = KS * WM * 16 * 64;                    \
         constexpr size_t shm = sizeof(float) * (GF > RF ? GF : RF);                                           \
-        static bool attr_set = false;                                                                         \
-        if (!attr_set) {                                                                                      \
+        static DeviceOnce attr_set;                                                                         \
+        if (attr_set.first()) {                                                                                      \
             CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<WM, KS, KA, KB, V>), \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));               \
-            attr_set = true;                                                                                  \
         }                                                                                                     \
         hipLaunchKernelGGL((gemm_skinny_kernel<WM, KS, KA, KB, V>), dim3(grid), blk, shm, st, g);             \
     } while (0)
@@ -2053,11 +2052,10 @@ bool ldsb_walk_ok(const cic_gemm_args& g) {
 int launch_ldsb_walk(const cic_gemm_args& g, hipStream_t st) {
     constexpr int NG = 32;
     constexpr size_t lds_bytes = 2 * 16 * (16 * NG + 4) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (attr_set.first()) {
         CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb_walk_kernel<NG>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_set = true;
     }
     const int Mtot = g.M;
     // row groups of 64; with row blocks each block is rounded up on its own (groups never straddle the blocks)
@@ -2072,8 +2070,8 @@ int launch_ldsb_walk(const cic_gemm_args& g, hipStream_t st) {
     if (g_ldsb2 == 2 || g_ldsb2 == 4) {
         // staged tiles + the K-half hand-off + the noise hand-off of the fused epilogue
         const size_t lds2_bytes = lds_bytes + 2 * 4 * (g_ldsb2 - 1) * 4 * 64 * sizeof(float) + 2 * 4 * 4 * 64 * sizeof(float);
-        static bool attr2_set = false;
-        if (!attr2_set) {
+        static DeviceOnce attr2_set;
+        if (attr2_set.first()) {
             CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2_walk_kernel<NG, 2, 0>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bytes + 2 * 4 * 1 * 4 * 64 * 4 + 8192)));
             CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2_walk_kernel<NG, 4, 0>),
@@ -2082,15 +2080,14 @@ int launch_ldsb_walk(const cic_gemm_args& g, hipStream_t st) {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bytes + 2 * 4 * 1 * 4 * 64 * 4 + 8192)));
             CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2_walk_kernel<NG, 4, 1>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bytes + 2 * 4 * 3 * 4 * 64 * 4 + 8192)));
-            attr2_set = true;
         }
         cic_logit_epilogue epi = {};
         if (g.epi) epi = *g.epi;
         if (g_ldsb2 == 2 && g_bfx && g.precision != CIC_PRECISION_F32_MFMA) {
             // bf16-part form (f32 results): two tiles of three bf16 images + the two hand-off buffers
             constexpr size_t bf_bytes = 2 * 3 * 16 * (16 * NG + 8) * 2 + 2 * 4 * 1 * 4 * 64 * sizeof(float) + 2 * 4 * 4 * 64 * sizeof(float);
-            static bool attr3_set = false;
-            if (!attr3_set) {
+            static DeviceOnce attr3_set;
+            if (attr3_set.first()) {
                 CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2bf_walk_kernel<NG, 0, 0>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf_bytes));
                 CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2bf_walk_kernel<NG, 1, 0>),
@@ -2099,7 +2096,6 @@ int launch_ldsb_walk(const cic_gemm_args& g, hipStream_t st) {
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf_bytes));
                 CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2bf_walk_kernel<NG, 1, 1>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf_bytes));
-                attr3_set = true;
             }
             const __bf16* wparts = reinterpret_cast<const __bf16*>(g.B_parts);
             if (wparts && g.epi)
@@ -2209,13 +2205,12 @@ int launch_rega(const cic_gemm_args& g, hipStream_t st) {
             const int ch = (per % 3 == 0 && per % 2 != 0) ? 3 : 2;
             const int gps2 = cic_cdiv(per, ch) * ch;
             constexpr size_t lds_bytes = 16 * 32 * 64 * sizeof(float);
-            static bool attr_set = false;
-            if (!attr_set) {
+            static DeviceOnce attr_set;
+            if (attr_set.first()) {
                 CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rega2_kernel<16, 2>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
                 CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rega2_kernel<16, 3>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-                attr_set = true;
             }
             if (ch == 3) hipLaunchKernelGGL((gemm_rega2_kernel<16, 3>), dim3(grid2, ky2), dim3(1024), lds_bytes, st, g, gps2);
             else hipLaunchKernelGGL((gemm_rega2_kernel<16, 2>), dim3(grid2, ky2), dim3(1024), lds_bytes, st, g, gps2);

@@ -55,10 +55,16 @@ __global__ __launch_bounds__(SNW * 64) __attribute__((amdgpu_waves_per_eu(RV <= 
                                                           const float* __restrict__ lse_all,
                                                           // U == NULL: the uniforms are drawn here, element i of the
                                                           // [T+1,B,V1] slab = element u_elem0 + i of the Philox stream
-                                                          int u_philox, uint64_t u_seed, uint64_t u_elem0) {
+                                                          int u_philox, uint64_t u_seed, uint64_t u_elem0,
+                                                          // != 0: the forward masked column seq[b, t-1] of row (t >= 1, b)
+                                                          // to -inf before the log-softmax (AttModel.py:438-442)
+                                                          int decoding_constraint) {
     constexpr int NT = SNW * 64;
     __shared__ float sh[SNW];
     const int row = blockIdx.x, t = row / B, b = row % B, tid = threadIdx.x;
+    // the constrained column carries log p = -inf: y = 0, p = 0, no gradient (lse_all was taken without it; a row kernel
+    // that stored log-probs wrote -inf there itself)
+    const int cons = (decoding_constraint && seq && t >= 1) ? seq[(size_t)b * T + (t - 1)] : -1;
     const float lse = lse_all ? lse_all[row] : 0.f;
     const int L = Lp ? *Lp : T;
     const float* lp = logp_all + (size_t)row * V1;
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(SNW * 64) __attribute__((amdgpu_waves_per_eu(RV <= 
         for (int r = 0; r < RV; ++r)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const bool ok = (tid + NT * r) < nq;
+                const bool ok = (tid + NT * r) < nq && 4 * (tid + NT * r) + e != cons;
                 x[r][e] = ok ? xv[r][e] - lse : -INFINITY;
                 gg[r][e] = (ok && unf) ? gv[r][e] : 0.f;
                 float z = -INFINITY;
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(SNW * 64) __attribute__((amdgpu_waves_per_eu(RV <= 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int c = 4 * (tid + NT * r) + e;
-                const bool ok = (tid + NT * r) < nq && c < V1;
+                const bool ok = (tid + NT * r) < nq && c < V1 && c != cons;
                 x[r][e] = ok ? lp[c] - lse : -INFINITY;
                 gg[r][e] = (ok && unf) ? g[c] : 0.f;
                 float z = -INFINITY;
@@ -715,7 +721,7 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         const int64_t* tgt = io->mode == CIC_SAMPLE_TEACHER ? io->pick : nullptr;
 #define GO(RV) hipLaunchKernelGGL((sampler_bwd_kernel<RV>), grid, blk, 0, st, w.logp_all, io->U, bio->d_onehot, w.it_all, \
                                   tgt, io->seq, bio->dslp, io->L, io->mode, io->temp, g.dlogits, T, B, V1, w.lse_all,        \
-                                  io->u_philox, io->u_seed, io->u_offset * 4ull)
+                                  io->u_philox, io->u_seed, io->u_offset * 4ull, io->decoding_constraint)
         if (V1 <= 4096) GO(1); else if (V1 <= 12288) GO(3); else if (V1 <= 32768) GO(8);
         else { cic_set_error("vocabulary too large"); return 1; }
 #undef GO

@@ -76,8 +76,20 @@ class DataLoader:
 
     N_BUFFERS = 3        # batch i is consumed by the step, i+1 is uploading, i+2 is being filled
 
-    def __init__(self, opt, workers=None, window=None):
+    def __init__(self, opt, workers=None, window=None, rank=None, world=None):
         self.opt = opt
+        # data-parallel runs (rank r takes its own images of every global batch): the TRAIN split is dealt
+        # round robin over the ranks - rank r reads positions r, r + world, ... of the epoch's order, which is the same
+        # list on every rank (the shuffle at an epoch wrap is seeded by (loader_seed, epoch), not by process state).  The
+        # order is padded to a multiple of `world` with its own head, so every rank wraps in the same iteration.
+        # val / test stay whole: evaluation runs on one rank, as in the reference.
+        self.rank = int(os.environ.get('RANK', '0')) if rank is None else int(rank)
+        self.world = int(os.environ.get('WORLD_SIZE', '1')) if world is None else int(world)
+        assert 0 <= self.rank < self.world, (self.rank, self.world)
+        self.loader_seed = int(getattr(opt, 'loader_seed', getattr(opt, 'seed', 0)) or 0)
+        self.sharded_splits = ('train',) if self.world > 1 else ()
+        self.epochs = {'train': 0, 'val': 0, 'test': 0}
+        self._shard_cache = {}
         self.batch_size = opt.batch_size
         self.seq_per_img = opt.seq_per_img
         self.dataset = getattr(opt, 'dataset', 'coco')
@@ -123,7 +135,7 @@ class DataLoader:
         self._queue = {s: [] for s in self.split_ix}      # [(ix, wrapped, future)] read ahead, in hand-out order
         self._cursor = dict(self.iterators)               # position of the read-ahead (>= iterators)
         self._buffers = {}
-        self._turn = 0
+        self._turn = {s: 0 for s in self.split_ix}        # per split: a val batch never lands in a train batch's buffers
 
     # ---- reference accessors (:58-70)
     def get_vocab_size(self):
@@ -143,12 +155,48 @@ class DataLoader:
         self.iterators[split] = 0
         self._cursor[split] = 0
 
+    # ---- the rank's view of a split
+    def _order(self, split):
+        """Positions this rank reads, in hand-out order: the split's order itself, or every world-th entry of it."""
+        order = self.split_ix[split]
+        if split not in self.sharded_splits:
+            return order
+        cached = self._shard_cache.get(split)
+        if cached is not None and cached[0] is order:
+            return cached[1]
+        pad = (-len(order)) % self.world
+        mine = (list(order) + list(order[:pad]))[self.rank::self.world]
+        self._shard_cache[split] = (order, mine)
+        return mine
+
+    def _shuffle(self, split):
+        """dataloader.py:352-353: the train split is reshuffled when an epoch wraps.  One process: the module-level
+        `random`, as the reference.  Data-parallel: a generator seeded by (loader_seed, epoch) - every rank draws the
+        same permutation without talking to the others.  The list is REPLACED, never shuffled in place: snapshots taken
+        for a resume keep pointing at the order their batch was drawn from."""
+        order = list(self.split_ix[split])
+        self.epochs[split] += 1
+        if self.world > 1:
+            random.Random(self.loader_seed * 1000003 + self.epochs[split]).shuffle(order)
+        else:
+            random.shuffle(order)
+        self.split_ix[split] = order
+
     # ---- resume (the reference keeps iterators / split_ix in infos, train.py:312-313,363-364)
-    def state_dict(self, rewind=0):
-        """rewind: batches of the train split already handed out that the caller has not consumed (a prefetcher's)."""
-        it = dict(self.iterators)
-        it['train'] = max(0, it['train'] - int(rewind) * self.batch_size)
-        return dict(iterators=it, split_ix={k: list(v) for k, v in self.split_ix.items()})
+    def _snapshot(self):
+        """The stream's position NOW (cheap: the orders are shared, not copied - _shuffle replaces them)."""
+        return dict(iterators=dict(self.iterators), split_ix=dict(self.split_ix), epochs=dict(self.epochs))
+
+    def state_dict(self, rewind=0, snapshot=None):
+        """snapshot: the handle['state'] of the oldest batch handed out by begin_batch() that the trainer has not consumed
+        (a prefetcher's): resuming from it replays that batch, across an epoch wrap too.  rewind (batches, kept for
+        loaders driven without handles) steps the train iterator back inside the current epoch."""
+        snap = snapshot if snapshot is not None else self._snapshot()
+        it = dict(snap['iterators'])
+        if snapshot is None and rewind:
+            it['train'] = max(0, it['train'] - int(rewind) * self.batch_size)
+        return dict(iterators=it, split_ix={k: list(v) for k, v in snap['split_ix'].items()}, epochs=dict(snap['epochs']),
+                    rank=self.rank, world=self.world)
 
     def load_state_dict(self, st):
         for s in self.split_ix:
@@ -156,9 +204,16 @@ class DataLoader:
                 if fut is not None:
                     fut.cancel()
             self._queue[s] = []
-        self.iterators.update(st.get('iterators', {}))
         if st.get('split_ix'):
             self.split_ix = {k: list(v) for k, v in st['split_ix'].items()}
+        self.epochs.update({k: int(v) for k, v in (st.get('epochs') or {}).items()})
+        its = dict(st.get('iterators', {}))
+        if int(st.get('world', self.world)) != self.world:
+            # iterators count positions of a rank's own view: under another world size the epoch restarts
+            print(f"loader state was saved with world={st.get('world')}, resuming with world={self.world}: "
+                  f"the train iterator restarts at the beginning of the saved epoch's order")
+            its['train'] = 0
+        self.iterators.update(its)
         self._cursor = dict(self.iterators)
 
     # ---- one image (:250-294)
@@ -198,9 +253,10 @@ class DataLoader:
 
     # ---- read-ahead in hand-out order (BlobFetcher._get_next_minibatch_inds, :343-358)
     def _advance(self, split):
-        max_index = len(self.split_ix[split])
+        order = self._order(split)
+        max_index = len(order)
         ri = self._cursor[split]
-        ix = self.split_ix[split][ri]
+        ix = order[ri]
         ri_next, wrapped = ri + 1, False
         if ri_next >= max_index:
             ri_next, wrapped = 0, True
@@ -220,14 +276,14 @@ class DataLoader:
         self._fill(split, 1)
         ix, wrapped, fut = self._queue[split].pop(0)
         if wrapped and split == 'train':
-            random.shuffle(self.split_ix[split])            # :352-353: shuffled when the epoch wraps
+            self._shuffle(split)                            # :352-353: shuffled when the epoch wraps
         self.iterators[split] = 0 if wrapped else self.iterators[split] + 1
         fc, att, ix2 = fut.result() if fut is not None else self.__getitem__(ix)
         assert ix2 == ix, 'ix not equal'
         return fc, att, ix, wrapped
 
-    def _buffer(self, name, shape, dtype):
-        key = (name, self._turn % self.N_BUFFERS)
+    def _buffer(self, name, split, shape, dtype):
+        key = (name, split, self._turn[split] % self.N_BUFFERS)
         b = self._buffers.get(key)
         if b is None or b.shape != tuple(shape):
             b = self._buffers[key] = pinned_empty(shape, dtype, pin=getattr(self.opt, 'pin_memory', 1))
@@ -247,7 +303,9 @@ class DataLoader:
     def begin_batch(self, split, batch_size=None):
         batch_size = batch_size or self.batch_size
         spi = self.seq_per_img
-        self._fill(split, min(self._window + batch_size, len(self.split_ix[split])))
+        state = self._snapshot()                            # where a resume must start to hand out THIS batch again
+        n_mine = len(self._order(split))
+        self._fill(split, min(self._window + batch_size, n_mine))
         fcs, atts, label_batch, gts, infos = [], [], [], [], []
         wrapped = False
         for _ in range(batch_size):
@@ -264,13 +322,13 @@ class DataLoader:
             label_batch.append(lab)
             img = self.info['images'][ix]
             infos.append({'ix': ix, 'id': img['id'], 'file_path': img.get('file_path', '')})
-        self._fill(split, min(self._window, len(self.split_ix[split])))       # keep the readers busy under the step
-        self._turn += 1
+        self._fill(split, min(self._window, n_mine))       # keep the readers busy under the step
+        self._turn[split] += 1
         data = {}
-        fcb = self._buffer('fc', (batch_size * spi,) + tuple(fcs[0].shape), torch.float32)
+        fcb = self._buffer('fc', split, (batch_size * spi,) + tuple(fcs[0].shape), torch.float32)
         data['fc_feats'] = fcb
         max_att_len = max(a.shape[0] for a in atts)
-        attb = self._buffer('att', (batch_size * spi, max_att_len, atts[0].shape[1]), torch.float32)
+        attb = self._buffer('att', split, (batch_size * spi, max_att_len, atts[0].shape[1]), torch.float32)
         masks_att = np.zeros(attb.shape[:2], dtype='float32')
         for i, a in enumerate(atts):
             masks_att[i * spi:(i + 1) * spi, :a.shape[0]] = 1
@@ -285,20 +343,20 @@ class DataLoader:
         # packed store come out of the page cache here; per-image files were read ahead and are only copied)
         data['att_feats'] = attb
         data['att_masks'] = None if masks_att.sum() == masks_att.size else masks_att      # :228-229
-        labels = self._buffer('labels', (batch_size * spi, self.seq_length + 2), torch.int64)
+        labels = self._buffer('labels', split, (batch_size * spi, self.seq_length + 2), torch.int64)
         labels[:] = np.vstack(label_batch)
         data['labels'] = labels
         nonzeros = (labels != 0).sum(1) + 2
-        mask_batch = self._buffer('masks', (batch_size * spi, self.seq_length + 2), torch.float32)
+        mask_batch = self._buffer('masks', split, (batch_size * spi, self.seq_length + 2), torch.float32)
         mask_batch[:] = (np.arange(self.seq_length + 2)[None, :] < nonzeros[:, None]).astype('float32')
         data['masks'] = mask_batch
         data['gts'] = gts
-        data['bounds'] = {'it_pos_now': self.iterators[split], 'it_max': len(self.split_ix[split]), 'wrapped': wrapped}
+        data['bounds'] = {'it_pos_now': self.iterators[split], 'it_max': n_mine, 'wrapped': wrapped}
         data['infos'] = infos
         # submitted last: the bookkeeping above does not then share the interpreter with the copy threads
         n, w = len(atts), self._workers
         copies = [self._pool.submit(lambda c=c: [place(i) for i in range(c, n, w)]) for c in range(min(w, n))]
-        return {'data': data, 'copies': copies}
+        return {'data': data, 'copies': copies, 'state': state}
 
     def close(self):
         self._pool.shutdown(wait=False, cancel_futures=True)

@@ -36,6 +36,10 @@ class FlatAdam:
         self.grad_scale = 1.0         # extra factor on the gradient (1/n after accumulating n micro-batches)
         self._pending = {}            # bucket name -> async all-reduce handle of THIS step
         self._done = set()            # buckets already summed over the ranks in this step
+        # gradient accumulation under data parallelism: while True, the early starts from inside backward() are skipped
+        # (the gradient of a bucket is final only after the LAST micro-batch's backward); step() exchanges whatever has
+        # not left.  See accumulate_gradients().
+        self.defer_exchange = False
 
     @property
     def flat(self):
@@ -64,9 +68,14 @@ class FlatAdam:
         """utils.clip_gradient() on a FlatAdam defers the clamp into the fused step kernel."""
         self._grad_clip = float(grad_clip)
 
-    @staticmethod
-    def _distributed():
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    # run the bucketed exchange even in a process group of ONE rank (the sum over one rank is the identity): lets a single
+    # GPU exercise the RCCL branch - communicator stream, three asynchronous handles in flight, wait ordering -
+    # tests/test_gpu_rccl_world1.py.  Also settable from the environment (CIC_FORCE_GRAD_EXCHANGE=1).
+    force_exchange = os.environ.get('CIC_FORCE_GRAD_EXCHANGE', '0') == '1'
+
+    @classmethod
+    def _distributed(cls):
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or cls.force_exchange)
 
     def begin_all_reduce(self, bucket=None):
         """Start the all-reduce of one bucket (default: every bucket not started yet) as soon as its gradient is final,
@@ -231,9 +240,21 @@ def save_optimizer(opt, optimizer_dict):
         _save(optimizer_dict['optimizer'], 'optimizer.pth')
 
 
+def accumulate_gradients(optimizer_dict, more_to_come):
+    """Gradient accumulation under data parallelism: call with more_to_come=True before the backward of every micro-batch
+    but the last, and with False before the last one.  While True the exchanges that overlap_gradient_exchange() starts
+    from inside backward() stay off (they would sum a gradient that is not final, and a second start raises); the last
+    backward starts them as usual and step() exchanges the rest.  Scale with FlatAdam.grad_scale = 1/n."""
+    for v in optimizer_dict.values():
+        for o in (v.values() if isinstance(v, dict) else [v]):
+            if isinstance(o, FlatAdam):
+                o.defer_exchange = bool(more_to_come)
+
+
 def overlap_gradient_exchange(model, optimizer_dict):
     """Data-parallel runs: let the joint model start the listener's all-reduce from inside backward() (right after
-    the listener's backward engines, before the speaker's), instead of after the whole backward pass."""
+    the listener's backward engines, before the speaker's), instead of after the whole backward pass.  With more than one
+    backward per step (gradient accumulation) bracket the micro-batches with accumulate_gradients()."""
     lst = spk = None
     for v in optimizer_dict.values():
         for o in (v.values() if isinstance(v, dict) else [v]):
@@ -243,10 +264,10 @@ def overlap_gradient_exchange(model, optimizer_dict):
                 spk = o
     if lst is not None:
         lst._started_early = True
-    model.listener_grads_ready = lst.begin_all_reduce if lst is not None else None
+    model.listener_grads_ready = (lambda: None if lst.defer_exchange else lst.begin_all_reduce()) if lst is not None else None
     # the speaker's logit bucket (final before the BPTT loop of its backward engine) leaves from inside backward() too
     if spk is not None and 'logit' in spk.buckets():
-        model.speaker_logit_grads_ready = lambda: spk.begin_all_reduce('logit')
+        model.speaker_logit_grads_ready = lambda: None if spk.defer_exchange else spk.begin_all_reduce('logit')
     else:
         model.speaker_logit_grads_ready = None
 

@@ -44,6 +44,18 @@ class PrefetchLoader:
         """Batches pulled from the wrapped loader but not handed to the trainer yet (a resume replays them)."""
         return (0 if self._next is None else 1) + (0 if self._assembling is None else 1)
 
+    def state_dict(self):
+        """The wrapped loader's position such that a resume hands out the oldest batch the trainer has NOT consumed yet
+        (pulled ahead by this class): the snapshot that batch's begin_batch() took, across an epoch wrap too."""
+        inner = self.loader
+        if not hasattr(inner, 'state_dict'):
+            return None
+        if self._next is not None and self._next[0].get('_loader_state') is not None:
+            return inner.state_dict(snapshot=self._next[0]['_loader_state'])
+        if self._next is None and self._assembling is not None and self._assembling.get('state') is not None:
+            return inner.state_dict(snapshot=self._assembling['state'])
+        return inner.state_dict(rewind=self.ahead()) if self.ahead() else inner.state_dict()
+
     def _pinned(self, key, t):
         if not t.is_pinned():
             self.pageable_bytes += t.numel() * t.element_size()
@@ -56,6 +68,7 @@ class PrefetchLoader:
         if self._two_phase:
             handle = self._assembling if self._assembling is not None else self.loader.begin_batch(self.split)
             data = self.loader.end_batch(handle)                   # copied while the previous step was computing
+            data['_loader_state'] = handle.get('state')
             # the loader rotates three sets of pinned buffers: the set the next assembly writes was the source of the
             # upload issued two calls ago - that DMA has long finished, but nothing may overwrite it before it has
             if len(self._uploads) >= 2:

@@ -102,13 +102,11 @@ def checkpoint(opt, model, optimizer_dict, iteration, epoch, loss_history, loade
 
 def _loader_state(loader):
     """Position of the batch source, as the reference keeps loader.iterators / split_ix in infos (train.py:312-313)."""
-    inner = getattr(loader, 'loader', loader)             # PrefetchLoader wraps the real one
-    if inner is None:
+    if loader is None:
         return None
-    if hasattr(inner, 'state_dict'):
-        # batches the prefetcher pulled ahead of the step are replayed after a resume
-        return inner.state_dict(rewind=int(loader.ahead()) if hasattr(loader, 'ahead') else 0)
-    return None
+    # PrefetchLoader: the batches it pulled ahead of the step are replayed after a resume (its state_dict() hands back the
+    # snapshot of the oldest one)
+    return loader.state_dict() if hasattr(loader, 'state_dict') else None
 
 
 def load_infos(opt):

@@ -117,3 +117,79 @@ def test_packed_store_hands_out_the_same_batches(tmp_path):
         assert [i['ix'] for i in da['infos']] == [i['ix'] for i in db['infos']]
     a.close()
     b.close()
+
+
+def test_rank_sharded_train_split_is_disjoint_and_covers_every_epoch(tmp_path):
+    """Data-parallel runs: rank r of `world` reads its own images of every global batch.  Over an epoch the
+    ranks' images are disjoint and together cover the train split (padded with the order's head to a multiple of world, so
+    that all ranks wrap in the same iteration); the shuffle at the wrap is the same permutation on every rank and differs
+    from epoch to epoch; val stays whole on every rank."""
+    from cooperativeimagecaptioning_amd.dataloader import DataLoader
+    opt, images, *_ = _dataset(str(tmp_path), n=26, val_from=23)          # 23 train images, 3 val
+    opt.batch_size, opt.seq_per_img = 3, 1
+    world = 2
+    random.seed(1)
+    dls = [DataLoader(opt, workers=1, rank=r, world=world) for r in range(world)]
+    train = [ix for ix, im in enumerate(images) if im['split'] == 'train']
+    per_rank = (len(train) + world - 1) // world                            # 12: the order is padded by one image
+    orders = []
+    for epoch in range(3):
+        seen = [[] for _ in range(world)]
+        wrapped = [False] * world
+        while not all(wrapped):
+            for r, dl in enumerate(dls):
+                random.seed(100 + r)                                        # process-local state must not matter
+                d = dl.get_batch('train')
+                assert d['bounds']['it_max'] == per_rank
+                seen[r] += [inf['ix'] for inf in d['infos']]
+                wrapped[r] = wrapped[r] or d['bounds']['wrapped']
+            assert len(set(wrapped)) == 1, 'the ranks must wrap in the same iteration'
+        # the batch that wraps continues into the next epoch: cut at the epoch's length
+        epoch_seen = [s[:per_rank] for s in seen]
+        carried = [s[per_rank:] for s in seen]
+        both = epoch_seen[0] + epoch_seen[1]
+        assert len(set(epoch_seen[0]) & set(epoch_seen[1])) <= (-len(train)) % world, 'disjoint shards (but for the padding)'
+        assert set(both) == set(train), f'epoch {epoch}: the shards together cover the split'
+        assert len(both) - len(set(both)) == (-len(train)) % world, 'only the padding repeats'
+        orders.append(tuple(x for pair in zip(*epoch_seen) for x in pair))
+        for dl, c in zip(dls, carried):                                      # put the carried images back: restart the epoch view
+            dl.load_state_dict(dict(dl.state_dict(), iterators=dict(dl.iterators, train=0)))
+        assert dls[0].split_ix['train'] == dls[1].split_ix['train'], 'every rank holds the same epoch order'
+    assert orders[0][:len(train)] == tuple(train), 'first epoch in split order (dealt round robin)'
+    assert orders[1] != orders[0] and orders[2] != orders[1], 'reshuffled at every wrap'
+    va = [[inf['ix'] for inf in dl.get_batch('val', batch_size=3)['infos']] for dl in dls]
+    assert va[0] == va[1] and len(va[0]) == 3                               # evaluation splits are not sharded
+    for dl in dls:
+        dl.close()
+
+
+def test_snapshot_resume_replays_the_prefetched_batch_across_an_epoch_wrap(tmp_path):
+    """ADVICE (round 2): the state saved while a prefetcher holds batches ahead of the trainer is the snapshot taken when
+    the OLDEST unconsumed batch was drawn - not arithmetic on the current position, which loses the tail of an epoch
+    once the read-ahead has crossed the wrap (iterator reset + reshuffle)."""
+    from cooperativeimagecaptioning_amd.dataloader import DataLoader
+    opt, *_ = _dataset(str(tmp_path))                                       # 9 training images, batches of 4
+    random.seed(7)
+    a = DataLoader(opt, workers=1)
+    a.get_batch('train')
+    h2 = a.begin_batch('train')                                             # images 4..7
+    h3 = a.begin_batch('train')                                             # image 8 + wrap + 3 of the reshuffled epoch
+    want2 = [inf['ix'] for inf in a.end_batch(h2)['infos']]
+    want3 = [inf['ix'] for inf in a.end_batch(h3)['infos']]
+    assert h3['data']['bounds']['wrapped']
+    for handle, want in ((h2, want2), (h3, want3)):
+        st = json.loads(json.dumps(a.state_dict(snapshot=handle['state'])))
+        b = DataLoader(opt, workers=1)
+        b.load_state_dict(st)
+        got = [inf['ix'] for inf in b.get_batch('train')['infos']]
+        if handle is h2:
+            assert got == want
+        else:
+            assert got[0] == want[0], 'the tail of the old epoch is replayed, not dropped'
+        b.close()
+    # a val batch assembled while a train batch is held does not touch the train batch's pinned buffers
+    held = a.begin_batch('train')
+    before = a.end_batch(held)['att_feats'].copy()
+    a.get_batch('val', batch_size=2)
+    np.testing.assert_array_equal(held['data']['att_feats'], before)
+    a.close()

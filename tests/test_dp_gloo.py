@@ -51,6 +51,12 @@ def _worker(rank, world, port, out_dir):
             # the overlapped form bench.py / train.py use for the listener: started from inside backward(),
             # awaited by step()
             assert model.listener_grads_ready is not None and list(o.buckets()) == ['all']
+            # gradient accumulation: before every micro-batch but the last the early starts stay off
+            optim.accumulate_gradients(od, True)
+            model.listener_grads_ready()
+            model.listener_grads_ready()
+            assert not o._pending and not o._done
+            optim.accumulate_gradients(od, False)
             model.listener_grads_ready()
             assert set(o._pending) == {'all'}
         else:

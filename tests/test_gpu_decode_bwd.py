@@ -75,7 +75,7 @@ def _run(W, cfg, att_raw, noise, mode_name, seed, att_masks=None):
     am_d = att_masks.cuda().contiguous() if att_masks is not None else None
     f = engine.speaker_decode_fwd(dims, params, att_pre, mode, temp, am_d, nz('att_keep', torch.uint8),
                                   nz('x_keep', torch.uint8), nz('out_keep', torch.uint8), nz('gumbel_u'), nz('pick'),
-                                  0, want_stv=(oh is not None), ps_u=nz('ps_u') if ps else None,
+                                  int(cfg.get('decoding_constraint', 0)), want_stv=(oh is not None), ps_u=nz('ps_u') if ps else None,
                                   ps_prob=ps_prob if ps else 0.0)
     assert int(f['L']) == L
     if ps:   # the soft rows themselves (time-major here, [B,L,V+2] in the oracle)
@@ -157,3 +157,33 @@ def test_decode_bwd_partial_sampling_flagship_dims():
                  out_keep=(torch.rand(T + 1, B, H, generator=g) >= 0.5).float(),
                  gumbel_u=torch.rand(T + 1, B, V + 1, generator=g), ps_u=torch.rand(T + 1, B, generator=g))
     _run(W, cfg, att_raw, noise, 'gumbel_ps', 5)
+
+
+def test_decode_bwd_with_the_decoding_constraint():
+    """a gradient decode with --decoding_constraint 1 (AttModel.py:438-442: the previously emitted word's
+    column is -inf before the log-softmax).  The backward rebuilds log-probs from raw logits + lse, so it has to mask the
+    same column: p = 0 there, no gradient.  Plain multinomial decode (the REINFORCE path: the only one where the reference's
+    scatter_ of seq[-1] is defined), recorded weights and dropout masks, picks without immediate repeats."""
+    z = GU.load_case('sample_multinomial_plain')
+    cfg = dict(GU.cfg_dict(z), decoding_constraint=1)
+    W = {k: T_(v) for k, v in z['weights'].items()}
+    noise = {k: T_(v) for k, v in GU.noise_dict(z, 'noise').items()}
+    pick = noise['pick'].clone()
+    V = cfg['vocab_size']
+    for t in range(2, pick.shape[0]):
+        same = pick[t] == pick[t - 1]
+        pick[t][same] = (pick[t][same] % V) + 1          # another word, never <eos>
+    noise['pick'] = pick
+    _run(W, cfg, T_(z['att_raw']), noise, 'multinomial', 6)
+
+
+@pytest.mark.parametrize('temp', [0.5, 2.0])
+def test_decode_bwd_multinomial_st_with_a_temperature(temp):
+    """ST-multinomial at multinomial_temp != 1 (run_joint.sh passes --multinomial_temp) on a small
+    vocabulary, where the row partials come from the fallback kernel with fewer than 64 parts per row: empty partials
+    (-FLT_MAX) times 1/temp > 1 overflowed to -inf and (-inf) - (-inf) poisoned the straight-through value of every row."""
+    z = GU.load_case('sample_multinomial_st')
+    cfg = dict(GU.cfg_dict(z), multinomial_temp=temp)
+    W = {k: T_(v) for k, v in z['weights'].items()}
+    noise = {k: T_(v) for k, v in GU.noise_dict(z, 'noise').items()}
+    _run(W, cfg, T_(z['att_raw']), noise, 'multinomial_st', 7)

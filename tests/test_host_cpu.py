@@ -223,3 +223,31 @@ def test_misc_utils_helpers():
     sd['extra'] = torch.zeros(1)
     utils.load_state_dict(small, sd)                    # shape mismatch: the common leading part is copied
     assert torch.equal(small.weight.reshape(-1), big.weight.reshape(-1)[:6]) and torch.equal(small.bias, big.bias[:2])
+
+
+def test_bench_launches_its_own_ranks_when_started_without_a_launcher(monkeypatch):
+    """`python bench.py --gpus N` with WORLD_SIZE unset (the way the driver starts N = 1): the parent makes no GPU call and
+    runs `python -m torch.distributed.run --nproc-per-node N bench.py <same flags>` as a child, returning its exit code."""
+    import importlib.util
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_under_test', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    calls = []
+
+    def fake_call(cmd, env=None):
+        calls.append((cmd, env))
+        return 7
+    monkeypatch.setattr(subprocess, 'call', fake_call)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '8', '--steps', '5', '--warmup', '2'])
+    monkeypatch.setattr(torch.cuda, 'set_device', lambda *a, **k: (_ for _ in ()).throw(AssertionError('GPU call in the parent')))
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd, env = calls[0]
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and '--nproc-per-node=8' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and int(cmd[cmd.index('--master-port') + 1]) > 0
+    assert cmd[-6:] == ['--gpus', '8', '--steps', '5', '--warmup', '2'] and cmd[-7].endswith('bench.py')
+    assert env['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
