@@ -69,6 +69,11 @@ def build_parser():
                    help='distinct synthetic batches served round robin (0: draw a fresh batch on every call)')
     p.add_argument('--max_iterations', type=int, default=-1, help='stop after this many iterations (-1: never)')
     p.add_argument('--seed', type=int, default=0)
+    p.add_argument('--eval_at_checkpoint', type=int, default=1,
+                   help='1 (the reference): evaluate the val split at every checkpoint and keep model-best / model_vse-best; '
+                        '0: save only')
+    p.add_argument('--loader_seed', type=int, default=0, help='seed of the per-epoch shuffle shared by the ranks of a '
+                                                               'data-parallel run (dataloader.DataLoader)')
     p.add_argument('--prefetch', type=int, default=1, help='1: upload the next batch on a copy stream while the '
                                                             'current step computes (prefetch.PrefetchLoader)')
     return p

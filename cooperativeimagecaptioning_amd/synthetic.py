@@ -58,12 +58,54 @@ class SyntheticLoader:
     drawing 9.4 M normals per call costs 50-150 ms of host time, an order of magnitude more than the step);
     pool = 0 draws a fresh batch on every call."""
 
-    def __init__(self, opt, seed=1234, K=36, iters_per_epoch=100, pool=8, pin=True):
+    def __init__(self, opt, seed=1234, K=36, iters_per_epoch=100, pool=8, pin=True, val_batches=2):
         self.opt, self.seed, self.K, self.n, self.ipe = opt, seed, K, 0, iters_per_epoch
         self.vocab_size, self.seq_length = opt.vocab_size, opt.seq_length
         self.pool = int(pool)
         self.pin = bool(pin) and torch.cuda.is_available()      # pool batches live in page-locked memory: asynchronous uploads
         self._cache = {}
+        # what the evaluation drivers read from a loader (eval_utils.eval_split / encode_data): a small 'val' / 'test' split
+        # of `val_batches` batches of its own, one caption row per image
+        self.batch_size, self.seq_per_img, self.dataset = opt.batch_size, 1, 'coco'
+        self.val_batches = int(val_batches)
+        self._eval_pos = {'val': 0, 'test': 0}
+        self.ix_to_word = None
+
+    def get_vocab(self):
+        if self.ix_to_word is None:
+            self.ix_to_word = {str(i): f'w{i}' for i in range(1, self.vocab_size + 1)}
+        return self.ix_to_word
+
+    def reset_iterator(self, split):
+        if split in self._eval_pos:
+            self._eval_pos[split] = 0
+        else:
+            self.n = 0
+
+    def _eval_batch(self, split):
+        i = self._eval_pos[split]
+        key = (split, i)
+        if key not in self._cache:
+            self._cache[key] = self._make(1000003 * (1 + list(self._eval_pos).index(split)) + i)
+        b = dict(self._cache[key])
+        B = self.batch_size
+        if self.seq_per_img > 1:        # encode_data asks for 5 caption rows per image (eval_utils.py:300-304)
+            spi = self.seq_per_img
+            rep = lambda a: np.repeat(a, spi, axis=0)        # noqa: E731
+            lab = np.zeros((B * spi, self.seq_length + 2), np.int64)
+            msk = np.zeros((B * spi, self.seq_length + 2), np.float32)
+            for k in range(B):
+                for q in range(spi):
+                    cap = b['gts'][k][q % len(b['gts'][k])]
+                    lab[k * spi + q, 1:self.seq_length + 1] = cap
+                    msk[k * spi + q, :int((cap > 0).sum()) + 2] = 1
+            b.update(fc_feats=rep(b['fc_feats']), att_feats=rep(b['att_feats']), labels=lab, masks=msk)
+        self._eval_pos[split] = (i + 1) % self.val_batches
+        b['bounds'] = dict(it_pos_now=(i + 1) * B if i + 1 < self.val_batches else 0, it_max=self.val_batches * B,
+                           wrapped=(i + 1 == self.val_batches))
+        b['infos'] = [{'ix': i * B + k, 'id': 900000 * (1 + list(self._eval_pos).index(split)) + i * B + k, 'file_path': ''}
+                      for k in range(B)]
+        return b
 
     def state_dict(self, rewind=0):
         """Position of the stream (the reference keeps loader.iterators in infos, train.py:312); rewind: batches
@@ -80,6 +122,8 @@ class SyntheticLoader:
                     labels=host(b['labels']), masks=host(b['masks']), gts=b['gts'])
 
     def get_batch(self, split):
+        if split in self._eval_pos:
+            return self._eval_batch(split)
         if self.pool > 0:
             idx = self.n % self.pool
             if idx not in self._cache:

@@ -76,28 +76,126 @@ def save_model(model, opt, model_kind, iteration=None):
         torch.save(sd, os.path.join(opt.checkpoint_path, f'{model_kind}-{iteration}.pth'))
 
 
-def checkpoint(opt, model, optimizer_dict, iteration, epoch, loss_history, loader=None):
-    """train.py:299-336 (save_any_kind_of_model, save_optimizer, dump_infos_miscellaneous, save_results): weights,
-    optimizer states, and the infos / histories records as JSON (the reference pickles them; nothing here is ever
-    unpickled).  Besides the reference's fields the infos record carries what this implementation needs to continue
-    the SAME run: the schedule values in force and the position of the noise stream and of the loader."""
+def _jsonable(x):
+    """Histories / infos records as plain JSON: numpy scalars and arrays, tensors and integer keys made portable."""
+    if isinstance(x, dict):
+        return {str(k): _jsonable(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_jsonable(v) for v in x]
+    if torch.is_tensor(x):
+        return x.item() if x.numel() == 1 else x.tolist()
+    if isinstance(x, np.ndarray):
+        return x.tolist()
+    if isinstance(x, (np.floating, np.integer)):
+        return x.item()
+    return x
+
+
+def save_json(args, file_name, save_me, iteration=None, best=None):
+    """train.py:93-116 (save_pkl) with the reference's three file names - <name>_<id>.json, <name>_<id>-<iteration>.json,
+    <name>_<id>-best.json - written as JSON: nothing this trainer writes ever needs unpickling."""
+    assert not (iteration is not None and best is not None), 'Only one of (iteration, best) can be different than None'
+    ext = f'-{iteration}' if iteration else ('-best' if best else '')
+    path = os.path.join(args['checkpoint_path'], f"{file_name}_{args['id']}{ext}.json")
+    with open(path, 'w') as f:
+        json.dump(_jsonable(save_me), f)
+    print(f"{file_name}_{args['id']}{ext}.json saved to {args['checkpoint_path']}")
+
+
+def load_histories(opt):
+    """train.py:187-195: the histories record of the run to continue (JSON; integer keys restored)."""
+    histories = {}
+    if vars(opt).get('start_from', None) is not None:
+        path = os.path.join(opt.start_from, 'histories_' + opt.id + '.json')
+        if os.path.isfile(path):
+            with open(path) as f:
+                raw = json.load(f)
+            histories = {k: ({int(i): v for i, v in d.items()} if isinstance(d, dict) else d) for k, d in raw.items()}
+    return histories
+
+
+def evaluate_model(opt, model, loader, iteration, val_result_history):
+    """train.py:238-251: validation losses, one generated caption per image and (with --rank_eval 1) the retrieval ranks of
+    the val split, on the device engines (eval_utils.eval_split -> greedy / beam decode, cic_listener_fwd,
+    cic_retrieval_ranks)."""
+    from . import eval_utils
+    eval_kwargs = {'split': 'val', 'dataset': opt.input_json, 'use_att': opt.use_att}
+    eval_kwargs.update(vars(opt))
+    eval_kwargs.setdefault('verbose', False)
+    val_loss, predictions, lang_stats = eval_utils.eval_split(model, loader, eval_kwargs,
+                                                              useGenSent=opt.rank_on_gen_captions)
+    val_result_history[iteration] = {'loss': val_loss, 'lang_stats': lang_stats, 'predictions': predictions}
+    return val_result_history, lang_stats, val_loss
+
+
+def get_current_score(opt, lang_stats, val_loss):
+    """train.py:254-277.  language_eval (CIDEr from the Java coco-caption pipeline) is out of scope: the speaker's
+    selection score is -loss_cap, as the reference computes it with --language_eval 0; the listener's is
+    100 x val_loss[vse_eval_criterion] (rsum of the rank evaluation with --rank_eval 1, else 0)."""
+    if opt.language_eval == 1:
+        raise NotImplementedError('language_eval = 1 selects the best model by CIDEr from the Java coco-caption pipeline '
+                                  '(train.py:256-263): out of scope, run with --language_eval 0')
+    current_score = 0 if opt.phase == 1 else -val_loss.get('loss_cap', 0.0)
+    crit = val_loss.get(opt.vse_eval_criterion, None)
+    if crit is None and isinstance(val_loss.get('val'), dict):               # phase 1 ranks come per split (:274-276)
+        crit = val_loss['val'].get(opt.vse_eval_criterion, 0)
+    return float(current_score), float(crit or 0) * 100
+
+
+def check_if_best(current_score, best_val_score, current_score_vse, best_val_score_vse):
+    """train.py:280-292."""
+    best_flag = best_flag_vse = False
+    if best_val_score is None or current_score > best_val_score:
+        best_val_score, best_flag = current_score, True
+    if best_val_score_vse is None or current_score_vse > best_val_score_vse:
+        best_val_score_vse, best_flag_vse = current_score_vse, True
+    return best_val_score, best_flag, best_val_score_vse, best_flag_vse
+
+
+def operations_in_checkpoint(opt, model, loader, iteration, epoch, best, optimizer_dict, infos, histories, eval_loader=None):
+    """train.py:438-470: evaluate on the val split, score, save weights + optimizers + infos + histories, and keep
+    `model-best.pth` / `model_vse-best.pth` with their infos copies when a selection score improved.
+
+    best: {'score', 'score_vse'} - the best validation scores so far, UPDATED in place.  (The reference passes the two
+    scores by value and never hands the new ones back to its loop, train.py:543-547, so inside one run it keeps comparing
+    with the scores it started with and only a restart picks the recorded ones up from infos; the running best is what the
+    record and the -best files are for, so it is kept here.)
+    Records are JSON (the reference pickles them).  Besides the reference's fields the infos record carries what this
+    implementation needs to continue the SAME run: the schedule values in force, the noise stream's and the loader's
+    position."""
     if dist.is_initialized() and dist.get_rank() != 0:
         return
-    save_model(model, opt, 'alternatingModel' if opt.is_alternating else 'model', iteration)
+    val_result_history = histories.setdefault('val_result_history', {})
+    ev = eval_loader if eval_loader is not None else getattr(loader, 'loader', loader)
+    flags = (False, False)
+    if ev is not None and getattr(opt, 'eval_at_checkpoint', 1) and hasattr(ev, 'reset_iterator'):
+        val_result_history, lang_stats, val_loss = evaluate_model(opt, model, ev, iteration, val_result_history)
+        score, score_vse = get_current_score(opt, lang_stats, val_loss)
+        best['score'], f1, best['score_vse'], f2 = check_if_best(score, best.get('score'), score_vse, best.get('score_vse'))
+        flags = (f1, f2)
+        print(f'validation at iteration {iteration}: score {score:.4f} (best {best["score"]:.4f}), '
+              f'listener score {score_vse:.2f} (best {best["score_vse"]:.2f})')
+    save_model(model, opt, 'alternatingModel' if opt.is_alternating else 'model', iteration)      # :295-302
     save_optimizer(opt, optimizer_dict)
     cg = model.caption_generator
-    infos = dict(iter=iteration, epoch=epoch, gumbel_temp=float(cg.gumbel_temp),
+    infos.update(iter=iteration, epoch=epoch, iterators=_loader_state(loader),                    # :305-317
+                 best_val_score=best.get('score'), best_val_score_vse=best.get('score_vse'),
+                 vocab=(ev.get_vocab() if hasattr(ev, 'get_vocab') else None), gumbel_temp=float(cg.gumbel_temp),
+                 opt={k: v for k, v in vars(opt).items() if isinstance(v, (int, float, str, list, type(None)))},
                  ss_prob=float(cg.ss_prob), current_lr=float(getattr(opt, 'current_lr', opt.learning_rate)),
                  retrieval_reward_weight=float(model.retrieval_reward_weight),
                  prob_gumbel_softmax=float(cg.prob_gumbel_softmax), prob_multinomial_soft=float(cg.prob_multinomial_soft),
-                 noise=dict(seed=int(cg.noise.seed), counter=int(cg.noise.counter)),
-                 iterators=_loader_state(loader),
-                 opt={k: v for k, v in vars(opt).items() if isinstance(v, (int, float, str, list, type(None)))})
-    for name in ('infos_' + opt.id + '.json', f'infos_{opt.id}-{iteration}.json'):       # save_pkl writes both (:109-118)
-        with open(os.path.join(opt.checkpoint_path, name), 'w') as f:                     # JSON, not pickle
-            json.dump(infos, f)
-    with open(os.path.join(opt.checkpoint_path, 'histories_' + opt.id + '.json'), 'w') as f:
-        json.dump(dict(loss_history=loss_history), f)
+                 noise=dict(seed=int(cg.noise.seed), counter=int(cg.noise.counter)))
+    args = {'checkpoint_path': opt.checkpoint_path, 'id': opt.id}
+    save_json(args, 'infos', infos)                                                               # save_results :333-336
+    save_json(args, 'infos', infos, iteration=iteration)
+    save_json(args, 'histories', histories)
+    if flags[0]:                                                                                  # save_best_results :339-347
+        save_model(model, opt, 'model-best')
+        save_json(args, 'infos', infos, best=True)
+    if flags[1]:
+        save_model(model, opt, 'model_vse-best')
+        save_json(args, 'infos_vse', infos, best=True)
 
 
 def _loader_state(loader):
@@ -140,6 +238,42 @@ def load_from_infos(infos, loader, opt):
     if loader is not None and st is not None and hasattr(inner, 'load_state_dict'):
         inner.load_state_dict(st)
     return epoch, epoch_start, iteration
+
+
+class LossLog:
+    """The per-iteration log line without draining the queue.  The reference reads `loss.data[0]` right after the step
+    (train.py:533-535): a host sync per iteration, after which the device idles while Python prepares the next step's first
+    launches.  Here the step's loss and the logged terms (model.loss(): 0-dim device values) are gathered by ONE small launch,
+    copied to page-locked memory asynchronously and read when their event has fired - normally while the NEXT step is being
+    enqueued; the host never runs more than `depth` iterations ahead of the device."""
+
+    def __init__(self, device, depth=2, width=32):
+        self.depth, self.width = depth, width
+        self.slots = [torch.empty(width, dtype=torch.float32).pin_memory() for _ in range(depth + 1)]
+        self.pending = []                   # [(meta, keys, slot, event)]
+        self.last = {}                      # iteration -> train_loss of the lines already read
+        self._n = 0
+
+    def push(self, meta, loss, terms):
+        keys = list(terms.keys())[:self.width - 1]
+        vals = [loss.detach().reshape(())] + [torch.as_tensor(terms[k], device=loss.device).detach().reshape(()).float()
+                                              for k in keys]
+        slot = self.slots[self._n % len(self.slots)]
+        self._n += 1
+        slot[:len(vals)].copy_(torch.stack(vals), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending.append((meta, keys, slot, ev, len(vals)))
+
+    def pop(self, emit, block_to=None):
+        """Emit every line whose values have landed; block until at most `block_to` lines are outstanding."""
+        block_to = self.depth if block_to is None else block_to
+        while self.pending and (len(self.pending) > block_to or self.pending[0][3].query()):
+            meta, keys, slot, ev, n = self.pending.pop(0)
+            ev.synchronize()
+            vals = slot[:n].tolist()
+            self.last[meta['iteration']] = vals[0]
+            emit(meta, vals[0], dict(zip(keys, vals[1:])))
 
 
 def load_data(data, opt, device):
@@ -205,16 +339,34 @@ def train(opt, loader=None):
         overlap_gradient_exchange(model, optimizer_dict)
     update_lr_flag = True
     epoch, epoch_start, iteration = load_from_infos(infos, None, opt)
+    histories = load_histories(opt)                                                # train.py:374-379
+    loss_history = histories.setdefault('loss_history', {})
+    lr_history = histories.setdefault('lr_history', {})
+    ss_prob_history = histories.setdefault('ss_prob_history', {})
+    best = {'score': None, 'score_vse': None}
+    if getattr(opt, 'load_best_score', 1):                                         # train.py:369-374
+        best = {'score': infos.get('best_val_score'), 'score_vse': infos.get('best_val_score_vse')}
     reported_path = False
-    loss_history = {}
     num_turns = len(opt.alternating_turn) if opt.is_alternating else 1
     init_scorer(opt.cached_tokens)
+    log = LossLog(device)
+    want_history = set()
+
+    def emit(meta, train_loss, terms):
+        if meta['iteration'] + 1 in want_history:                                  # write_loss_summary, train.py:229-235
+            want_history.discard(meta['iteration'] + 1)
+            loss_history[meta['iteration'] + 1] = train_loss
+        if rank == 0:
+            extra = ' '.join(f'{k} = {v:.3f}' for k, v in terms.items())
+            print(f"iter {meta['iteration']} (epoch {meta['epoch']}) [{meta['turn']}], train_loss = {train_loss:.4f}, "
+                  f"time/batch = {meta['host_s']:.4f}  {extra}", flush=True)
+
+    last_end = time.time()
     while True:
         curr_turn = opt.alternating_turn[iteration % num_turns] if opt.is_alternating else 'optimizer'
         optimizer = optimizer_dict[curr_turn]
         update_lr_flag = apply_schedules(update_lr_flag, opt, epoch, optimizer_dict, optimizer, model, epoch_start,
                                          iteration)
-        start = time.time()
         data = loader.get_batch('train')
         fc_feats, att_feats, att_masks, labels, masks = load_data(data, opt, device)
         zeroing_optimizer(opt, optimizer_dict, optimizer)
@@ -227,27 +379,36 @@ def train(opt, loader=None):
         update_optimizer(optimizer_dict, optimizer, opt)
         if hasattr(loader, 'prefetch'):
             loader.prefetch()                                   # batch i+1 travels to HBM while step i computes
-        train_loss = float(loss.detach())                       # the step's one host sync (train.py:533-535)
         end = time.time()
+        # the loss and the logged terms follow asynchronously; the line of iteration i is printed once they have landed
+        # (while step i+1 is being enqueued): steady-state time per iteration = what the device needs, as in bench.py
+        log.push(dict(iteration=iteration, epoch=epoch, turn=curr_turn, host_s=end - last_end), loss, model.loss())
+        last_end = end
+        log.pop(emit)
         if rank == 0 and not reported_path and hasattr(model, 'caption_generator'):
             fused = getattr(model.caption_generator, 'last_pair_fused', None)
             if fused is not None:      # which decode path this batch size gets (B % 32 == 0 and B <= 128: shared launches)
                 print('sampled + greedy decodes: ' + ('one launch chain over 2B rows' if fused else 'two launch chains'))
                 reported_path = True
-        if rank == 0:
-            extra = ' '.join(f'{k} = {float(v):.3f}' for k, v in model.loss().items())
-            print(f'iter {iteration} (epoch {epoch}) [{curr_turn}], train_loss = {train_loss:.4f}, '
-                  f'time/batch = {end - start:.4f}  {extra}', flush=True)
         iteration += 1
         if data['bounds']['wrapped']:
             epoch += 1
             update_lr_flag = True
-        if iteration % opt.losses_log_every == 0:
-            loss_history[iteration] = train_loss
-        if iteration % opt.save_checkpoint_every == 0:
-            checkpoint(opt, model, optimizer_dict, iteration, epoch, loss_history, loader)
-        if (epoch >= opt.max_epochs != -1) or (0 < opt.max_iterations <= iteration):
+        start_ckpt = bool(getattr(opt, 'start_with_checkpoint', 0))
+        if iteration % opt.losses_log_every == 0 or start_ckpt:                    # train.py:540-543
+            want_history.add(iteration)
+            lr_history[iteration] = float(getattr(opt, 'current_lr', opt.learning_rate))
+            ss_prob_history[iteration] = float(model.caption_generator.ss_prob)
+        done = (epoch >= opt.max_epochs != -1) or (0 < opt.max_iterations <= iteration)
+        if iteration % opt.save_checkpoint_every == 0 or start_ckpt:               # train.py:546-552
+            log.pop(emit, block_to=0)                            # the histories record holds every line up to here
+            operations_in_checkpoint(opt, model, loader, iteration, epoch, best, optimizer_dict, infos, histories)
+            model.train()
+        if start_ckpt:
+            opt.start_with_checkpoint = 0
+        if done:
             break
+    log.pop(emit, block_to=0)
     if hasattr(loader, 'close'):
         loader.close()
     return model

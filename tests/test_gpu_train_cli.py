@@ -122,3 +122,59 @@ def test_resume_continues_the_same_run(tmp_path, capsys):
         if k.endswith('alpha_net.bias'):
             continue          # a softmax shift: its gradient is rounding noise, which Adam turns into lr-sized steps
         np.testing.assert_allclose(wc[k].numpy(), wa[k].numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
+
+
+def test_checkpoint_evaluates_scores_and_keeps_the_best_model(tmp_path, capsys):
+    """train.py:438-470 (operations_in_checkpoint): at every --save_checkpoint_every the val split is evaluated on the device
+    engines (losses, one generated caption per image, retrieval ranks with --rank_eval 1), the speaker's selection score is
+    -loss_cap and the listener's 100 x rsum (get_current_score :254-277), improved scores write model-best.pth /
+    model_vse-best.pth with their infos copies (:339-347), the four histories are kept (:238-244,323-336), and a resumed
+    run starts from the recorded best scores (load_best_score :369-374)."""
+    import json
+    from cooperativeimagecaptioning_amd import opts, train
+
+    def run(path, iters, start_from=None):
+        argv = [a for a in COMMON] + ['--retrieval_reward', 'gumbel', '--max_iterations', str(iters), '--checkpoint_path', str(path),
+                                      '--rank_eval', '1', '--val_images_use', '16', '--language_eval', '0']
+        argv[argv.index('--save_checkpoint_every') + 1] = '2'
+        argv[argv.index('--caption_loss_weight') + 1] = '1'      # loss_cap exists: the speaker's score is -loss_cap
+        if start_from is not None:
+            argv += ['--start_from', str(start_from)]
+        opt = opts.parse_opt(argv)
+        opt.vocab_size, opt.seq_length = 199, 16
+        return train.train(opt)
+    a = tmp_path / 'a'
+    run(a, 4)
+    out = capsys.readouterr().out
+    assert out.count('validation at iteration') == 2
+    assert len([l for l in out.splitlines() if l.startswith('iter ')]) == 4
+    for f in ('alternatingModel-2.pth', 'alternatingModel-4.pth', 'model-best.pth', 'model_vse-best.pth', 'infos_cli.json',
+              'infos_cli-2.json', 'infos_cli-4.json', 'infos_cli-best.json', 'infos_vse_cli-best.json', 'histories_cli.json'):
+        assert os.path.isfile(os.path.join(str(a), f)), f
+    hist = json.load(open(os.path.join(str(a), 'histories_cli.json')))
+    assert set(hist['val_result_history']) == {'2', '4'} and set(hist['loss_history']) == {'1', '2', '3', '4'}
+    assert set(hist['lr_history']) == set(hist['ss_prob_history']) == {'1', '2', '3', '4'}
+    scores, scores_vse = [], []
+    for it in ('2', '4'):
+        v = hist['val_result_history'][it]
+        assert len(v['predictions']) == 16 and all('caption' in p and 'image_id' in p for p in v['predictions'])
+        assert np.isfinite(v['loss']['loss_cap']) and 0 <= v['loss']['rsum'] <= 600
+        scores.append(-v['loss']['loss_cap'])
+        scores_vse.append(100 * v['loss']['rsum'])
+    infos = json.load(open(os.path.join(str(a), 'infos_cli.json')))
+    assert infos['best_val_score'] == pytest.approx(max(scores)) and infos['best_val_score_vse'] == pytest.approx(max(scores_vse))
+    best = json.load(open(os.path.join(str(a), 'infos_cli-best.json')))
+    assert best['iter'] == (2 if scores[0] >= scores[1] else 4) and best['best_val_score'] == pytest.approx(max(scores))
+    # the best weights are those of the checkpoint that scored best
+    wb = torch.load(os.path.join(str(a), 'model-best.pth'), map_location='cpu', weights_only=True)
+    wi = torch.load(os.path.join(str(a), f'alternatingModel-{best["iter"]}.pth'), map_location='cpu', weights_only=True)
+    assert all(torch.equal(wb[k], wi[k]) for k in wb)
+    # a resumed run keeps the recorded best scores: they can only improve
+    run(tmp_path / 'b', 6, start_from=a)
+    out = capsys.readouterr().out
+    assert out.count('validation at iteration') == 1
+    infos_b = json.load(open(os.path.join(str(tmp_path / 'b'), 'infos_cli.json')))
+    assert infos_b['iter'] == 6 and infos_b['best_val_score'] >= infos['best_val_score'] - 1e-12
+    assert infos_b['best_val_score_vse'] >= infos['best_val_score_vse'] - 1e-12
+    hist_b = json.load(open(os.path.join(str(tmp_path / 'b'), 'histories_cli.json')))
+    assert set(hist_b['val_result_history']) == {'2', '4', '6'}          # the record continues

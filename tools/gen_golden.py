@@ -522,10 +522,36 @@ def gen_retrieval(torch):
         save(name, images=images, captions=cap.astype(np.float32), cpi=np.int64(cpi), **out)
 
 
+def gen_state_dict_layout(torch, models):
+    """Checkpoint compatibility: the KEYS and SHAPES of the reference's AlternatingJointModel.state_dict()
+    - what train.py's save_model writes into alternatingModel.pth (train.py:119-129) - at BASELINE's widths: a fresh model,
+    and the model after a REINFORCE speaker turn, when changeModelUpdateStatus (AlternatingJointModel.py:571-586) has
+    deep-copied both agents into the sub-modules prev_vse / prev_caption_generator, whose tensors the reference then saves
+    as well.  Names and shapes only (plus a digest of the seed-0 initial values per tensor): no weights are stored."""
+    import json as _json
+    opt = make_opt(vocab_size=9487, input_encoding_size=512, rnn_size=512, att_hid_size=512, fc_feat_size=2048,
+                   att_feat_size=2048, vse_embed_size=1024, retrieval_reward='reinforce', batch_size=4)
+    torch.manual_seed(0)
+    m = models.AlternatingJointModel(opt)
+    fresh = {k: [int(d) for d in v.shape] for k, v in m.state_dict().items()}
+    dig = {k: [float(v.double().sum()), float(v.double().abs().sum())] for k, v in m.state_dict().items()}
+    m.changeModelUpdateStatus({'vseModel': False, 'captionModel': True})          # what a reinforce speaker turn does first (:508-511)
+    after = {k: [int(d) for d in v.shape] for k, v in m.state_dict().items()}
+    assert set(fresh) < set(after)
+    np.savez_compressed(os.path.join(OUT, 'state_dict_layout.npz'),
+                        fresh=np.array(_json.dumps(fresh)), after_reinforce_speaker_turn=np.array(_json.dumps(after)),
+                        init_digest_seed0=np.array(_json.dumps(dig)), opt=np.array(_json.dumps(
+                            {k: v for k, v in vars(opt).items() if isinstance(v, (int, float, str, list, type(None)))})))
+    print('state_dict_layout:', len(fresh), 'keys fresh,', len(after), 'after a reinforce speaker turn')
+
+
 def main():
     torch, models, rewards = install_harness()
     rec = Recorder(torch)
     torch.set_num_threads(4)
+    if '--only-statedict' in sys.argv:
+        gen_state_dict_layout(torch, models)
+        return
     only_masks = '--only-masks' in sys.argv     # the att_masks cases only (other fixtures untouched)
     only_full = '--only-fullwidth' in sys.argv  # the BASELINE-width joint step only
     if '--only-retrieval' in sys.argv:
@@ -918,6 +944,7 @@ def main():
         gen_fc_joint(torch, models, rec)
         gen_beam(torch, models, rec)
         gen_retrieval(torch)
+        gen_state_dict_layout(torch, models)
     # ------------------------------------------------------------------ att_masks (ragged region counts)
     for name, rr, kw, opts_, eos in SAMPLE_MASKED:
         sample_case(name, rr, kw, opts_, eos, masked=True)
