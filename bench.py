@@ -212,6 +212,7 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if args.same_device:
             assert args.backend == 'gloo', '--same-device is a gloo rehearsal (RCCL wants one GPU per rank)'
+            os.environ['CIC_SHARED_DEVICE'] = '1'     # several ranks compute on one GPU: no launches that need the whole chip
             local_rank = 0
         torch.cuda.set_device(local_rank)
         dist.init_process_group(args.backend)  # 'nccl' = RCCL over xGMI
@@ -239,6 +240,7 @@ def main():
         optimizer_dict = optim.load_optimizer(model, opt)
     if world > 1:
         optim.overlap_gradient_exchange(model, optimizer_dict)   # listener all-reduce under the speaker backward
+    optim.fuse_zero_grad(optimizer_dict)        # the gradient buffers are cleared inside the clamp+Adam kernels
     # per-rank shard of the global batch; `--batches` distinct batches stay resident in HBM and are served round robin
     # (their reference captions are packed for the CIDEr-D kernels on first use: host work outside the metric, like
     # the loader's; the n-gram / document-frequency / score kernels run in every step)
@@ -272,13 +274,19 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
+    host_t = []
     for i in range(args.steps):
         loss = step()
         marks[i + 1].record()
+        host_t.append(time.perf_counter() - t0)          # when the host had ENQUEUED step i
     barrier()
     dt = time.perf_counter() - t0
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     median_ms = step_ms[len(step_ms) // 2]
+    # how far the host runs ahead of the device: (device time at which step i ended) - (host time at which it was enqueued).
+    # Growing from step to step = the device sets the pace (the host waits in the end); ~0 throughout = launch-bound.
+    ahead = [marks[0].elapsed_time(marks[i + 1]) - host_t[i] * 1e3 for i in range(args.steps)]
+    host_ms = (host_t[-1] - host_t[0]) / max(args.steps - 1, 1) * 1e3
     # roofline legs, AFTER the timed region: the same step a few more times with a cic_timer attached to the decodes, which
     # brackets every in-step launch of the attention / logit / sampler kernels with HIP events on this stream
     # (every rank runs them - the steps contain the gradient exchange -, rank 0 reads its timer)
@@ -324,6 +332,8 @@ def main():
             'metric': 'joint-step images/sec (B=128, seq16)', 'value': B * world * args.steps / dt, 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'median_ms_per_step': median_ms,
+            'host_enqueue_ms_per_step': host_ms, 'device_behind_host_ms': {'first': ahead[0], 'median': sorted(ahead)[len(ahead) // 2],
+                                                                          'last': ahead[-1]},
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'AlternatingJointModel joint step, att2in2 speaker + VSE-fc listener, ST-Gumbel '
                                    'tau=1 + self-critical CIDEr-D, 36x2048 att_feats, vocab 9487, seq_len 16, '

@@ -47,7 +47,8 @@ class GemmArgs(C.Structure):
                 ('C_tail', c_ptr), ('C_tail_b', c_ptr), ('ldc_tail', C.c_int),
                 ('epi', c_ptr),        # fused vocabulary epilogue (the decode engine's logit product); NULL here
                 ('precision', C.c_int),   # 0 f32 accuracy (default), 1 f32-input MFMA only, 2 bf16 operands
-                ('B_parts', c_ptr)]       # B pre-split by cic_split_bf16x3 (the logit weights), or NULL
+                ('B_parts', c_ptr),       # B pre-split by cic_split_bf16x3 (the logit weights), or NULL
+                ('live', c_ptr), ('live_b', c_ptr)]   # decode-loop early stop flags (engines only); NULL here
 
 
 class SamplerArgs(C.Structure):
@@ -139,7 +140,7 @@ class ListenerIO(C.Structure):
     _fields_ = [('fc_feats', c_ptr), ('labels', c_ptr), ('masks', c_ptr), ('seq', c_ptr), ('stv', c_ptr),
                 ('L', c_ptr), ('soft', c_ptr), ('only_one_retrieval', C.c_int), ('loss_rows', c_ptr),
                 ('loss_sum', c_ptr),
-                ('img_emb_out', c_ptr), ('cap_emb_out', c_ptr)]
+                ('img_emb_out', c_ptr), ('cap_emb_out', c_ptr), ('device_shared', C.c_int)]
 
 
 class ListenerBwdIO(C.Structure):

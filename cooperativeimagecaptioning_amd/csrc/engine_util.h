@@ -45,7 +45,8 @@ int cic_attn_fwd2(Dual<const float> att_h, Dual<const float> p_att, Dual<const f
                   const float* b_alpha, const float* masks, Dual<float> att_res, Dual<float> alpha, Dual<float> dot, int B,
                   int nb, int K, int A, int H, hipStream_t st, int att_div = 1,
                   Dual<const uint16_t> p_att_bf = Dual<const uint16_t>{nullptr, nullptr},
-                  Dual<const uint16_t> att_bf = Dual<const uint16_t>{nullptr, nullptr});
+                  Dual<const uint16_t> att_bf = Dual<const uint16_t>{nullptr, nullptr},
+                  Dual<const int32_t> live = Dual<const int32_t>{nullptr, nullptr});
 // x <- bf16(x) (round to nearest even, in place as f32) and its packed bf16 copy
 int cic_round_pack_bf16(float* x, uint16_t* packed, int64_t n, hipStream_t st);
 int cic_cell_fwd2(Dual<const float> pre, Dual<const float> c_prev, Dual<const uint8_t> keep, float p_drop, Dual<float> h_new,
@@ -55,7 +56,7 @@ int cic_embed_fwd2(const float* E, Dual<const int32_t> it, Dual<const uint8_t> k
 bool cic_a2c_cell_fused_ok(int H);
 int cic_a2c_cell_fused(Dual<const float> att_res, const float* Wa, const float* ba, Dual<float> pre, Dual<const float> c_prev,
                        Dual<const uint8_t> keep, float p_drop, Dual<float> h_new, Dual<float> c_new, Dual<float> out, int B,
-                       int nb, int H, hipStream_t st);
+                       int nb, int H, hipStream_t st, Dual<const int32_t> live = Dual<const int32_t>{nullptr, nullptr});
 int cic_logsoftmax_sample2(const cic_sampler_args* a, const cic_sampler_args* b, hipStream_t st);
 // the sampler on the row partials of the step's logits (no pass over the vocabulary); writes the rows' lse
 int cic_teacher_tokens(const int64_t* pick, int32_t* it_all, int32_t* unfinished, int32_t* any_unf, int32_t* seq, int T, int B,

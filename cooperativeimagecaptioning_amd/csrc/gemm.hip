@@ -1245,6 +1245,7 @@ __global__ __launch_bounds__(KS * 64) void gemm_walk16bf_kernel(cic_gemm_args g,
     static_assert(KS == 8, "8 accumulator registers (2 row tiles x 4) dealt one per wave");
     constexpr int JS = 4;                                   // k-steps per wave
     __shared__ float red[2 * KS * 8 * 64];
+    if (g.live && *g.live == 0 && (!g.live_b || *g.live_b == 0)) return;   // every caption has ended (grid-uniform)
     const int tid = threadIdx.x, lane = tid & 63, ks = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
     const int li = lane & 15, lq = lane >> 4;
     const int tiles_n = (g.N + 15) / 16;
@@ -1778,6 +1779,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int wg = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * per_xcd + blockIdx.x / 8 : blockIdx.x;
     const int rg = wg % row_groups, first = wg / row_groups;
     if (first >= walkers) return;                          // whole workgroup: no barrier is skipped by a part of it
+    if (g.live && *g.live == 0 && (!g.live_b || *g.live_b == 0)) return;   // every caption has ended (grid-uniform)
     const int tiles_n = (g.N + 15) / 16;
     const int rg_a = g.rows_blk > 0 ? (g.rows_blk + 63) / 64 : row_groups;
     const bool blk2 = rg >= rg_a;

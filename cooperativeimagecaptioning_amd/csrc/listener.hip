@@ -15,7 +15,10 @@
 
 namespace {
 
-CIC_SWITCH(g_gru_fused, 1);   // development build: cic_debug_gru_fused(0) = GEMM + cell launches per step (A/B measurement)
+// 2 = the whole GRU pass as one launch with W_hh stationary in registers (gru_seq_kernel; needs one resident workgroup per
+// 32-row strip x 16-unit tile, else 1); 1 = one fused launch per step; 0 = a GEMM + a cell launch per step.
+// Development build: cic_debug_gru_fused(n) selects (A/B measurement, bit-exactness tests of 2 against 1).
+CIC_SWITCH(g_gru_fused, 2);
 
 // ---- token preparation -----------------------------------------------------------------
 // generated captions: tokens = [<bos>, seq[:, 0:L]], lens from masks [1,1,(seq>0)[:, :L-1]]
@@ -23,10 +26,11 @@ CIC_SWITCH(g_gru_fused, 1);   // development build: cic_debug_gru_fused(0) = GEM
 __global__ void prep_generated_kernel(const int32_t* __restrict__ seq, const float* __restrict__ stv,
                                       const int32_t* __restrict__ Lp, int B, int T, int bos, int dense,
                                       int32_t* __restrict__ idx, float* __restrict__ val,
-                                      int32_t* __restrict__ len) {
+                                      int32_t* __restrict__ len, unsigned* __restrict__ sync, int nsync) {
     // dense != 0 (soft caption rows): positions 1..T are embedded by a dense product added afterwards, so
     // their gather contributes nothing (val = 0)
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = b; i < nsync; i += gridDim.x * blockDim.x) sync[i] = 0u;    // hand-off counters of gru_seq_kernel
     if (b >= B) return;
     const int L = *Lp;
     int n = 2;
@@ -43,8 +47,10 @@ __global__ void prep_generated_kernel(const int32_t* __restrict__ seq, const flo
 }
 // ground-truth labels: idx = labels, lens = sum(masks > 0)   (VSEFCModel.py:83-85)
 __global__ void prep_labels_kernel(const int64_t* __restrict__ labels, const float* __restrict__ masks, int B, int Lp,
-                                   int32_t* __restrict__ idx, float* __restrict__ val, int32_t* __restrict__ len) {
+                                   int32_t* __restrict__ idx, float* __restrict__ val, int32_t* __restrict__ len,
+                                   unsigned* __restrict__ sync, int nsync) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = b; i < nsync; i += gridDim.x * blockDim.x) sync[i] = 0u;    // hand-off counters of gru_seq_kernel
     if (b >= B) return;
     int n = 0;
     for (int j = 0; j < Lp; ++j) {
@@ -202,6 +208,144 @@ __global__ __launch_bounds__(KS * 64) void gru_step_fused_kernel(const float* __
             hn = (1.0f - zz) * nn + zz * hp;
         }
         h_new[(size_t)orow * J + col] = hn;
+    }
+}
+
+// ---- the whole GRU pass in ONE launch: recurrent weights stationary in registers ------------------------------------
+// gru_step_fused_kernel re-streams its 196 KB weight tile (3 gates x 16 units x J floats) in every one of the Lp steps
+// although it never changes: the tile is exactly what the 8 waves of the workgroup can HOLD - 96 VGPRs per lane.  This
+// kernel is that step kernel with the time loop inside: same workgroup decomposition (32-row strip x 16-unit tile, K split
+// over 8 waves, one workgroup per CU, all of them resident), same MFMA order, same cross-wave sums, same gate arithmetic
+// - so h and gh come out bit for bit as from the per-step launches -, but W_hh is read once, there are no launch
+// boundaries, and a step moves only the strip's h rows (128 KB per workgroup).
+//
+// What a step t >= 1 needs from OTHER workgroups is h_t of its own 32-row strip, written by the 64 workgroups of that
+// strip in step t-1.  Hand-off per strip and step (MI355X_MICROARCH.md, inter-workgroup visibility, first row of the sc1
+// table; hipMalloc'ed memory, one workgroup per CU):
+//   producer: every lane stores its h element write-through (buffer_store ... sc1), every wave drains (s_waitcnt
+//             vmcnt(0)), workgroup barrier, ONE lane adds 1 to the strip's counter of step t+1 (agent-scope atomic);
+//   consumer: ONE lane polls that counter (relaxed agent-scope load = global_load sc1, s_sleep between polls) until it
+//             reads tiles_j, workgroup barrier, then EVERY load of the handed-off rows is a buffer_load ... sc1.
+// No fence on either side; the counters are zeroed by the token-preparation kernel that precedes this launch on the
+// stream.  Nothing here depends on dispatch order or placement; it needs every workgroup RESIDENT (grid <= CUs, checked
+// by the launcher, which otherwise uses the per-step kernel).  Every spin is bounded by a wall-clock budget: a workgroup
+// that gives up raises *err and poisons its outputs with NaN (the loss then says so) instead of hanging the device.
+constexpr unsigned long long GRU_SPIN_TICKS = 20ull * 100000ull;     // 20 ms of the 100 MHz s_memrealtime counter
+template <int GPS, int KS>
+__global__ __launch_bounds__(KS * 64) void gru_seq_kernel(float* __restrict__ h_all, const float* __restrict__ W,
+                                                          const float* __restrict__ b_hh, const float* __restrict__ gi_all,
+                                                          const int32_t* __restrict__ len, float* __restrict__ gh_all,
+                                                          unsigned* __restrict__ sync, int B, int J, int Lp) {
+    static_assert(KS == 8, "8 accumulator registers (2 row tiles x 4) dealt one per wave");
+    __shared__ float red[2 * KS * 8 * 64];
+    __shared__ int ok_s;
+    const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int tiles_j = J / 16;
+    const int strip = blockIdx.x / tiles_j, jt = blockIdx.x % tiles_j;
+    const int m0 = strip * 32;
+    const int col = jt * 16 + li;
+    const int orow = m0 + 16 * (ks >> 2) + 4 * lq + (ks & 3);
+    const int orc = orow < B ? orow : B - 1;
+    const int ln = len[orc];
+    unsigned* cnt = sync + (size_t)strip * (Lp + 1);      // cnt[t]: workgroups of this strip that have published h_t
+    unsigned* err = sync + (size_t)gridDim.x / tiles_j * (Lp + 1);
+    const size_t slab = (size_t)B * J;
+    // the weight tile, once: B fragments of the three gates for this wave's K slice
+    f32x4 wf[3][GPS];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const float* wrow = W + ((size_t)g * J + col) * J;
+#pragma unroll
+        for (int i = 0; i < GPS; ++i) wf[g][i] = *reinterpret_cast<const f32x4*>(wrow + 16 * (ks * GPS + i) + 4 * lq);
+    }
+    const float bh0 = b_hh[col], bh1 = b_hh[J + col], bh2 = b_hh[2 * J + col];
+    float poison = 0.f;
+    if (orow < B) h_all[(size_t)orow * J + col] = 0.f;    // h_0 (read by the backward pass; this kernel never reads it)
+    for (int t = 0; t < Lp; ++t) {
+        const float* gi = gi_all + (size_t)t * B * 3 * J;
+        float* gh_out = gh_all + (size_t)t * B * 3 * J;
+        float* h_new = h_all + (size_t)(t + 1) * slab;
+        // this step's input projections: written before the launch, independent of the hand-off
+        const float gir = gi[(size_t)orc * 3 * J + col], giz = gi[(size_t)orc * 3 * J + J + col],
+                    gin = gi[(size_t)orc * 3 * J + 2 * J + col];
+        float ghv[3] = {bh0, bh1, bh2};
+        float hp = 0.f;
+        if (t > 0) {
+            if (tid == 0) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                int ok = 1;
+                while (__hip_atomic_load(cnt + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)tiles_j) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > GRU_SPIN_TICKS) { ok = 0; break; }
+                }
+                ok_s = ok;
+                if (!ok) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // compiler only: no load of h_t above the poll
+            if (!ok_s) poison = __builtin_nanf("");
+            // h_t of the strip: every load of the handed-off bytes is sc1 (aux 16)
+            const auto hsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(h_all + (size_t)t * slab), 0,
+                                                                (int)(slab * sizeof(float)), 0x00020000);
+            f32x4 af[2][GPS];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int mc = min(m0 + 16 * rt + li, B - 1);
+#pragma unroll
+                for (int i = 0; i < GPS; ++i) {
+                    const int k = 16 * (ks * GPS + i) + 4 * lq;
+                    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(hsrc, (int)(((size_t)mc * J + k) * 4), 0, 16);
+                    af[rt][i] = __builtin_bit_cast(f32x4, raw);     // rows past B repeat row B-1: their sums are never stored
+                }
+            }
+            hp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hsrc, (int)(((size_t)orc * J + col) * 4), 0, 16));
+            __builtin_amdgcn_sched_barrier(0);      // all 16 KB of the wave's h rows are requested before the first MFMA waits
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                f32x4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < GPS; ++i)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][i][s], wf[g][i][s], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][i][s], wf[g][i][s], acc1, 0, 0, 0);
+                    }
+                float* rb = red + (g & 1) * (KS * 8 * 64);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    rb[(ks * 8 + v) * 64 + lane] = acc0[v];
+                    rb[(ks * 8 + 4 + v) * 64 + lane] = acc1[v];
+                }
+                __syncthreads();
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < KS; ++w) v += rb[(w * 8 + ks) * 64 + lane];
+                ghv[g] = v + (g == 0 ? bh0 : (g == 1 ? bh1 : bh2));
+            }
+        }
+        if (orow < B) {
+            const size_t o = (size_t)orow * 3 * J + col;
+            gh_out[o] = ghv[0];
+            gh_out[o + J] = ghv[1];
+            gh_out[o + 2 * J] = ghv[2];
+            float hn = hp;
+            if (t < ln) {
+                const float rr = fast_sigmoid(gir + ghv[0]);
+                const float zz = fast_sigmoid(giz + ghv[1]);
+                const float nn = fast_tanh(gin + rr * ghv[2]);
+                hn = (1.0f - zz) * nn + zz * hp;
+            }
+            if (poison != 0.f) hn = poison;      // NaN != 0: a workgroup that gave up on a hand-off marks what it produced
+            // publish: write-through store of the one element this lane owns
+            const auto hdst = __builtin_amdgcn_make_buffer_rsrc(h_new, 0, (int)(slab * sizeof(float)), 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hn), hdst, (int)(((size_t)orow * J + col) * 4), 0, 16);
+        }
+        if (t + 1 < Lp) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // EVERY storing wave drains before the signal
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(cnt + t + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -437,6 +581,8 @@ __global__ __launch_bounds__(256) void contrastive_bwd_kernel(const float* __res
 }
 
 struct LstWs {
+    unsigned* sync;           // gru_seq_kernel: [strips][Lp+1] hand-off counters + 1 error word (zeroed by the prep kernels)
+    int nsync;
     int32_t *idx, *len, *arg_s, *arg_im;
     float *val, *x_emb, *gi_all, *gh_all, *h_all, *img_lin, *img_emb, *cap_emb, *nrm_img, *nrm_cap, *S;
     // backward scratch
@@ -449,6 +595,8 @@ LstWs lst_carve(const cic_listener_dims& d, void* base) {
     LstWs w;
     Carver c(base);
     const size_t B = d.B, J = d.J, E = d.E, Lp = d.Lp;
+    w.nsync = (int)(((B + 31) / 32) * (Lp + 1) + 1);
+    w.sync = reinterpret_cast<unsigned*>(c.i32((size_t)(w.nsync + 3) / 4 * 4));
     w.idx = c.i32(B * Lp);
     w.len = c.i32(B);
     w.arg_s = c.i32(B);
@@ -534,11 +682,11 @@ static int listener_fwd_impl(const cic_listener_dims* dp, const cic_listener_par
     if (io->labels) {
         CIC_REQUIRE(io->masks);
         hipLaunchKernelGGL(prep_labels_kernel, dim3(cic_cdiv(B, 256)), dim3(256), 0, st, io->labels, io->masks, B, Lp,
-                           w.idx, w.val, w.len);
+                           w.idx, w.val, w.len, w.sync, w.nsync);
     } else {
         CIC_REQUIRE(io->seq && io->L && Lp == d.T + 1);
         hipLaunchKernelGGL(prep_generated_kernel, dim3(cic_cdiv(B, 256)), dim3(256), 0, st, io->seq, io->stv, io->L, B,
-                           d.T, d.V + 1, io->soft ? 1 : 0, w.idx, w.val, w.len);
+                           d.T, d.V + 1, io->soft ? 1 : 0, w.idx, w.val, w.len, w.sync, w.nsync);
     }
     CIC_LAUNCH_CHECK();
     // image encoder: l2norm(fc W^T + b)                                  (VSEFCModel.py:40-54)
@@ -558,9 +706,24 @@ static int listener_fwd_impl(const cic_listener_dims* dp, const cic_listener_par
         RUN(gemm_nn_fwd(io->soft, d.V + 1, p->embed_w, E, w.x_emb + (size_t)B * E, E, (Lp - 1) * B, E, d.V + 1, true, st));
     }
     RUN(gemm_nt(w.x_emb, E, p->w_ih, E, w.gi_all, 3 * J, Lp * B, 3 * J, E, p->b_ih, false, false, st));
-    CIC_HIP(hipMemsetAsync(w.h_all, 0, sizeof(float) * B * J, st));
     const bool fused_step = g_gru_fused && J == 1024;       // the flagship width: one launch per step (see the kernel)
-    for (int t = 0; t < Lp; ++t) {
+    bool seq_kernel = false;
+    if (g_gru_fused >= 2 && J == 1024 && !io->device_shared) {
+        // the one-launch form needs every workgroup resident at once: one per CU (512 threads holding the weight tile in
+        // ~200 VGPRs each fill a CU's register file)
+        int dev = 0, cus = 0;
+        CIC_HIP(hipGetDevice(&dev));
+        CIC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        seq_kernel = cic_cdiv(B, 32) * (J / 16) <= cus;
+    }
+    if (seq_kernel) {
+        hipLaunchKernelGGL((gru_seq_kernel<8, 8>), dim3(cic_cdiv(B, 32) * (J / 16)), dim3(512), 0, st, w.h_all, p->w_hh, p->b_hh,
+                           w.gi_all, w.len, w.gh_all, w.sync, B, J, Lp);
+        CIC_LAUNCH_CHECK();
+    } else {
+        CIC_HIP(hipMemsetAsync(w.h_all, 0, sizeof(float) * B * J, st));
+    }
+    for (int t = 0; t < Lp && !seq_kernel; ++t) {
         float* h = w.h_all + (size_t)t * B * J;
         float* gh = w.gh_all + (size_t)t * B * 3 * J;
         if (fused_step) {

@@ -68,7 +68,9 @@ __global__ __launch_bounds__(256) void masked_nll_kernel(const float* __restrict
 }
 
 // clip_gradient (elementwise clamp, misc/utils.py:65-69) + torch.optim.Adam.step (optimizer.py:25-27)
-__global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+// ZERO: the gradient is cleared on the way out (the next step's zero_grad(), optimizer.py:224-230, without a pass of its own)
+template <bool ZERO>
+__global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, float* __restrict__ g,
                                                          float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                          float clip, float wd, float b1, float b2, float eps,
                                                          float step_size, float bc2_sqrt, float gscale) {
@@ -91,6 +93,7 @@ __global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, 
         *reinterpret_cast<f32x4*>(p + i) = pp;
         *reinterpret_cast<f32x4*>(m + i) = mm;
         *reinterpret_cast<f32x4*>(v + i) = vv;
+        if (ZERO) *reinterpret_cast<f32x4*>(g + i) = f32x4{0.f, 0.f, 0.f, 0.f};
     } else {
         for (int64_t j = i; j < n; ++j) {
             float x = fminf(fmaxf(g[j] * gscale, -clip), clip);
@@ -99,6 +102,7 @@ __global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, 
             v[j] = v[j] * b2 + (1.0f - b2) * x * x;
             const float denom = sqrtf(v[j]) / bc2_sqrt + eps;
             p[j] = p[j] - step_size * (m[j] / denom);
+            if (ZERO) g[j] = 0.f;
         }
     }
 }
@@ -153,15 +157,27 @@ extern "C" int cic_masked_nll(const float* slp, const float* mask, int mask_ld, 
 extern "C" int cic_clamp_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
                               double beta2, double eps, double weight_decay, double grad_clip, int step,
                               double grad_scale, cic_stream_t s) {
+    return cic_clamp_adam_zero(p, const_cast<float*>(g), m, v, n, lr, beta1, beta2, eps, weight_decay, grad_clip, step,
+                               grad_scale, 0, s);
+}
+
+extern "C" int cic_clamp_adam_zero(float* p, float* g, float* m, float* v, int64_t n, double lr, double beta1,
+                                   double beta2, double eps, double weight_decay, double grad_clip, int step,
+                                   double grad_scale, int zero_grad, cic_stream_t s) {
     CIC_REQUIRE(p && g && m && v && n > 0 && step >= 1 && grad_clip > 0.0);
     CIC_REQUIRE(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                   reinterpret_cast<uintptr_t>(v)) & 15) == 0);
     const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
     const float step_size = (float)(lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
-    hipLaunchKernelGGL(clamp_adam_kernel, dim3(cic_cdiv((n + 3) / 4, 256)), dim3(256), 0, cic_s(s), p, g, m, v, n,
-                       (float)grad_clip, (float)weight_decay, (float)beta1, (float)beta2, (float)eps, step_size, bc2_sqrt,
-                       (float)grad_scale);
+    if (zero_grad)
+        hipLaunchKernelGGL(clamp_adam_kernel<true>, dim3(cic_cdiv((n + 3) / 4, 256)), dim3(256), 0, cic_s(s), p, g, m, v, n,
+                           (float)grad_clip, (float)weight_decay, (float)beta1, (float)beta2, (float)eps, step_size, bc2_sqrt,
+                           (float)grad_scale);
+    else
+        hipLaunchKernelGGL(clamp_adam_kernel<false>, dim3(cic_cdiv((n + 3) / 4, 256)), dim3(256), 0, cic_s(s), p, g, m, v, n,
+                           (float)grad_clip, (float)weight_decay, (float)beta1, (float)beta2, (float)eps, step_size, bc2_sqrt,
+                           (float)grad_scale);
     CIC_LAUNCH_CHECK();
     return 0;
 }

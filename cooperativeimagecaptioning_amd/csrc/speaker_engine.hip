@@ -8,6 +8,7 @@
 
 namespace {
 
+CIC_SWITCH(g_early_stop, 1);         // development build: cic_debug_early_stop(0) = every step of a decode runs in full (A/B)
 CIC_SWITCH(g_gates_att_fused, 1);   // development build: cic_debug_gates_att_fused(0) = separate h2att launch (A/B timing)
 
 __global__ void fill_i32_kernel(int32_t* p, int n, int32_t v) {
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(256) void decode_init_kernel(DecodeInit a, DecodeIn
 
 #ifdef CIC_DEVTOOLS
 extern "C" int cic_debug_gates_att_fused(int on) { g_gates_att_fused = on; return 0; }
+extern "C" int cic_debug_early_stop(int on) { g_early_stop = on; return 0; }
 #endif
 
 int cic_fill_i32(int32_t* p, int n, int32_t v, hipStream_t st) {
@@ -265,6 +267,8 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     // decode (8 us) instead of once per weight tile and workgroup inside the walker (cic_gemm_args.B_parts; bit-identical)
     const bool presplit_logit = !teacher_batched && !ps && H == 512 && V1 >= 2048 && ((size_t)V1 * H) % 4 == 0;   // the walker's shapes
     if (presplit_logit) RUN(cic_split_bf16x3(p->logit_w, (int64_t)V1 * H, w[0].logit_parts, s));
+    bool early_stop = g_early_stop && !fc && !ps && !teacher_batched;
+    for (int q = 0; q < nb; ++q) early_stop = early_stop && !io[q]->first_token;
     for (int t = 0; t < T; ++t) {
         const Dual<float> x = SLAB(x_all, B * E), att_h = SLAB(att_h_all, B * A), att_res = SLAB(att_res_all, B * H),
                           pre = SLAB(pre_all, B * 5 * H), out = SLAB(out_all, B * H), logp = SLAB(logp_all, B * V1);
@@ -278,6 +282,14 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         // dropout is on or off for the whole model (same p_drop); a decode without masks passes NULL
         CIC_REQUIRE(nb == 1 || ((io[0]->x_keep != nullptr) == (io[1]->x_keep != nullptr) &&
                                 (io[0]->out_keep != nullptr) == (io[1]->out_keep != nullptr)));
+        // Early stop (AttModel.py:401-408: the reference leaves the loop once every caption has ended).  No host sync here:
+        // the sampler of step t-1 left "some caption is still open" in any_unf[t]; the heavy kernels of step t read it and
+        // return at once when it is 0 for every decode of the launch.  Their outputs then keep what an earlier call left
+        // (finite: the workspace is zero-filled when it is allocated); everything past a decode's length L is masked
+        // downstream, and the sampler still runs and keeps tokens / flags / L exact.  Decodes that feed given tokens
+        // (teacher forcing) run all their steps.
+        Dual<const int32_t> live{nullptr, nullptr};
+        if (early_stop && t >= 1) live = Dual<const int32_t>{w[0].any_unf + t, nb == 2 ? w[1].any_unf + t : nullptr};
         if (ps && t >= 1) {
             // xt = relu_dropout(soft_vec @ embed.weight)                   (:395-397), soft_vec un-masked
             float* xp = io[0]->xpre + (size_t)t * B * E;
@@ -302,6 +314,7 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
             g.n_split = 5 * H; g.B2_tail = p->h2att_w; g.ldb2_tail = H; g.bias_tail = p->h2att_b;
             g.C_tail = att_h.a; g.C_tail_b = att_h.b; g.ldc_tail = A;
             if (nb == 2) { g.rows_blk = B; g.A_b = x.b; g.A2_b = h.b; g.C_b = pre.b; }
+            g.live = live.a; g.live_b = live.b;
             if (g_gates_att_fused && cic_gemm_split_ok(&g)) {
                 RUN(cic_gemm_f32(&g, st));
                 gates_done = true;
@@ -322,7 +335,7 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
                                         Dual<const float>{w[0].att, w[1].att}, p->alpha_w, p->alpha_b, io[0]->att_masks, att_res,
                                         SLAB(alpha_all, B * K), SLAB(dot_all, B * K), B, nb, K, A, H, st, 1,
                                         Dual<const uint16_t>{bf ? w[0].p_att_bf : nullptr, bf ? w[1].p_att_bf : nullptr},
-                                        Dual<const uint16_t>{bf ? w[0].att_bf : nullptr, bf ? w[1].att_bf : nullptr}));
+                                        Dual<const uint16_t>{bf ? w[0].att_bf : nullptr, bf ? w[1].att_bf : nullptr}, live));
             if (rc) return rc;
         }
         // all_input_sums = i2h(xt) + h2h(h);  in_transform += a2c(att_res)   (:514,521-522)
@@ -336,7 +349,7 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         if (!fc && cic_a2c_cell_fused_ok(H)) {
             // a2c product + cell in one launch (flagship width)
             RUN(cic_a2c_cell_fused(Dual<const float>{att_res.a, att_res.b}, p->a2c_w, p->a2c_b, pre, c, ok, ok.a ? p_drop : 0.f,
-                                   h_new, c_new, out, B, nb, H, st));
+                                   h_new, c_new, out, B, nb, H, st, live));
         } else {
             if (!fc) {
                 cic_gemm_args g = {};
@@ -358,6 +371,7 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         lg.C = logp.a; lg.ldc = V1; lg.bias = p->logit_b;
         if (presplit_logit) lg.B_parts = w[0].logit_parts;
         if (nb == 2) { lg.rows_blk = B; lg.A_b = out.b; lg.C_b = logp.b; }
+        lg.live = live.a; lg.live_b = live.b;
         cic_logit_epilogue epi = {};
         int np = 0;
         if (!ps) {

@@ -181,8 +181,9 @@ __global__ __launch_bounds__(1024) void attn_fwd_cols_kernel(Dual<const float> a
                                                              Dual<const ST> att_d, const float* __restrict__ w_alpha,
                                                              const float* __restrict__ b_alpha, const float* __restrict__ masks,
                                                              Dual<float> att_res_d, Dual<float> alpha_d, Dual<float> dot_d, int B0,
-                                                             int K, int H, int att_div) {
+                                                             int K, int H, int att_div, Dual<const int32_t> live) {
     __shared__ float sp[16 * 64];
+    if (live.a && *live.a == 0 && (!live.b || *live.b == 0)) return;   // every caption has ended (AttModel.py:401-408)
     unsigned long long* stamps = CIC_STAMP_BUF(g_attn_stamps);
     unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     if (stamps) s0 = __builtin_amdgcn_s_memrealtime();
@@ -334,9 +335,10 @@ __global__ __launch_bounds__(KS * 64) void a2c_cell_fused_kernel(Dual<const floa
                                                              const float* __restrict__ ba, Dual<float> pre_d,
                                                              Dual<const float> c_prev_d, Dual<const uint8_t> keep_d, float scale,
                                                              Dual<float> h_new_d, Dual<float> c_new_d, Dual<float> out_d,
-                                                             int B0, int nb, int H) {
+                                                             int B0, int nb, int H, Dual<const int32_t> live) {
     static_assert(KS == 8, "8 accumulator registers (2 row tiles x 4) dealt one per wave");
     __shared__ float red[2 * KS * 8 * 64];
+    if (live.a && *live.a == 0 && (!live.b || *live.b == 0)) return;   // every caption has ended (AttModel.py:401-408)
     const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int tiles_j = H / 16;
@@ -1105,7 +1107,7 @@ bool cic_attn_pair_ok(int K, int A, int H) { return A == H && (H & 63) == 0 && H
 int cic_attn_fwd2(Dual<const float> att_h_d, Dual<const float> p_att_d, Dual<const float> att_d, const float* w_alpha,
                   const float* b_alpha, const float* masks, Dual<float> att_res_d, Dual<float> alpha_d, Dual<float> dot_d,
                   int B, int nb, int K, int A, int H, hipStream_t st, int att_div, Dual<const uint16_t> p_att_bf,
-                  Dual<const uint16_t> att_bf) {
+                  Dual<const uint16_t> att_bf, Dual<const int32_t> live) {
     CIC_REQUIRE(att_div >= 1);
     const bool bf = p_att_bf.a != nullptr;
     CIC_REQUIRE(!bf || (att_bf.a && cic_attn_pair_ok(K, A, H) && (nb == 1 || (p_att_bf.b && att_bf.b))));
@@ -1124,7 +1126,7 @@ int cic_attn_fwd2(Dual<const float> att_h_d, Dual<const float> p_att_d, Dual<con
         dim3 blk((H / 32 / ncg) * 64);
         if (bf) {      // bf16 storage of the region features (compute_dtype bf16): half the bytes per image
 #define GOB(J) hipLaunchKernelGGL((attn_fwd_cols_kernel<J, 1, uint16_t>), grid, blk, 0, st, att_h_d, p_att_bf, att_bf, w_alpha, \
-                                  b_alpha, masks, att_res_d, alpha_d, dot_d, B, K, H, att_div)
+                                  b_alpha, masks, att_res_d, alpha_d, dot_d, B, K, H, att_div, live)
             if (K <= 8) GOB(1); else if (K <= 16) GOB(2); else if (K <= 24) GOB(3); else if (K <= 32) GOB(4);
             else if (K <= 40) GOB(5); else if (K <= 48) GOB(6); else GOB(8);
 #undef GOB
@@ -1134,9 +1136,9 @@ int cic_attn_fwd2(Dual<const float> att_h_d, Dual<const float> p_att_d, Dual<con
 #define GOC(J)                                                                                                       \
     do {                                                                                                             \
         if (ncg == 2) hipLaunchKernelGGL((attn_fwd_cols_kernel<J, 2>), grid, blk, 0, st, att_h_d, p_att_d, att_d, w_alpha, \
-                                         b_alpha, masks, att_res_d, alpha_d, dot_d, B, K, H, att_div);               \
+                                         b_alpha, masks, att_res_d, alpha_d, dot_d, B, K, H, att_div, live);               \
         else hipLaunchKernelGGL((attn_fwd_cols_kernel<J, 1>), grid, blk, 0, st, att_h_d, p_att_d, att_d, w_alpha,     \
-                                b_alpha, masks, att_res_d, alpha_d, dot_d, B, K, H, att_div);                        \
+                                b_alpha, masks, att_res_d, alpha_d, dot_d, B, K, H, att_div, live);                        \
     } while (0)
         if (K <= 8) GOC(1); else if (K <= 16) GOC(2); else if (K <= 24) GOC(3); else if (K <= 32) GOC(4);
         else if (K <= 40) GOC(5); else if (K <= 48) GOC(6); else GOC(8);
@@ -1240,12 +1242,12 @@ bool cic_a2c_cell_fused_ok(int H) { return g_a2c_cell_fused && H == 512; }
 
 int cic_a2c_cell_fused(Dual<const float> att_res, const float* Wa, const float* ba, Dual<float> pre, Dual<const float> c_prev,
                        Dual<const uint8_t> keep, float p_drop, Dual<float> h_new, Dual<float> c_new, Dual<float> out, int B,
-                       int nb, int H, hipStream_t st) {
+                       int nb, int H, hipStream_t st, Dual<const int32_t> live) {
     CIC_REQUIRE(cic_a2c_cell_fused_ok(H) && att_res.a && Wa && ba && pre.a && c_prev.a && h_new.a && c_new.a && out.a && B > 0);
     CIC_REQUIRE(nb == 1 || (nb == 2 && att_res.b && pre.b && c_prev.b && h_new.b && c_new.b && out.b));
     const int grid = nb * cic_cdiv(B, 32) * (H / 16);
     hipLaunchKernelGGL((a2c_cell_fused_kernel<4, 8>), dim3(grid), dim3(512), 0, st, att_res, Wa, ba, pre, c_prev, keep,
-                       1.0f / (1.0f - p_drop), h_new, c_new, out, B, nb, H);
+                       1.0f / (1.0f - p_drop), h_new, c_new, out, B, nb, H, live);
     CIC_LAUNCH_CHECK();
     return 0;
 }

@@ -46,8 +46,13 @@ lib.cic_masked_nll.argtypes = [P, P, C.c_int, C.c_float, C.c_int, C.c_int, P, P,
 lib.cic_masked_nll.restype = C.c_int
 lib.cic_clamp_adam.argtypes = [P, P, P, P, C.c_int64] + [C.c_double] * 6 + [C.c_int, C.c_double, P]
 lib.cic_clamp_adam.restype = C.c_int
+lib.cic_clamp_adam_zero.argtypes = [P, P, P, P, C.c_int64] + [C.c_double] * 6 + [C.c_int, C.c_double, C.c_int, P]
+lib.cic_clamp_adam_zero.restype = C.c_int
 
 ONLY_ONE = {'off': 0, 'image': 1, 'caption': 2}
+# several processes computing on ONE GPU (the multi-rank rehearsals on a one-GPU box: bench.py / train.py / tools with
+# --same-device; CIC_SHARED_DEVICE=1): launches that need all their workgroups resident together are not used then
+DEVICE_SHARED = [__import__('os').environ.get('CIC_SHARED_DEVICE', '0') == '1']
 
 
 def _p(t):
@@ -124,7 +129,9 @@ def speaker_decode_io(dims, params, att_pre, mode, temp=1.0, att_masks=None, att
     B, T = dims.B, dims.T
     nbytes = lib.cic_speaker_decode_ws_bytes(C.byref(dims))
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        # zero-filled ONCE: a decode that stops early (every caption ended) leaves the slabs of its remaining steps as
+        # they were, and the backward pass multiplies them by zero gradients - they have to be finite
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
     if out is None:
         out = dict(seq=torch.zeros(B, T, dtype=torch.int32, device=dev), slp=torch.zeros(B, T, device=dev),
                    stv=torch.ones(B, T, device=dev) if want_stv else None,
@@ -162,7 +169,7 @@ def speaker_decode_bwd(dims, params, fwd, grads, att_raw, d_onehot=None, dslp=No
     the parameters).  fwd: the dict returned by speaker_decode_fwd."""
     nbytes = lib.cic_speaker_decode_bwd_ws_bytes(C.byref(dims))
     if ws_bwd is None or ws_bwd.numel() < nbytes:
-        ws_bwd = torch.empty(nbytes, dtype=torch.uint8, device=fwd['ws'].device)
+        ws_bwd = torch.zeros(nbytes, dtype=torch.uint8, device=fwd['ws'].device)
     bio = DecodeBwdIO()
     gp = grad_params if grad_params is not None else speaker_params(grads)
     bio.d_onehot, bio.dslp, bio.att_raw, bio.d_x0 = _p(d_onehot), _p(dslp), _p(att_raw), _p(d_x0)
@@ -234,6 +241,7 @@ def listener_fwd(dims, params, fc_feats, labels=None, masks=None, seq=None, stv=
     io.only_one_retrieval = ONLY_ONE[only_one_retrieval]
     io.loss_rows, io.loss_sum = _p(out['loss_rows']), _p(out['loss_sum'])
     io.img_emb_out, io.cap_emb_out = _p(out['img_emb']), _p(out['cap_emb'])
+    io.device_shared = 1 if DEVICE_SHARED[0] else 0
     check(lib.cic_listener_fwd(C.byref(dims), C.byref(params), C.byref(io), ws.data_ptr(), ws.numel(), stream()),
           'cic_listener_fwd')
     out['io'] = io
@@ -332,9 +340,10 @@ def masked_nll(slp, mask, weight, dslp=None, loss_out=None):
     return loss_out
 
 
-def clamp_adam(p, g, m, v, lr, step, grad_clip=0.1, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
-    check(lib.cic_clamp_adam(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay,
-                             grad_clip, int(step), grad_scale, stream()), 'cic_clamp_adam')
+def clamp_adam(p, g, m, v, lr, step, grad_clip=0.1, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0,
+               zero_grad=False):
+    check(lib.cic_clamp_adam_zero(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay,
+                                  grad_clip, int(step), grad_scale, 1 if zero_grad else 0, stream()), 'cic_clamp_adam_zero')
 
 
 TIMED_IDS = {'attn_fwd': 0, 'logit_gemm': 1, 'attn_bwd': 2, 'sampler': 3}

@@ -40,6 +40,11 @@ class FlatAdam:
         # (the gradient of a bucket is final only after the LAST micro-batch's backward); step() exchanges whatever has
         # not left.  See accumulate_gradients().
         self.defer_exchange = False
+        # True: step() clears the gradient buffer inside the clamp+Adam kernel (each element is in registers there) and the
+        # zero_grad() that opens the next step finds nothing to do.  Gradients are then NOT readable after step() - the
+        # trainer and the benchmark never do; off by default, as torch.optim keeps .grad until zero_grad().
+        self.zero_grad_in_step = False
+        self._grad_is_zero = False
 
     @property
     def flat(self):
@@ -62,6 +67,11 @@ class FlatAdam:
         # extra backward): it must land before the buffer is cleared, and must not be mistaken for the next step's
         self._drain()
         self._done.clear()
+        if self._grad_is_zero and self.flat.attached():
+            self._grad_is_zero = False      # cleared by the last step(); whatever runs next writes into it again
+            self.flat.ensure()
+            return
+        self._grad_is_zero = False
         self.flat.zero_grad()
 
     def set_grad_clip(self, grad_clip):
@@ -121,7 +131,8 @@ class FlatAdam:
         fl.step += 1
         clip = self._grad_clip if self._grad_clip is not None else 3.0e38
         engine.clamp_adam(fl.flat, fl.grad, fl.exp_avg, fl.exp_avg_sq, g['lr'], fl.step, clip, g['betas'], g['eps'],
-                          g['weight_decay'], scale)
+                          g['weight_decay'], scale, zero_grad=self.zero_grad_in_step)
+        self._grad_is_zero = bool(self.zero_grad_in_step)
 
     # torch-compatible checkpoints: per-parameter state in parameter order
     def state_dict(self):
@@ -238,6 +249,14 @@ def save_optimizer(opt, optimizer_dict):
                 _save(o, agent + '_optimizer.pth')
     else:
         _save(optimizer_dict['optimizer'], 'optimizer.pth')
+
+
+def fuse_zero_grad(optimizer_dict, on=True):
+    """Let every FlatAdam clear its gradient buffer inside its clamp+Adam kernel (see FlatAdam.zero_grad_in_step)."""
+    for v in optimizer_dict.values():
+        for o in (v.values() if isinstance(v, dict) else [v]):
+            if isinstance(o, FlatAdam):
+                o.zero_grad_in_step = bool(on)
 
 
 def accumulate_gradients(optimizer_dict, more_to_come):

@@ -169,7 +169,11 @@ def operations_in_checkpoint(opt, model, loader, iteration, epoch, best, optimiz
     ev = eval_loader if eval_loader is not None else getattr(loader, 'loader', loader)
     flags = (False, False)
     if ev is not None and getattr(opt, 'eval_at_checkpoint', 1) and hasattr(ev, 'reset_iterator'):
+        # the evaluation draws from the speaker's noise stream (sampled captions of the loss forward): the TRAINING stream
+        # continues where it was, so a run's weights do not depend on how often it was evaluated (and a resume is exact)
+        noise_at = model.caption_generator.noise.counter
         val_result_history, lang_stats, val_loss = evaluate_model(opt, model, ev, iteration, val_result_history)
+        model.caption_generator.noise.counter = noise_at
         score, score_vse = get_current_score(opt, lang_stats, val_loss)
         best['score'], f1, best['score_vse'], f2 = check_if_best(score, best.get('score'), score_vse, best.get('score_vse'))
         flags = (f1, f2)
@@ -294,6 +298,8 @@ def train(opt, loader=None):
         backend = os.environ.get('CIC_DIST_BACKEND', 'nccl')
         if os.environ.get('CIC_SAME_DEVICE') == '1':
             assert backend == 'gloo', 'CIC_SAME_DEVICE is a gloo rehearsal (RCCL wants one GPU per rank)'
+            from . import engine as _engine
+            _engine.DEVICE_SHARED[0] = True           # several ranks compute on one GPU
             local_rank = 0
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend)
@@ -330,6 +336,8 @@ def train(opt, loader=None):
         if infos.get('noise'):
             cg.noise.counter = int(infos['noise']['counter'])   # every rank keeps its own seed and continues its stream
     optimizer_dict = load_optimizer(model, opt)
+    from .optimizer import fuse_zero_grad
+    fuse_zero_grad(optimizer_dict)                            # gradients are cleared inside the clamp+Adam kernels
     if infos.get('current_lr') is not None:
         opt.current_lr = infos['current_lr']
         for o in _all_optimizers(optimizer_dict):
@@ -350,11 +358,9 @@ def train(opt, loader=None):
     num_turns = len(opt.alternating_turn) if opt.is_alternating else 1
     init_scorer(opt.cached_tokens)
     log = LossLog(device)
-    want_history = set()
 
     def emit(meta, train_loss, terms):
-        if meta['iteration'] + 1 in want_history:                                  # write_loss_summary, train.py:229-235
-            want_history.discard(meta['iteration'] + 1)
+        if meta['to_history']:                                                     # write_loss_summary, train.py:229-235
             loss_history[meta['iteration'] + 1] = train_loss
         if rank == 0:
             extra = ' '.join(f'{k} = {v:.3f}' for k, v in terms.items())
@@ -382,7 +388,10 @@ def train(opt, loader=None):
         end = time.time()
         # the loss and the logged terms follow asynchronously; the line of iteration i is printed once they have landed
         # (while step i+1 is being enqueued): steady-state time per iteration = what the device needs, as in bench.py
-        log.push(dict(iteration=iteration, epoch=epoch, turn=curr_turn, host_s=end - last_end), loss, model.loss())
+        start_ckpt = bool(getattr(opt, 'start_with_checkpoint', 0))
+        to_history = (iteration + 1) % opt.losses_log_every == 0 or start_ckpt     # train.py:540-543
+        log.push(dict(iteration=iteration, epoch=epoch, turn=curr_turn, host_s=end - last_end, to_history=to_history),
+                 loss, model.loss())
         last_end = end
         log.pop(emit)
         if rank == 0 and not reported_path and hasattr(model, 'caption_generator'):
@@ -394,9 +403,7 @@ def train(opt, loader=None):
         if data['bounds']['wrapped']:
             epoch += 1
             update_lr_flag = True
-        start_ckpt = bool(getattr(opt, 'start_with_checkpoint', 0))
-        if iteration % opt.losses_log_every == 0 or start_ckpt:                    # train.py:540-543
-            want_history.add(iteration)
+        if to_history:
             lr_history[iteration] = float(getattr(opt, 'current_lr', opt.learning_rate))
             ss_prob_history[iteration] = float(model.caption_generator.ss_prob)
         done = (epoch >= opt.max_epochs != -1) or (0 < opt.max_iterations <= iteration)

@@ -124,6 +124,13 @@ typedef struct {
      * that many launches read unchanged (the logit weights: T launches per decode).  Used by the logit walker only; the
      * results are those of the launch without it, bit for bit.  NULL elsewhere. */
     const uint16_t* B_parts;
+    /* Optional: device flags of a decode loop, "some caption of the decode (pair) is still being written"
+     * (AttModel.py:401-408: the reference breaks out of the loop once every caption has ended).  When live is not NULL and
+     * *live == 0 (and live_b is NULL or *live_b == 0) the launch returns at once and leaves C untouched.  Honoured by the
+     * per-timestep kernels of the decode engines' flagship shapes; other kernels compute as if it were NULL (the
+     * engines mask everything past a decode's length anyway). */
+    const int32_t* live;
+    const int32_t* live_b;
 } cic_gemm_args;
 enum { CIC_PRECISION_F32 = 0, CIC_PRECISION_F32_MFMA = 1, CIC_PRECISION_BF16 = 2 };
 /* Row partials of the vocabulary: the columns of a row are dealt to `nparts` parts; a part reduces its columns
@@ -327,7 +334,10 @@ typedef struct {
 } cic_decode_io;
 
 /* Bytes of workspace a decode needs; the same workspace must be handed, untouched, to
- * cic_speaker_decode_bwd. */
+ * cic_speaker_decode_bwd.  Zero-fill a workspace ONCE when it is allocated (it may then be reused call after call): a
+ * sampling decode whose captions have all ended (AttModel.py:401-408) returns from the heavy kernels of its remaining
+ * steps at once and leaves their slabs as they were; the backward pass multiplies those by zero gradients, so they must
+ * hold finite values.  Everything a caller can observe - tokens, log-probs, L, gradients - is that of the full loop. */
 size_t cic_speaker_decode_ws_bytes(const cic_speaker_dims* d);
 /* AttModel.sample (beam_size 1), models/AttModel.py:291-452: T core steps + samplers, no host
  * sync (the reference's early break is replaced by the device-side length L). */
@@ -423,6 +433,11 @@ typedef struct {
     float* loss_sum;          /* out [1]: scalar loss (whole_batch=False) */
     float* img_emb_out;       /* out [B, J] or NULL */
     float* cap_emb_out;       /* out [B, J] or NULL */
+    int device_shared;        /* != 0: other processes run kernels on this device at the same time.  The GRU pass is then
+                                 launched step by step; 0 lets it run as ONE launch whose workgroups hand the hidden state
+                                 to each other inside the launch, which needs all of them resident together (a second
+                                 process's kernels could hold the CUs some of them wait for: the pass would then give up
+                                 after its time budget and mark its outputs NaN rather than hang) */
 } cic_listener_io;
 
 typedef struct {
@@ -474,6 +489,11 @@ int cic_loss_combine(const float* const* term, const float* weight, int count, f
 int cic_clamp_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
                    double beta2, double eps, double weight_decay, double grad_clip, int step,
                    double grad_scale, cic_stream_t s);
+/* The same update that also CLEARS the gradient buffer while each element is in registers (zero_grad != 0): the next
+ * step's zeroing_optimizer (optimizer.py:224-230) then has nothing left to do.  zero_grad == 0: cic_clamp_adam. */
+int cic_clamp_adam_zero(float* p, float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                        double eps, double weight_decay, double grad_clip, int step, double grad_scale, int zero_grad,
+                        cic_stream_t s);
 
 /* ---- self-critical CIDEr-D reward: misc/rewards.py:26-72, ciderD_scorer.py:13-215 ---------- */
 typedef struct {

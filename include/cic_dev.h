@@ -31,7 +31,10 @@ int cic_debug_set_attn_stamps(unsigned long long* buf);
 int cic_debug_gemm_tail_split(int on);
 /* diagnostics: 0 = the decode engines launch the attention query product on its own (A/B timing of the column split) */
 int cic_debug_gates_att_fused(int on);
-/* diagnostics: 0 runs every listener GRU step as a GEMM launch + a cell launch instead of the fused step kernel */
+/* diagnostics: 0 = the decode engines run every step in full even after every caption has ended (A/B of the early stop) */
+int cic_debug_early_stop(int on);
+/* diagnostics: 2 (default) the whole GRU pass in one launch where the grid fits the chip, 1 one fused launch per step,
+ * 0 every listener GRU step as a GEMM launch + a cell launch */
 int cic_debug_gru_fused(int on);
 /* diagnostics: 0 runs the speaker's a2c product and cell as two launches instead of the fused kernel */
 int cic_debug_a2c_cell_fused(int on);

@@ -1,0 +1,37 @@
+"""GPU: the two in-launch / no-host-sync control structures of this round, each checked against the plain form it replaces
+(the development build flips between them; tools/ print a JSON line and exit non-zero on a mismatch):
+  * gru_seq_kernel - the listener's whole GRU pass as ONE launch with W_hh stationary in registers and per-strip
+    hand-offs of the hidden state inside the launch - must reproduce the one-launch-per-step kernel BIT FOR BIT, also with
+    another stream saturating the chip while it runs (tools/gru_seq_check.py);
+  * the device-side early stop of the decode loops (AttModel.py:401-408) must leave tokens, lengths, loss and gradients
+    of a full-width joint step exactly as the full loops give them (tools/early_stop_check.py)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(tool, *args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', tool)] + list(args), cwd=ROOT, capture_output=True, text=True,
+                       timeout=560)
+    assert r.returncode == 0, r.stdout[-2000:] + '\n' + r.stderr[-3000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+
+
+@pytest.mark.timeout(600)
+def test_one_launch_gru_pass_equals_the_per_step_kernel_bit_for_bit():
+    doc = _run('gru_seq_check.py', '--iters', '20')
+    assert doc['gru_seq_check'] == 'ok' and doc['uneven_load']['mismatches'] == 0
+    for mode in ('generated', 'labels'):
+        assert all(doc[mode]['outputs_bit_equal'].values()) and doc[mode]['finite']
+
+
+@pytest.mark.timeout(600)
+def test_early_stop_of_the_decode_loops_changes_nothing_observable():
+    doc = _run('early_stop_check.py', '--iters', '5')
+    assert doc['early_stop_check'] == 'ok' and max(doc['L_sampled'], doc['L_greedy']) < 16

@@ -141,3 +141,21 @@ def test_clamp_adam_golden():
         g = torch.cat([T_(z['grads'][i]).view(-1), torch.zeros(pad)]).cuda()
         engine.clamp_adam(p, g, m, v, float(z['lr']), i + 1, float(z['grad_clip']))
         np.testing.assert_allclose(p[:n].cpu().numpy(), z['traj'][i].reshape(-1), rtol=2e-6, atol=2e-7)
+
+
+def test_clamp_adam_clears_the_gradient_on_request():
+    """cic_clamp_adam_zero: the update of cic_clamp_adam bit for bit, and the gradient buffer left at zero (the next
+    step's zero_grad() folded into the kernel); odd length = the scalar tail path."""
+    from cooperativeimagecaptioning_amd import engine
+    g0 = torch.randn(4099, generator=torch.Generator().manual_seed(2)).cuda()
+    outs = []
+    for zero in (False, True):
+        p = torch.linspace(-1, 1, 4099).cuda()
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        for step in (1, 2):
+            g = (g0 * step).clone()
+            engine.clamp_adam(p, g, m, v, 5e-4, step, 0.1, zero_grad=zero)
+            assert bool((g == 0).all()) == zero
+        outs.append((p.clone(), m.clone(), v.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -43,6 +43,8 @@ def main():
     local_rank = 0 if args.same_device else int(os.environ.get('LOCAL_RANK', '0'))
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     assert not args.same_device or args.backend == 'gloo', '--same-device is a gloo rehearsal (RCCL wants one GPU per rank)'
+    if args.same_device:
+        os.environ['CIC_SHARED_DEVICE'] = '1'         # several ranks compute on one GPU: no launches that need the whole chip
     torch.cuda.set_device(local_rank)
     dist.init_process_group(args.backend)
     dev = torch.device('cuda', local_rank)
