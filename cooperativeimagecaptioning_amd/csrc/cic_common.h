@@ -277,3 +277,66 @@ __device__ __forceinline__ void rowpart_merge(RowPart& p, int mode, float inv_t,
     p.xbest = better ? q.xbest : p.xbest;
     p.kidx = better ? q.kidx : p.kidx;
 }
+
+// What the sampler does with a row once its partials are merged (models/AttModel.py:328-365,401-434; gumbel.py:13-30;
+// multinomial.py:4-27): token choice, gathered log-prob, straight-through value - used by sample_finish_kernel and by the
+// gate walker that takes the previous step's sampler into its prologue (cic_finish_fold).  Returns the token the NEXT core
+// step embeds (un-masked, :399); `it`/`slp`/`v` are what the bookkeeping stores.
+struct RowChoice { int it, tok; float slp, v, lse; };
+__device__ __forceinline__ RowChoice row_choice(const cic_sampler_args& a, const RowPart& rp, int b) {
+    RowChoice c;
+    const float inv_t = 1.0f / a.temp;
+    c.lse = rp.m1 + logf(rp.s1);
+    const bool gumbel_mode = a.mode == CIC_SAMPLE_GUMBEL_ST;
+    const bool ss_on = a.mode == CIC_SAMPLE_TEACHER && a.ss_u && a.ss_prob > 0.f;
+    int it = rp.kidx;
+    int it_feed = -1;                                   // teacher mode: token fed to the next step
+    if (a.mode == CIC_SAMPLE_TEACHER) {
+        const int target = (int)a.pick[b];
+        const int drawn = a.ss_pick ? (int)a.ss_pick[b] : rp.kidx;
+        it_feed = (ss_on && a.ss_u[b] < a.ss_prob) ? drawn : target;   // AttModel.py:119-128
+        it = target;                                     // the loss gathers log p(target)
+    } else if (a.pick && a.mode != CIC_SAMPLE_GREEDY && !gumbel_mode) {
+        it = (int)a.pick[b];
+    }
+    float x_it = rp.xbest;
+    if (it != rp.kidx) {
+        const int cons = (a.decoding_constraint && a.step >= 2) ? a.seq[(size_t)b * a.seq_ld + (a.step - 2)] : -1;
+        x_it = it == cons ? -INFINITY : a.logits[(size_t)b * a.ld + it];
+    }
+    c.slp = x_it - c.lse;
+    float v = 1.0f;
+    if (gumbel_mode) {
+        const float y = 1.0f / rp.s2;                   // softmax(k)[arg max k] = exp(0) / sum exp(k - kbest), gumbel.py:13-15
+        v = (1.0f - y) + y;                              // (y_hard - y).detach() + y at the arg-max entry, gumbel.py:28
+    } else if (a.mode == CIC_SAMPLE_MULTINOMIAL_ST) {
+        const float y = __expf((x_it - rp.m1) * inv_t) / rp.s2;         // softmax(logp / tau)[it], multinomial.py:10-15
+        v = (1.0f - y) + y;
+    }
+    c.v = v;
+    c.it = it;
+    c.tok = it_feed >= 0 ? it_feed : it;
+    return c;
+}
+// EOS bookkeeping of one row (AttModel.py:401-434), by ONE lane
+__device__ __forceinline__ void row_bookkeeping(const cic_sampler_args& a, const RowChoice& c, int b) {
+    const int t = a.step;
+    int unf = (c.it > 0) ? 1 : 0;
+    if (t > 1) unf = unf & a.unfinished[b];
+    a.unfinished[b] = unf;
+    a.it_next[b] = c.tok;                                     // un-masked: embed(it) precedes the masking (:399)
+    a.seq[(size_t)b * a.seq_ld + (t - 1)] = unf ? c.it : 0;   // it * unfinished (:409)
+    a.slp[(size_t)b * a.seq_ld + (t - 1)] = c.slp;
+    if (a.stv) a.stv[(size_t)b * a.seq_ld + (t - 1)] = unf ? c.v : 1.0f;   // finished rows -> exact EOS one-hot (:419-420)
+    if (unf) atomicOr(a.any_unfinished + t, 1);
+}
+// xt = dropout(relu(embed(tok))) (AttModel.py:74-76,399) for four consecutive columns; kp: their four keep bytes
+__device__ __forceinline__ f32x4 embed_transform(const cic_sampler_args& a, f32x4 ev, uint32_t kp) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float kf = (float)((kp >> (8 * e)) & 0xffu);
+        const float r = a.emb_plain ? ev[e] : fmaxf(ev[e], 0.f);
+        ev[e] = a.emb_keep ? r * (kf * a.emb_scale) : r;
+    }
+    return ev;
+}

@@ -78,6 +78,8 @@ int cic_soft_mask(const float* soft_raw, const int32_t* seq, const int32_t* L, f
 struct GemmCtx {
     hipStream_t st;
     int precision;
+    const int32_t* live = nullptr;      // cic_gemm_args.live / live_min of the products launched through this context
+    int live_min = 0;
     GemmCtx(hipStream_t s, int p = CIC_PRECISION_F32) : st(s), precision(p) {}
     operator hipStream_t() const { return st; }
 };
@@ -116,6 +118,7 @@ static inline int gemm_nn(const float* A, int lda, const float* Bm, int ldb, flo
     g.B = Bm; g.ldb = ldb; g.b_kc = 0;
     g.C = C; g.ldc = ldc; g.accumulate = accumulate; g.sum_order_free = order_free; g.c_is_zero = c_is_zero;
     g.precision = st.precision;
+    if (c_is_zero) { g.live = st.live; g.live_min = st.live_min; }      // leaving the launch out leaves the zeros
     return cic_gemm_f32(&g, st.st);
 }
 // the same product in a FORWARD pass (soft caption rows @ embedding): fixed summation order
@@ -134,6 +137,7 @@ static inline int gemm_nn2(const float* A1, int lda1, const float* B1, int ldb1,
     g.K2 = K2; g.A2 = A2; g.lda2 = lda2; g.B2 = B2; g.ldb2 = ldb2;
     g.C = C; g.ldc = ldc; g.accumulate = accumulate; g.sum_order_free = 1; g.c_is_zero = c_is_zero;
     g.precision = st.precision;
+    if (c_is_zero) { g.live = st.live; g.live_min = st.live_min; }      // leaving the launch out leaves the zeros
     return cic_gemm_f32(&g, st.st);
 }
 // C[M,N] = At[K,M]^T Bm[K,N] (+C)                 — dW = dY^T X

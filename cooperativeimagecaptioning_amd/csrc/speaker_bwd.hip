@@ -11,6 +11,8 @@
 
 namespace {
 
+CIC_SWITCH(g_bptt_early_stop, 1);   // development build: cic_debug_bptt_early_stop(0) = the products of every BPTT step run (A/B)
+
 
 constexpr int SNW = 16;   // waves per row workgroup of sampler_bwd_kernel
 __device__ __forceinline__ float block_sum4(float v, float* sh) {
@@ -673,6 +675,10 @@ SpkBws spk_bcarve(const cic_speaker_dims& d, void* base, bool own_dlogits) {
 
 }  // namespace
 
+#ifdef CIC_DEVTOOLS
+extern "C" int cic_debug_bptt_early_stop(int on) { g_bptt_early_stop = on; return 0; }
+#endif
+
 extern "C" size_t cic_speaker_decode_bwd_ws_bytes(const cic_speaker_dims* d) {
     if (!d) return 0;
     return spk_bcarve(*d, nullptr, true).bytes;
@@ -765,7 +771,11 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         CIC_LAUNCH_CHECK();
         // d att_res = d in_transform a2c.W            [B,2H] x [2H,H]   (into the slab the cell kernel cleared)
         float* dres = g.d_att_res_all + (size_t)t * B * H;
-        if (!fc) RUN(gemm_nn(dpre + 3 * H, 5 * H, p->a2c_w, H, dres, H, B, H, 2 * H, false, st, true, true));
+        // steps at or beyond the decode's length L carry no gradient (d out = 0, no carry): their two products would add
+        // zeros into the buffers the cell kernel has just cleared, so they return at once (device-side L, no host sync)
+        GemmCtx stl = st;
+        if (!ps && !fc && io->L && g_bptt_early_stop) { stl.live = io->L; stl.live_min = t + 1; }
+        if (!fc) RUN(gemm_nn(dpre + 3 * H, 5 * H, p->a2c_w, H, dres, H, B, H, 2 * H, false, stl, true, true));
         if (!fc) {
             dim3 grid(B), blk(1024);
             const int mx = A > H ? A : H;
@@ -804,7 +814,7 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         } else if (t > 0) {
             // dh_t = dpre h2h.W + d_att_h h2att.W       [B,5H]x[5H,H] + [B,A]x[A,H]
             RUN(gemm_nn2(dpre, 5 * H, p->h2h_w, H, 5 * H, g.d_att_h_all + (size_t)t * B * A, A, p->h2att_w, H, A,
-                         dh_out, H, B, H, false, st, true));
+                         dh_out, H, B, H, false, stl, true));
             float* tmp = dh_in; dh_in = dh_out; dh_out = tmp;
         }
         if (ps) {

@@ -960,65 +960,23 @@ __global__ __launch_bounds__(256) void sample_finish_kernel(FinishArgs a0, Finis
         rowpart_merge(rp, a.mode, inv_t, q);
     }
     rp = wave_merge_rowpart(rp, a.mode, inv_t);
-    const float lse = rp.m1 + logf(rp.s1);
-    if (fa.lse && lane == 0) fa.lse[b] = lse;
-    if (a.mode == CIC_SAMPLE_NONE) return;
-
-    const bool gumbel_mode = a.mode == CIC_SAMPLE_GUMBEL_ST;
-    const bool ss_on = a.mode == CIC_SAMPLE_TEACHER && a.ss_u && a.ss_prob > 0.f;
-    int it = rp.kidx;
-    int it_feed = -1;                                   // teacher mode: token fed to the next step
-    if (a.mode == CIC_SAMPLE_TEACHER) {
-        const int target = (int)a.pick[b];
-        const int drawn = a.ss_pick ? (int)a.ss_pick[b] : rp.kidx;
-        it_feed = (ss_on && a.ss_u[b] < a.ss_prob) ? drawn : target;   // AttModel.py:119-128
-        it = target;                                     // the loss gathers log p(target)
-    } else if (a.pick && a.mode != CIC_SAMPLE_GREEDY && !gumbel_mode) {
-        it = (int)a.pick[b];
+    if (a.mode == CIC_SAMPLE_NONE) {
+        if (fa.lse && lane == 0) fa.lse[b] = rp.m1 + logf(rp.s1);
+        return;
     }
-    float x_it = rp.xbest;
-    if (it != rp.kidx) {
-        const int cons = (a.decoding_constraint && a.step >= 2) ? a.seq[(size_t)b * a.seq_ld + (a.step - 2)] : -1;
-        x_it = it == cons ? -INFINITY : a.logits[(size_t)b * a.ld + it];
-    }
-    const float slp = x_it - lse;
-    float v = 1.0f;
-    if (gumbel_mode) {
-        const float y = 1.0f / rp.s2;                   // softmax(k)[arg max k] = exp(0) / sum exp(k - kbest), gumbel.py:13-15
-        v = (1.0f - y) + y;                              // (y_hard - y).detach() + y at the arg-max entry, gumbel.py:28
-    } else if (a.mode == CIC_SAMPLE_MULTINOMIAL_ST) {
-        const float y = __expf((x_it - rp.m1) * inv_t) / rp.s2;         // softmax(logp / tau)[it], multinomial.py:10-15
-        v = (1.0f - y) + y;
-    }
+    const RowChoice c = row_choice(a, rp, b);
+    if (fa.lse && lane == 0) fa.lse[b] = c.lse;
     // next step's input: xt = dropout(relu(embed(it))) (AttModel.py:74-76,399), un-masked `it`
     if (a.emb_x) {
-        const int tok = it_feed >= 0 ? it_feed : it;
         const int E4 = a.emb_dim >> 2;
         for (int j = lane; j < E4; j += 64) {
-            f32x4 ev = reinterpret_cast<const f32x4*>(a.emb_w + (size_t)tok * a.emb_dim)[j];
+            const f32x4 ev = reinterpret_cast<const f32x4*>(a.emb_w + (size_t)c.tok * a.emb_dim)[j];
             uint32_t kp = 0x01010101u;
             if (a.emb_keep) kp = *reinterpret_cast<const uint32_t*>(a.emb_keep + (size_t)b * a.emb_dim + 4 * j);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float kf = (float)((kp >> (8 * e)) & 0xffu);
-                const float r = a.emb_plain ? ev[e] : fmaxf(ev[e], 0.f);
-                ev[e] = a.emb_keep ? r * (kf * a.emb_scale) : r;
-            }
-            reinterpret_cast<f32x4*>(a.emb_x + (size_t)b * a.emb_dim)[j] = ev;
+            reinterpret_cast<f32x4*>(a.emb_x + (size_t)b * a.emb_dim)[j] = embed_transform(a, ev, kp);
         }
     }
-    // EOS bookkeeping (AttModel.py:401-434)
-    if (lane == 0) {
-        const int t = a.step;
-        int unf = (it > 0) ? 1 : 0;
-        if (t > 1) unf = unf & a.unfinished[b];
-        a.unfinished[b] = unf;
-        a.it_next[b] = it_feed >= 0 ? it_feed : it;         // un-masked: embed(it) precedes the masking (:399)
-        a.seq[(size_t)b * a.seq_ld + (t - 1)] = unf ? it : 0;   // it * unfinished (:409)
-        a.slp[(size_t)b * a.seq_ld + (t - 1)] = slp;
-        if (a.stv) a.stv[(size_t)b * a.seq_ld + (t - 1)] = unf ? v : 1.0f;   // finished rows -> exact EOS one-hot (:419-420)
-        if (unf) atomicOr(a.any_unfinished + t, 1);
-    }
+    if (lane == 0) row_bookkeeping(a, c, b);      // EOS bookkeeping (AttModel.py:401-434)
 }
 
 // ---- teacher forcing without scheduled sampling: the fed tokens are the targets, known before the loop ------------------

@@ -29,6 +29,7 @@ def main():
     args = ap.parse_args()
     lib = _lib.lib
     lib.cic_debug_early_stop.argtypes = [C.c_int]
+    lib.cic_debug_bptt_early_stop.argtypes = [C.c_int]
     dev = torch.device('cuda', 0)
     opt = synthetic.default_opt(batch_size=args.batch)
     rewards.init_scorer('corpus')
@@ -58,6 +59,7 @@ def main():
     res = {}
     for on in (0, 1):
         lib.cic_debug_early_stop(on)
+        lib.cic_debug_bptt_early_stop(on)
         cg.logit.bias.data[0] = bias0
         step(long_batch, 5)                                   # leaves the slabs of a full-length decode in the workspaces
         cg.logit.bias.data[0] = args.bias
@@ -76,6 +78,7 @@ def main():
     times = {}
     for on in (0, 1):
         lib.cic_debug_early_stop(on)
+        lib.cic_debug_bptt_early_stop(on)
         for _ in range(3):
             step(batch, 7)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
