@@ -279,9 +279,8 @@ __device__ __forceinline__ void rowpart_merge(RowPart& p, int mode, float inv_t,
 }
 
 // What the sampler does with a row once its partials are merged (models/AttModel.py:328-365,401-434; gumbel.py:13-30;
-// multinomial.py:4-27): token choice, gathered log-prob, straight-through value - used by sample_finish_kernel and by the
-// gate walker that takes the previous step's sampler into its prologue (cic_finish_fold).  Returns the token the NEXT core
-// step embeds (un-masked, :399); `it`/`slp`/`v` are what the bookkeeping stores.
+// multinomial.py:4-27): token choice, gathered log-prob, straight-through value (sample_finish_kernel).  `tok` is the token
+// the NEXT core step embeds (un-masked, :399); `it`/`slp`/`v` are what the bookkeeping stores.
 struct RowChoice { int it, tok; float slp, v, lse; };
 __device__ __forceinline__ RowChoice row_choice(const cic_sampler_args& a, const RowPart& rp, int b) {
     RowChoice c;

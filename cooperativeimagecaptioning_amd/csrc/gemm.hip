@@ -26,7 +26,6 @@ CIC_SWITCH(g_tail_split, 1);   // bit 0: K-sliced tail tiles and K split over wo
 CIC_SWITCH(g_force_tile, 0);   // bits 8..15: 1 = 128x128, 2 = 64x64 tiles forced
 CIC_SWITCH(g_walk, 1);         // bit 16 set: strip walkers off
 CIC_SWITCH(g_walk16, 1);       // bit 21 set: 16-wide strip walkers off
-CIC_SWITCH(g_fold, 1);       // development build: 0 = the decode engines launch the sampler on its own (A/B of cic_finish_fold)
 CIC_SWITCH(g_ldsb, 1);         // bit 22 set: LDS-staged column walker (K = 512 logit product) off
 CIC_SWITCH(g_ldsb2, 2);        // K parts per row tile of the logit walker: 2 or 4 (bits 25..26 of the debug word: 1 -> 4-wave form, 2 -> 4 parts)
 CIC_SWITCH(g_rega2, 1);        // bit 24 set: two-strip dX kernel (gemm_rega2_kernel) off
@@ -1248,15 +1247,11 @@ __global__ __launch_bounds__(KS * 64) void gemm_walk16_kernel(cic_gemm_args g, i
 // gemm_walk16_kernel<8, 8, false>; K slice per wave = 128 = 4 k-steps of 32 (Kt == 1024, K1 % 32 == 0: no K padding).
 //   operand layout: lane l -> (i = l & 15, q = l >> 4); A: row i, k = 32 j + 8 q + 0..7 for k-step j (two dwordx4);
 //   B: column i likewise; D: 4 registers v: row 4q + v, column i.
-// FOLD: the previous decode step's sampler runs in the prologue (cic_finish_fold, cic.h): the workgroup merges the row
-// partials of its 32 rows (16 lanes per row, four rows per wave), chooses their tokens, and the x half of the A operand
-// (k < K1) is gathered from the embedding table; walker 0 of a strip also does the sampler's bookkeeping and stores x.
-template <int KS, int FOLD>
-__global__ __launch_bounds__(KS * 64) void gemm_walk16bf_kernel(cic_gemm_args g, int strips, cic_finish_fold fold) {
+template <int KS>
+__global__ __launch_bounds__(KS * 64) void gemm_walk16bf_kernel(cic_gemm_args g, int strips) {
     static_assert(KS == 8, "8 accumulator registers (2 row tiles x 4) dealt one per wave");
     constexpr int JS = 4;                                   // k-steps per wave
     __shared__ float red[2 * KS * 8 * 64];
-    __shared__ int tok_s[32];
     const int tid = threadIdx.x, lane = tid & 63, ks = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
     const int li = lane & 15, lq = lane >> 4;
     const int tiles_n = (g.N + 15) / 16;
@@ -1271,53 +1266,7 @@ __global__ __launch_bounds__(KS * 64) void gemm_walk16bf_kernel(cic_gemm_args g,
     if (blk2) m0 -= g.rows_blk;
     const int K1 = g.K;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    const cic_sampler_args& sa = fold.s[blk2 ? 1 : 0];
-    if (gemm_skipped(g)) {                                  // every caption has ended (grid-uniform)
-        if (FOLD && first == 0 && tid < 32 && m0 + tid < Mloc) {
-            // the sampler's outputs of this step for rows that ended long ago: <eos>, exact one-hot, nothing open
-            const int b = m0 + tid, t = sa.step;
-            sa.seq[(size_t)b * sa.seq_ld + (t - 1)] = 0;
-            sa.slp[(size_t)b * sa.seq_ld + (t - 1)] = 0.f;
-            if (sa.stv) sa.stv[(size_t)b * sa.seq_ld + (t - 1)] = 1.0f;
-            sa.it_next[b] = 0;
-        }
-        return;
-    }
-    if (FOLD) {
-        const int r = 4 * ks + lq;                          // the row this 16-lane group finishes
-        const int b = min(m0 + r, Mloc - 1);
-        const int np = fold.nparts;
-        const float* part = fold.part[blk2 ? 1 : 0];
-        const size_t plane = (size_t)fold.part_rows[blk2 ? 1 : 0] * np;
-        const float inv_t = 1.0f / sa.temp;
-        RowPart rp;
-        rp.init();
-        for (int p = li; p < np; p += 16) {
-            const float* pp = part + (size_t)b * np + p;
-            RowPart q;
-            q.m1 = pp[0]; q.s1 = pp[plane]; q.kbest = pp[2 * plane]; q.xbest = pp[3 * plane];
-            q.kidx = __float_as_int(pp[4 * plane]); q.s2 = pp[5 * plane];
-            rowpart_merge(rp, sa.mode, inv_t, q);
-        }
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-            RowPart q;
-            q.m1 = __shfl_xor(rp.m1, o, 64); q.s1 = __shfl_xor(rp.s1, o, 64);
-            q.kbest = __shfl_xor(rp.kbest, o, 64); q.xbest = __shfl_xor(rp.xbest, o, 64);
-            q.kidx = __shfl_xor(rp.kidx, o, 64); q.s2 = __shfl_xor(rp.s2, o, 64);
-            rowpart_merge(rp, sa.mode, inv_t, q);
-        }
-        const RowChoice c = row_choice(sa, rp, b);
-        if (li == 0) {
-            tok_s[r] = c.tok;
-            if (first == 0 && m0 + r < Mloc) {
-                float* lse = fold.lse[blk2 ? 1 : 0];
-                if (lse) lse[b] = c.lse;
-                row_bookkeeping(sa, c, b);
-            }
-        }
-        __syncthreads();
-    }
+    if (gemm_skipped(g)) return;                            // every caption has ended (grid-uniform)
     auto parts8 = [](const f32x4 lo, const f32x4 hi, bf16x8 (&dst)[3][JS], int j) {
         bf16x4 pl[3], ph[3];
         split_bf16<3>(lo, pl);
@@ -1335,26 +1284,6 @@ __global__ __launch_bounds__(KS * 64) void gemm_walk16bf_kernel(cic_gemm_args g,
         for (int j = 0; j < JS; ++j) {
             const int k0 = 32 * (ks * JS + j);             // wave-uniform
             const bool second = k0 >= K1;
-            if (FOLD && !second) {
-                // x_t = dropout(relu(embed(token))) of this row, gathered from the table (AttModel.py:74-76,399)
-                const int kk = k0 + 8 * lq;
-                const float* src = sa.emb_w + (size_t)tok_s[16 * rt + li] * sa.emb_dim + kk;
-                f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
-                uint32_t kp0 = 0x01010101u, kp1 = 0x01010101u;
-                if (sa.emb_keep) {
-                    const uint2 kb = *reinterpret_cast<const uint2*>(sa.emb_keep + (size_t)mc * sa.emb_dim + kk);
-                    kp0 = kb.x; kp1 = kb.y;
-                }
-                lo = embed_transform(sa, lo, kp0);
-                hi = embed_transform(sa, hi, kp1);
-                if (first == 0 && mok) {
-                    float* xd = sa.emb_x + (size_t)m * sa.emb_dim + kk;
-                    *reinterpret_cast<f32x4*>(xd) = lo;
-                    *reinterpret_cast<f32x4*>(xd + 4) = hi;
-                }
-                parts8(mok ? lo : z4, mok ? hi : z4, ap[rt], j);
-                continue;
-            }
             const float* src = (second ? gA2 : gA) + (size_t)mc * (second ? g.lda2 : g.lda) + (second ? k0 - K1 : k0) + 8 * lq;
             const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
             parts8(mok ? lo : z4, mok ? hi : z4, ap[rt], j);
@@ -2239,10 +2168,9 @@ int launch_rega(const cic_gemm_args& g, hipStream_t st) {
         if (nb < 1) nb = 1;
         // f32 results either way: three bf16 parts per operand (2.67x the MFMA rate) unless the caller asks for the
         // f32-input instruction
-        if (g_bfx && g.precision != CIC_PRECISION_F32_MFMA && (g.K % 32) == 0) {
-            if (g.fold) hipLaunchKernelGGL((gemm_walk16bf_kernel<8, 1>), dim3(strips * nb), dim3(512), 0, st, g, strips, *g.fold);
-            else hipLaunchKernelGGL((gemm_walk16bf_kernel<8, 0>), dim3(strips * nb), dim3(512), 0, st, g, strips, cic_finish_fold{});
-        } else
+        if (g_bfx && g.precision != CIC_PRECISION_F32_MFMA && (g.K % 32) == 0)
+            hipLaunchKernelGGL((gemm_walk16bf_kernel<8>), dim3(strips * nb), dim3(512), 0, st, g, strips);
+        else
             hipLaunchKernelGGL((gemm_walk16_kernel<8, 8, false>), dim3(strips * nb), dim3(512), 0, st, g, strips);
         CIC_LAUNCH_CHECK();
         return 0;
@@ -2425,7 +2353,6 @@ extern "C" int cic_debug_gemm_tail_split(int on) {
     g_ldsb2 = ((on >> 25) & 3) == 1 ? 0 : (((on >> 25) & 3) == 2 ? 4 : 2);
     g_logit_epi = ((on >> 27) & 1) ? 0 : 1;
     g_bfx = ((on >> 28) & 1) ? 0 : 1;
-    g_fold = ((on >> 29) & 1) ? 0 : 1;
     return 0;
 }
 
@@ -2442,13 +2369,6 @@ static bool gemm_split_supported(const cic_gemm_args& g) {
            !g.relu && (g.rows_blk == 0 || g.C_tail_b) && g_walk16 && rega_ok(g);   // K = K2 = 512: the walker's shape
 }
 extern "C" int cic_gemm_split_ok(const cic_gemm_args* a) { return a && gemm_split_supported(*a) ? 1 : 0; }
-// the prologue form exists in the 16-wide bf16-part strip walker only (see launch_rega's choice of it)
-extern "C" int cic_gemm_fold_ok(const cic_gemm_args* a) {
-    if (!a || !g_fold || !gemm_split_supported(*a)) return 0;
-    const cic_gemm_args& g = *a;
-    return (g_walk16 && g_bfx && g.precision != CIC_PRECISION_F32_MFMA && g.b_kc && g.N >= 2048 && g.K + g.K2 == 1024 &&
-            (g.K % 32) == 0) ? 1 : 0;
-}
 
 // rows 129..256 of K-contiguous activations are handed to the register-streaming kernels as two blocks of 128
 static bool split_rows_case(const cic_gemm_args& g) {
@@ -2479,14 +2399,6 @@ extern "C" int cic_gemm_f32(const cic_gemm_args* a, cic_stream_t s) {
     CIC_REQUIRE(a != nullptr);
     const cic_gemm_args& g = *a;
     CIC_REQUIRE(!g.epi || cic_gemm_logit_parts(a) > 0);
-    if (g.fold) {
-        CIC_REQUIRE(cic_gemm_fold_ok(a) && g.fold->nparts >= 1);
-        for (int q = 0; q < (g.rows_blk > 0 ? 2 : 1); ++q) {
-            const cic_sampler_args& sa = g.fold->s[q];
-            CIC_REQUIRE(sa.emb_w && sa.emb_x && sa.emb_dim == g.K && sa.mode != CIC_SAMPLE_NONE && g.fold->part[q] &&
-                        sa.unfinished && sa.it_next && sa.seq && sa.slp && sa.any_unfinished && sa.step >= 1 && sa.temp > 0.f);
-        }
-    }
     if (g.n_split > 0) {
         CIC_REQUIRE(gemm_split_supported(g));
         return launch_rega(g, cic_s(s));

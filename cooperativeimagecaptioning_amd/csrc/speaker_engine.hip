@@ -269,9 +269,6 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     if (presplit_logit) RUN(cic_split_bf16x3(p->logit_w, (int64_t)V1 * H, w[0].logit_parts, s));
     bool early_stop = g_early_stop && !fc && !ps && !teacher_batched;
     for (int q = 0; q < nb; ++q) early_stop = early_stop && !io[q]->first_token;
-    // the sampler of step t as the prologue of step t+1's gate product (cic_finish_fold): one launch less per step
-    cic_finish_fold pending = {};
-    bool have_pending = false, fold_ok = false;
     for (int t = 0; t < T; ++t) {
         const Dual<float> x = SLAB(x_all, B * E), att_h = SLAB(att_h_all, B * A), att_res = SLAB(att_res_all, B * H),
                           pre = SLAB(pre_all, B * 5 * H), out = SLAB(out_all, B * H), logp = SLAB(logp_all, B * V1);
@@ -318,20 +315,11 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
             g.C_tail = att_h.a; g.C_tail_b = att_h.b; g.ldc_tail = A;
             if (nb == 2) { g.rows_blk = B; g.A_b = x.b; g.A2_b = h.b; g.C_b = pre.b; }
             g.live = live.a; g.live_b = live.b;
-            if (t == 0) fold_ok = !ps && !teacher_batched && cic_gemm_fold_ok(&g) && io[0]->timer == nullptr;
-            if (have_pending) {
-                // this launch chooses the step's tokens itself: what it can know before is whether every caption had
-                // ended one step EARLIER (any_unf[t-1]; the entry of step 1 is the sampler's first)
-                g.fold = &pending;
-                g.live = (early_stop && t >= 2) ? w[0].any_unf + (t - 1) : nullptr;
-                g.live_b = (early_stop && t >= 2 && nb == 2) ? w[1].any_unf + (t - 1) : nullptr;
-            }
             if (g_gates_att_fused && cic_gemm_split_ok(&g)) {
                 RUN(cic_gemm_f32(&g, st));
                 gates_done = true;
             }
-            CIC_REQUIRE(!have_pending || gates_done);
-            have_pending = false;
+
         }
         // attention                                                        (:465-489)
         if (!fc && !gates_done) {
@@ -442,17 +430,6 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
                 a.emb_w = p->embed_w; a.emb_x = w[q].x_all + (size_t)(t + 1) * B * E; a.emb_keep = xkn;
                 a.emb_scale = 1.0f / (1.0f - p_drop); a.emb_dim = E; a.emb_plain = fc ? 1 : 0;
             }
-        }
-        if (!ps && fold_ok && t + 1 < T) {
-            // taken by the next step's gate product
-            pending = cic_finish_fold{};
-            for (int q = 0; q < nb; ++q) {
-                pending.s[q] = sa[q];
-                pending.part[q] = w[q].part; pending.part_rows[q] = B; pending.lse[q] = w[q].lse_all + (size_t)t * B;
-            }
-            pending.nparts = np;
-            have_pending = true;
-            continue;
         }
         if (ps) {
             CIC_TIMED(io[0]->timer, CIC_TIMED_SAMPLER, st, rc = cic_logsoftmax_sample2(&sa[0], nb == 2 ? &sa[1] : nullptr, st));

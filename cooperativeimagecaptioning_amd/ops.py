@@ -24,7 +24,6 @@ _gemm = _sig('cic_gemm_f32', [C.POINTER(GemmArgs), P])
 # every entry point gets its signature here or in engine.py: ctypes would pass an undeclared Python int as a 32-bit int
 _sig('cic_gemm_logit_parts', [C.POINTER(GemmArgs)])
 _sig('cic_gemm_split_ok', [C.POINTER(GemmArgs)])
-_sig('cic_gemm_fold_ok', [C.POINTER(GemmArgs)])
 _split3 = _sig('cic_split_bf16x3', [P, L64, P, P])
 _sig('cic_gemm_f32_timed', [C.POINTER(GemmArgs), I, C.POINTER(C.c_double), P])
 _sig('cic_logit_partials', [P, I, I, I, P, I, P])

@@ -135,9 +135,6 @@ typedef struct {
     const int32_t* live;
     const int32_t* live_b;
     int live_min;
-    /* Optional (decode engines): the sampler of the PREVIOUS step taken into this product's prologue - see
-     * cic_finish_fold below.  Only where cic_gemm_fold_ok() says so; NULL elsewhere. */
-    const struct cic_finish_fold* fold;
 } cic_gemm_args;
 enum { CIC_PRECISION_F32 = 0, CIC_PRECISION_F32_MFMA = 1, CIC_PRECISION_BF16 = 2 };
 /* Row partials of the vocabulary: the columns of a row are dealt to `nparts` parts; a part reduces its columns
@@ -254,25 +251,6 @@ typedef struct {
     int emb_dim;
     int emb_plain;
 } cic_sampler_args;
-/* The sampler on row partials (cic_sample_finish) as the PROLOGUE of the next core step's gate product
- * [i2h(x_t) + h2h(h_{t-1}) | h2att(h_{t-1})]: every workgroup of a 32-row strip merges the partials of its rows, chooses
- * their tokens exactly as the sampler launch would, and reads the FIRST operand pair's rows straight from the embedding
- * table (x_t = dropout(relu(embed(token))), AttModel.py:74-76,399) instead of from A; one workgroup per strip also does the
- * sampler's bookkeeping (tokens, log-probs, straight-through values, EOS flags, lse) and writes x_t to s[].emb_x for the
- * backward pass.  One launch less per decode step; tokens and every stored value as from the two launches, except that
- * a row's partials meet in another order (slp / lse / stv agree to rounding, ~1e-7).
- * s[q]: sampler arguments of row block q (emb_w / emb_x / emb_keep / emb_dim = K of the first pair are required; logits =
- * the raw logits of the previous step); part / part_rows / lse as for cic_sample_finish; nparts partials per row. */
-typedef struct cic_finish_fold {
-    cic_sampler_args s[2];
-    const float* part[2];
-    int part_rows[2];
-    float* lse[2];
-    int nparts;
-} cic_finish_fold;
-/* 1 if cic_gemm_f32 takes a->fold for these arguments (the 16-wide bf16-part strip walker: K-contiguous operands,
- * K = K2 = 512, many column tiles), 0 if not */
-int cic_gemm_fold_ok(const cic_gemm_args* a);
 /* logit bias/GEMM output -> F.log_softmax + sampling + EOS bookkeeping,
  * models/AttModel.py:328-365,401-434,438-444. */
 int cic_logsoftmax_sample(const cic_sampler_args* a, cic_stream_t s);

@@ -27,8 +27,7 @@ int cic_debug_set_attn_stamps(unsigned long long* buf);
  * 21 16-wide walkers, 22 LDS-staged logit walker, 23 row-block split of 129..256-row products, 24 two-strip dX kernel;
  * bits 25..26: K parts per row tile of the logit walker (0 = two, 1 = its 4-wave form with one, 2 = four);
  * bit 27: the logit walker without its fused vocabulary epilogue (the row partials then come from cic_logit_partials);
- * bit 28: the LDS-tiled products on the f32-input MFMA only (no bf16-part kernel);
- * bit 29: the decode engines launch the sampler on its own instead of folding it into the next gate product */
+ * bit 28: the LDS-tiled products on the f32-input MFMA only (no bf16-part kernel) */
 int cic_debug_gemm_tail_split(int on);
 /* diagnostics: 0 = the decode engines launch the attention query product on its own (A/B timing of the column split) */
 int cic_debug_gates_att_fused(int on);
