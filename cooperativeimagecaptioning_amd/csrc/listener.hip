@@ -249,7 +249,7 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_kernel(float* __restrict__ h_
     const int orc = orow < B ? orow : B - 1;
     const int ln = len[orc];
     unsigned* cnt = sync + (size_t)strip * (Lp + 1);      // cnt[t]: workgroups of this strip that have published h_t
-    unsigned* err = sync + (size_t)gridDim.x / tiles_j * (Lp + 1);
+    unsigned* err = sync + 2 * ((size_t)gridDim.x / tiles_j) * (Lp + 1);   // behind the forward and the backward counters
     const size_t slab = (size_t)B * J;
     // the weight tile, once: B fragments of the three gates for this wave's K slice
     f32x4 wf[3][GPS];
@@ -346,6 +346,166 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_kernel(float* __restrict__ h_
             __syncthreads();
             if (tid == 0) __hip_atomic_fetch_add(cnt + t + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+}
+
+// ---- the GRU's BPTT loop in ONE launch -------------------------------------------------------------------------------
+// The backward twin of gru_seq_kernel.  Per step the plain form launches gru_cell_bwd_kernel (d h_{t+1} -> d gates) and a
+// product dh_t += dgh_t W_hh that re-streams the 12.6 MB of W_hh from 32 fat workgroups (5 + 17 us, Lp times).  Here the
+// same 256 workgroups as in the forward pass (32-row strip x 16-unit tile) stay resident for the whole loop:
+//   * a workgroup keeps the COLUMNS jt*16 .. +16 of W_hh (all 3J rows: the contraction index of dX = dY W) as B fragments in
+//     registers, K = 3J split over its 8 waves: 96 VGPRs per lane, read once;
+//   * the gradient w.r.t. the hidden state never goes to memory: after the cross-wave sum every lane holds dh of ONE
+//     (row, unit), which is exactly what the gate derivative of the previous step needs at that (row, unit) - the cell
+//     backward runs on it in place and yields the three dgi / three dgh values of that unit;
+//   * what a step needs from the other 63 workgroups of its strip are the strip's dgh_t rows (32 x 3J floats: they are the A
+//     operand of the product): published and consumed with the hand-off of gru_seq_kernel (write-through stores, drain,
+//     barrier, one counter add; one poller, barrier, sc1 loads) on counters of their own.
+// Steps at or beyond the longest caption of a strip carry no gate gradient: their slabs are zeroed and neither the hand-off
+// nor the product runs (the same decision in every workgroup of the strip: it depends on the strip's lengths only).
+template <int GPS, int KS>   // GPS groups of 16 k per wave: 3J = 16*GPS*KS
+__global__ __launch_bounds__(KS * 64) void gru_seq_bwd_kernel(const float* __restrict__ h_all, const float* __restrict__ W,
+                                                              const float* __restrict__ gi_all, const float* __restrict__ gh_all,
+                                                              const int32_t* __restrict__ len, const float* __restrict__ dh_init,
+                                                              float* __restrict__ dgi_all, float* __restrict__ dgh_all,
+                                                              unsigned* __restrict__ sync, int B, int J, int Lp, int pool,
+                                                              const float* __restrict__ d_pool,
+                                                              const int32_t* __restrict__ pool_arg) {
+    static_assert(KS == 8, "8 accumulator registers (2 row tiles x 4) dealt one per wave");
+    constexpr int GPC = 4, NCH = GPS / GPC;               // the A rows arrive in chunks of GPC groups, two chunks in flight
+    static_assert(GPS % GPC == 0, "whole chunks");
+    __shared__ float red[KS * 8 * 64];
+    __shared__ int ok_s, smax_s;
+    const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int tiles_j = J / 16, strips = gridDim.x / tiles_j;
+    const int strip = blockIdx.x / tiles_j, jt = blockIdx.x % tiles_j;
+    const int m0 = strip * 32;
+    const int col = jt * 16 + li;
+    const int orow = m0 + 16 * (ks >> 2) + 4 * lq + (ks & 3);
+    const int orc = orow < B ? orow : B - 1;
+    const int ln = len[orc];
+    const int J3 = 3 * J;
+    unsigned* cnt = sync + ((size_t)strips + strip) * (Lp + 1);     // cnt[t]: workgroups of this strip that have published dgh_t
+    unsigned* err = sync + 2 * (size_t)strips * (Lp + 1);
+    if (tid == 0) smax_s = 0;
+    __syncthreads();
+    if (tid < 32) atomicMax(&smax_s, len[min(m0 + tid, B - 1)]);
+    // the weight tile, once: B fragments (k = 16*group + 4*lq + s, n = col) of this wave's K slice
+    f32x4 wf[GPS];
+#pragma unroll
+    for (int i = 0; i < GPS; ++i) {
+        const float* wk = W + (size_t)(16 * (ks * GPS + i) + 4 * lq) * J + col;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wf[i][s] = wk[(size_t)s * J];
+    }
+    __syncthreads();
+    const int smax = smax_s;
+    const size_t gslab = (size_t)B * J3;
+    float d = dh_init[(size_t)orc * J + col];              // d loss / d h_{t+1} at this lane's (row, unit)
+    float poison = 0.f;
+    for (int t = Lp - 1; t >= 0; --t) {
+        const size_t o = (size_t)orc * J3 + col;
+        float* dgi = dgi_all + (size_t)t * gslab;
+        float* dgh = dgh_all + (size_t)t * gslab;
+        const auto hdst = __builtin_amdgcn_make_buffer_rsrc(dgh, 0, (int)(gslab * sizeof(float)), 0x00020000);
+        if (t >= smax) {
+            // no caption of the strip reaches step t: zero gate gradients, d passes through (no pooled term either)
+            if (orow < B) {
+                dgi[o] = 0.f; dgi[o + J] = 0.f; dgi[o + 2 * J] = 0.f;
+                dgh[o] = 0.f; dgh[o + J] = 0.f; dgh[o + 2 * J] = 0.f;
+            }
+            continue;
+        }
+        // ---- gate derivative of step t at (orow, col): gru_cell_bwd_kernel on one element -------------------------------
+        {
+            const float* gi = gi_all + (size_t)t * gslab;
+            const float* gh = gh_all + (size_t)t * gslab;
+            const float ir = gi[o], iz = gi[o + J], in = gi[o + 2 * J];
+            const float hr = gh[o], hz = gh[o + J], hnn = gh[o + 2 * J];
+            const float hp = h_all[(size_t)t * B * J + (size_t)orc * J + col];
+            if (pool && t < ln) {
+                const float dp = d_pool[(size_t)orc * J + col];
+                if (pool == 1) d += dp * (1.0f / (float)ln);
+                else if (pool_arg[(size_t)orc * J + col] == t) d += dp;
+            }
+            float gir = 0.f, giz = 0.f, gin = 0.f, ghn = 0.f, dprev = d;
+            if (t < ln) {
+                const float r = fast_sigmoid(ir + hr);
+                const float z = fast_sigmoid(iz + hz);
+                const float n = fast_tanh(in + r * hnn);
+                const float dn = d * (1.0f - z);
+                const float dz = d * (hp - n);
+                const float dan = dn * (1.0f - n * n);
+                const float dr = dan * hnn;
+                gir = dr * r * (1.0f - r);
+                giz = dz * z * (1.0f - z);
+                gin = dan;
+                ghn = dan * r;
+                dprev = d * z;
+            }
+            if (poison != 0.f) { gir = poison; giz = poison; gin = poison; ghn = poison; }
+            if (orow < B) {
+                dgi[o] = gir; dgi[o + J] = giz; dgi[o + 2 * J] = gin;
+                // dgh_t is handed to the strip's other workgroups: write-through stores
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gir), hdst, (int)(o * 4), 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, giz), hdst, (int)((o + J) * 4), 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ghn), hdst, (int)((o + 2 * J) * 4), 0, 16);
+            }
+            d = dprev;
+        }
+        if (t == 0) break;                                  // h_0 is the constant zero state: nothing flows further
+        // ---- publish dgh_t, wait for the strip, dh_t = d h direct + dgh_t W_hh --------------------------------------------
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // EVERY storing wave drains before the signal
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(cnt + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            int ok = 1;
+            while (__hip_atomic_load(cnt + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)tiles_j) {
+                __builtin_amdgcn_s_sleep(1);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > GRU_SPIN_TICKS) { ok = 0; break; }
+            }
+            ok_s = ok;
+            if (!ok) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // compiler only: no load of dgh_t above the poll
+        if (!ok_s) poison = __builtin_nanf("");
+        const int mc0 = min(m0 + li, B - 1), mc1 = min(m0 + 16 + li, B - 1);   // rows past B repeat row B-1: never stored
+        f32x4 af[2][2][GPC];
+        auto load_chunk = [&](int c) {
+#pragma unroll
+            for (int i = 0; i < GPC; ++i) {
+                const int k = 16 * (ks * GPS + c * GPC + i) + 4 * lq;
+                af[c & 1][0][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hdst, (int)(((size_t)mc0 * J3 + k) * 4), 0, 16));
+                af[c & 1][1][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hdst, (int)(((size_t)mc1 * J3 + k) * 4), 0, 16));
+            }
+        };
+        f32x4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        load_chunk(0);
+        load_chunk(1);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int i = 0; i < GPC; ++i)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c & 1][0][i][s], wf[c * GPC + i][s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c & 1][1][i][s], wf[c * GPC + i][s], acc1, 0, 0, 0);
+                }
+            if (c + 2 < NCH) load_chunk(c + 2);             // into the registers this chunk's MFMAs have just read
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            red[(ks * 8 + v) * 64 + lane] = acc0[v];
+            red[(ks * 8 + 4 + v) * 64 + lane] = acc1[v];
+        }
+        __syncthreads();
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < KS; ++w) v += red[(w * 8 + ks) * 64 + lane];
+        d += v;                                             // red is rewritten only behind the next step's barriers
     }
 }
 
@@ -550,8 +710,12 @@ __global__ __launch_bounds__(256) void contrastive_bwd_kernel(const float* __res
                                                               int max_violation, int sel_s, int sel_im,
                                                               const float* __restrict__ g_rows, const float* __restrict__ g_scalar,
                                                               const int32_t* __restrict__ arg_s,
-                                                              const int32_t* __restrict__ arg_im, float* __restrict__ dS) {
+                                                              const int32_t* __restrict__ arg_im, float* __restrict__ dS,
+                                                              unsigned* __restrict__ sync_bwd, int nsync_bwd) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // hand-off counters of gru_seq_bwd_kernel (the first kernel of the backward pass clears them: a second backward pass
+    // over the same forward state starts from zero as well)
+    for (int k = i; k < nsync_bwd; k += gridDim.x * blockDim.x) sync_bwd[k] = 0u;
     if (i >= B) return;
     const float g = g_rows ? g_rows[i] : *g_scalar;
     const float d = S[(size_t)i * B + i];
@@ -581,7 +745,7 @@ __global__ __launch_bounds__(256) void contrastive_bwd_kernel(const float* __res
 }
 
 struct LstWs {
-    unsigned* sync;           // gru_seq_kernel: [strips][Lp+1] hand-off counters + 1 error word (zeroed by the prep kernels)
+    unsigned* sync;           // gru_seq_kernel / gru_seq_bwd_kernel: 2 x [strips][Lp+1] hand-off counters + 1 error word (zeroed by the prep kernels)
     int nsync;
     int32_t *idx, *len, *arg_s, *arg_im;
     float *val, *x_emb, *gi_all, *gh_all, *h_all, *img_lin, *img_emb, *cap_emb, *nrm_img, *nrm_cap, *S;
@@ -595,7 +759,7 @@ LstWs lst_carve(const cic_listener_dims& d, void* base) {
     LstWs w;
     Carver c(base);
     const size_t B = d.B, J = d.J, E = d.E, Lp = d.Lp;
-    w.nsync = (int)(((B + 31) / 32) * (Lp + 1) + 1);
+    w.nsync = (int)(2 * ((B + 31) / 32) * (Lp + 1) + 1);     // forward counters, backward counters, error word
     w.sync = reinterpret_cast<unsigned*>(c.i32((size_t)(w.nsync + 3) / 4 * 4));
     w.idx = c.i32(B * Lp);
     w.len = c.i32(B);
@@ -776,7 +940,8 @@ static int listener_bwd_impl(const cic_listener_dims* dp, const cic_listener_par
     const int sel_s = io->only_one_retrieval != 1, sel_im = io->only_one_retrieval != 2;
     CIC_HIP(hipMemsetAsync(w.dS, 0, sizeof(float) * B * B, st));
     hipLaunchKernelGGL(contrastive_bwd_kernel, dim3(cic_cdiv(B, 256)), dim3(256), 0, st, w.S, B, d.margin,
-                       d.max_violation, sel_s, sel_im, bio->g_rows, bio->g_scalar, w.arg_s, w.arg_im, w.dS);
+                       d.max_violation, sel_s, sel_im, bio->g_rows, bio->g_scalar, w.arg_s, w.arg_im, w.dS,
+                       w.sync + (size_t)cic_cdiv(B, 32) * (Lp + 1), cic_cdiv(B, 32) * (Lp + 1));
     CIC_LAUNCH_CHECK();
     // S = im cap^T  ->  d_im = dS cap,  d_cap = dS^T im
     RUN(gemm_nn(w.dS, B, w.cap_emb, J, w.d_img, J, B, J, B, false, st));
@@ -795,7 +960,20 @@ static int listener_bwd_impl(const cic_listener_dims* dp, const cic_listener_par
     if (d.pool) CIC_HIP(hipMemsetAsync(w.dh, 0, sizeof(float) * B * J, st));   // nothing reaches the final state directly
     float* dh = w.dh;
     float* dh2 = w.dh2;
-    for (int t = Lp - 1; t >= 0; --t) {
+    bool seq_kernel = false;
+    if (g_gru_fused >= 2 && J == 1024 && !io->device_shared) {
+        // as in the forward pass: every workgroup resident at once, one per CU
+        int dev = 0, cus = 0;
+        CIC_HIP(hipGetDevice(&dev));
+        CIC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        seq_kernel = cic_cdiv(B, 32) * (J / 16) <= cus;
+    }
+    if (seq_kernel) {
+        hipLaunchKernelGGL((gru_seq_bwd_kernel<24, 8>), dim3(cic_cdiv(B, 32) * (J / 16)), dim3(512), 0, st, w.h_all, p->w_hh,
+                           w.gi_all, w.gh_all, w.len, dh, w.dgi_all, w.dgh_all, w.sync, B, J, Lp, d.pool, w.d_pool, w.pool_arg);
+        CIC_LAUNCH_CHECK();
+    }
+    for (int t = Lp - 1; t >= 0 && !seq_kernel; --t) {
         float* dgi = w.dgi_all + (size_t)t * B * 3 * J;
         float* dgh = w.dgh_all + (size_t)t * B * 3 * J;
         hipLaunchKernelGGL(gru_cell_bwd_kernel, dim3(cic_cdiv(B * (J / 4), 256)), dim3(256), 0, st,

@@ -81,22 +81,33 @@ def main():
     side = torch.cuda.Stream()
     big_a = torch.randn(64 << 20, device=dev)
     big_b = torch.empty_like(big_a)
-    ref, _ = run(1, 'generated')
+    ref, ref_g = run(1, 'generated')
     lib.cic_debug_gru_fused(2)
     dims = engine.listener_dims(B, F, E, J, V, T, Lp)
     bad = 0
+    bad_bwd = 0
+    gs = torch.ones(1, device=dev)
+    khh = 'txt_enc.rnn.weight_hh_l0'
+    gscale = float(ref_g[khh].abs().max())
     for i in range(60):
         with torch.cuda.stream(side):
             for _ in range(3):
                 big_b.copy_(big_a)
         f = engine.listener_fwd(dims, params, fc, seq=seq, stv=stv, L=Lt, want_emb=True)
+        grads = {k: torch.zeros_like(v) for k, v in W.items()}
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                big_b.copy_(big_a)
+        engine.listener_bwd(dims, params, f, g_scalar=gs, grads=grads)      # the one-launch BPTT loop under the same load
         if i % 10 == 9:
             torch.cuda.synchronize()
         if not torch.equal(f['cap_emb'], ref['cap_emb']):
             bad += 1
+        if not float((grads[khh] - ref_g[khh]).abs().max()) < 1e-5 * gscale:
+            bad_bwd += 1
     torch.cuda.synchronize()
-    report['uneven_load'] = dict(runs=60, mismatches=bad)
-    ok = ok and bad == 0
+    report['uneven_load'] = dict(runs=60, mismatches=bad, backward_mismatches=bad_bwd)
+    ok = ok and bad == 0 and bad_bwd == 0
     # timing of the forward engine (whole listener forward: the GRU pass is what differs)
     times = {}
     for form in (1, 2):
@@ -112,6 +123,22 @@ def main():
         torch.cuda.synchronize()
         times[form] = a.elapsed_time(b) * 1e3 / args.iters
     report['listener_fwd_us'] = {'per_step_launches': times[1], 'one_launch': times[2]}
+    # ... and of the backward engine (the BPTT loop is what differs)
+    grads = {k: torch.zeros_like(v) for k, v in W.items()}
+    for form in (1, 2):
+        lib.cic_debug_gru_fused(form)
+        f = engine.listener_fwd(dims, params, fc, seq=seq, stv=stv, L=Lt, want_emb=True)
+        for _ in range(5):
+            engine.listener_bwd(dims, params, f, g_scalar=gs, grads=grads)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(args.iters):
+            engine.listener_bwd(dims, params, f, g_scalar=gs, grads=grads)
+        b.record()
+        torch.cuda.synchronize()
+        times[form] = a.elapsed_time(b) * 1e3 / args.iters
+    report['listener_bwd_us'] = {'per_step_launches': times[1], 'one_launch': times[2]}
     report['gru_seq_check'] = 'ok' if ok else 'MISMATCH'
     print(json.dumps(report), flush=True)
     sys.exit(0 if ok else 1)
