@@ -19,6 +19,9 @@ namespace {
 // 32-row strip x 16-unit tile, else 1); 1 = one fused launch per step; 0 = a GEMM + a cell launch per step.
 // Development build: cic_debug_gru_fused(n) selects (A/B measurement, bit-exactness tests of 2 against 1).
 CIC_SWITCH(g_gru_fused, 2);
+#ifdef CIC_DEVTOOLS
+__device__ unsigned long long* g_gru_stamps = nullptr;   // development build: [workgroup][step][8] s_memrealtime stamps of gru_seq_bwd_kernel
+#endif
 
 // ---- token preparation -----------------------------------------------------------------
 // generated captions: tokens = [<bos>, seq[:, 0:L]], lens from masks [1,1,(seq>0)[:, :L-1]]
@@ -241,15 +244,22 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_kernel(float* __restrict__ h_
     __shared__ int ok_s;
     const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
-    const int tiles_j = J / 16;
-    const int strip = blockIdx.x / tiles_j, jt = blockIdx.x % tiles_j;
+    const int tiles_j = J / 16, strips = gridDim.x / tiles_j;
+    int strip = blockIdx.x / tiles_j, jt = blockIdx.x % tiles_j;
+    if (strips <= 8 && (8 % strips) == 0 && (tiles_j % (8 / strips)) == 0) {
+        // speed only: blocks b and b + 8 share an XCD - the workgroups of a strip (they exchange h among themselves) on as few
+        // XCDs as possible (the poll of a step: 3.9 -> 2.4 us in the backward twin, tools/gru_stamps.py)
+        const int xs = 8 / strips, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        strip = xcd / xs;
+        jt = (xcd % xs) * (tiles_j / xs) + local;
+    }
     const int m0 = strip * 32;
     const int col = jt * 16 + li;
     const int orow = m0 + 16 * (ks >> 2) + 4 * lq + (ks & 3);
     const int orc = orow < B ? orow : B - 1;
     const int ln = len[orc];
     unsigned* cnt = sync + (size_t)strip * (Lp + 1);      // cnt[t]: workgroups of this strip that have published h_t
-    unsigned* err = sync + 2 * ((size_t)gridDim.x / tiles_j) * (Lp + 1);   // behind the forward and the backward counters
+    unsigned* err = sync + ((size_t)gridDim.x / tiles_j + (B + 15) / 16) * (Lp + 1);   // behind the forward and the backward counters
     const size_t slab = (size_t)B * J;
     // the weight tile, once: B fragments of the three gates for this wave's K slice
     f32x4 wf[3][GPS];
@@ -351,60 +361,86 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_kernel(float* __restrict__ h_
 
 // ---- the GRU's BPTT loop in ONE launch -------------------------------------------------------------------------------
 // The backward twin of gru_seq_kernel.  Per step the plain form launches gru_cell_bwd_kernel (d h_{t+1} -> d gates) and a
-// product dh_t += dgh_t W_hh that re-streams the 12.6 MB of W_hh from 32 fat workgroups (5 + 17 us, Lp times).  Here the
-// same 256 workgroups as in the forward pass (32-row strip x 16-unit tile) stay resident for the whole loop:
-//   * a workgroup keeps the COLUMNS jt*16 .. +16 of W_hh (all 3J rows: the contraction index of dX = dY W) as B fragments in
-//     registers, K = 3J split over its 8 waves: 96 VGPRs per lane, read once;
+// product dh_t += dgh_t W_hh that re-streams the 12.6 MB of W_hh from 32 fat workgroups (5 + 17 us, Lp times).  Here 256
+// workgroups - a 16-row strip of the batch x a 32-unit tile each, one per CU - stay resident for the whole loop:
+//   * a workgroup keeps the COLUMNS jt*32 .. +32 of W_hh (all 3J rows: the contraction index of dX = dY W) as MFMA B fragments,
+//     K = 3J split over its 8 waves: 393 KB, two thirds of them in registers (128 VGPRs per lane) and one third in LDS
+//     (128 KB, stored in fragment order: one conflict-free ds_read_b128 per fragment), read from memory once;
 //   * the gradient w.r.t. the hidden state never goes to memory: after the cross-wave sum every lane holds dh of ONE
 //     (row, unit), which is exactly what the gate derivative of the previous step needs at that (row, unit) - the cell
 //     backward runs on it in place and yields the three dgi / three dgh values of that unit;
-//   * what a step needs from the other 63 workgroups of its strip are the strip's dgh_t rows (32 x 3J floats: they are the A
-//     operand of the product): published and consumed with the hand-off of gru_seq_kernel (write-through stores, drain,
-//     barrier, one counter add; one poller, barrier, sc1 loads) on counters of their own.
+//   * what a step needs from the other 31 workgroups of its strip are the strip's dgh_t rows (16 x 3J floats: the A operand
+//     of the product): published and consumed with the hand-off of gru_seq_kernel (write-through stores, drain, barrier, one
+//     counter add; one poller, barrier, sc1 loads) on counters of their own.
+// Why 16 x 32 and not the forward kernel's 32 x 16: bytes handed over inside a launch are served at the fabric's rate
+// (~7.4 TB/s chip-wide measured, whichever XCD the reader sits on and whether it loads sc1 or acquires and loads plainly:
+// tools/gru_stamps.py), and every workgroup of a strip reads ALL of the strip's dgh rows, so a step moves
+// rows-per-strip x 12 KB x 256 workgroups: 100 MB (13.6 us) with 32-row strips, 50 MB with 16 - about the 5.9 us of the step's
+// f32 MFMAs.  With 8 strips x 32 tiles the workgroups of a strip also share ONE XCD (blockIdx % 8; speed only).
 // Steps at or beyond the longest caption of a strip carry no gate gradient: their slabs are zeroed and neither the hand-off
 // nor the product runs (the same decision in every workgroup of the strip: it depends on the strip's lengths only).
-template <int GPS, int KS>   // GPS groups of 16 k per wave: 3J = 16*GPS*KS
+constexpr int GRUB_GPS = 24, GRUB_GR = 16, GRUB_GL = GRUB_GPS - GRUB_GR;       // k groups of 16 per wave: in registers / in LDS
+constexpr size_t GRUB_LDS_BYTES = sizeof(float) * ((size_t)8 * GRUB_GL * 2 * 64 * 4 + 8 * 8 * 64);
+template <int KS>   // 3J = 16 * GRUB_GPS * KS
 __global__ __launch_bounds__(KS * 64) void gru_seq_bwd_kernel(const float* __restrict__ h_all, const float* __restrict__ W,
                                                               const float* __restrict__ gi_all, const float* __restrict__ gh_all,
                                                               const int32_t* __restrict__ len, const float* __restrict__ dh_init,
                                                               float* __restrict__ dgi_all, float* __restrict__ dgh_all,
-                                                              unsigned* __restrict__ sync, int B, int J, int Lp, int pool,
-                                                              const float* __restrict__ d_pool,
+                                                              unsigned* __restrict__ cnt_base, unsigned* __restrict__ err,
+                                                              int B, int J, int Lp, int pool, const float* __restrict__ d_pool,
                                                               const int32_t* __restrict__ pool_arg) {
-    static_assert(KS == 8, "8 accumulator registers (2 row tiles x 4) dealt one per wave");
-    constexpr int GPC = 4, NCH = GPS / GPC;               // the A rows arrive in chunks of GPC groups, two chunks in flight
-    static_assert(GPS % GPC == 0, "whole chunks");
-    __shared__ float red[KS * 8 * 64];
+    static_assert(KS == 8, "8 accumulator registers (2 column tiles x 4) dealt one per wave");
+    constexpr int GPS = GRUB_GPS, GR = GRUB_GR, GL = GRUB_GL;
+    constexpr int GPC = 4, NCH = GPS / GPC, NBUF = 3;     // the A rows arrive in chunks of GPC groups, NBUF chunks in flight
+    static_assert(GPS % GPC == 0 && GR % GPC == 0 && NBUF <= NCH, "whole chunks");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    f32x4* wl = reinterpret_cast<f32x4*>(lds);            // [KS][GL][2 column tiles][64 lanes] B fragments
+    float* red = lds + (size_t)KS * GL * 2 * 64 * 4;      // [KS][8][64]
     __shared__ int ok_s, smax_s;
     const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
-    const int tiles_j = J / 16, strips = gridDim.x / tiles_j;
-    const int strip = blockIdx.x / tiles_j, jt = blockIdx.x % tiles_j;
-    const int m0 = strip * 32;
-    const int col = jt * 16 + li;
-    const int orow = m0 + 16 * (ks >> 2) + 4 * lq + (ks & 3);
+    const int tiles_j = J / 32, strips = gridDim.x / tiles_j;
+    int strip = blockIdx.x / tiles_j, jt = blockIdx.x % tiles_j;
+    if (strips <= 8 && (8 % strips) == 0 && (tiles_j % (8 / strips)) == 0) {
+        // speed only: blocks b and b + 8 share an XCD - the workgroups of a strip (they read the same dgh rows) on as few
+        // XCDs as possible
+        const int xs = 8 / strips, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        strip = xcd / xs;
+        jt = (xcd % xs) * (tiles_j / xs) + local;
+    }
+    const int m0 = strip * 16;
+    const int col = jt * 32 + 16 * (ks >> 2) + li;          // the output this wave finishes: register ks & 3 of column tile ks >> 2
+    const int orow = m0 + 4 * lq + (ks & 3);
     const int orc = orow < B ? orow : B - 1;
     const int ln = len[orc];
     const int J3 = 3 * J;
-    unsigned* cnt = sync + ((size_t)strips + strip) * (Lp + 1);     // cnt[t]: workgroups of this strip that have published dgh_t
-    unsigned* err = sync + 2 * (size_t)strips * (Lp + 1);
+    unsigned* cnt = cnt_base + (size_t)strip * (Lp + 1);    // cnt[t]: workgroups of this strip that have published dgh_t
     if (tid == 0) smax_s = 0;
     __syncthreads();
-    if (tid < 32) atomicMax(&smax_s, len[min(m0 + tid, B - 1)]);
-    // the weight tile, once: B fragments (k = 16*group + 4*lq + s, n = col) of this wave's K slice
-    f32x4 wf[GPS];
+    if (tid < 16) atomicMax(&smax_s, len[min(m0 + tid, B - 1)]);
+    // the weight tile, once: B fragments (k = 16*group + 4*lq + s, n = column li of tile ct) of this wave's K slice
+    f32x4 wf[GR][2];
 #pragma unroll
     for (int i = 0; i < GPS; ++i) {
-        const float* wk = W + (size_t)(16 * (ks * GPS + i) + 4 * lq) * J + col;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) wf[i][s] = wk[(size_t)s * J];
+        for (int ct = 0; ct < 2; ++ct) {
+            const float* wk = W + (size_t)(16 * (ks * GPS + i) + 4 * lq) * J + jt * 32 + 16 * ct + li;
+            f32x4 v;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) v[s] = wk[(size_t)s * J];
+            if (i < GR) wf[i < GR ? i : 0][ct] = v;
+            else wl[((ks * GL + (i - GR)) * 2 + ct) * 64 + lane] = v;
+        }
     }
     __syncthreads();
     const int smax = smax_s;
     const size_t gslab = (size_t)B * J3;
     float d = dh_init[(size_t)orc * J + col];              // d loss / d h_{t+1} at this lane's (row, unit)
     float poison = 0.f;
+    unsigned long long* stamps = CIC_STAMP_BUF(g_gru_stamps);
+#define GRU_STAMP(i) if (stamps && tid == 0) stamps[((size_t)blockIdx.x * Lp + t) * 8 + (i)] = __builtin_amdgcn_s_memrealtime()
     for (int t = Lp - 1; t >= 0; --t) {
+        GRU_STAMP(0);
         const size_t o = (size_t)orc * J3 + col;
         float* dgi = dgi_all + (size_t)t * gslab;
         float* dgh = dgh_all + (size_t)t * gslab;
@@ -456,8 +492,10 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_bwd_kernel(const float* __res
         }
         if (t == 0) break;                                  // h_0 is the constant zero state: nothing flows further
         // ---- publish dgh_t, wait for the strip, dh_t = d h direct + dgh_t W_hh --------------------------------------------
+        GRU_STAMP(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // EVERY storing wave drains before the signal
         __syncthreads();
+        GRU_STAMP(2);
         if (tid == 0) {
             __hip_atomic_fetch_add(cnt + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -472,41 +510,52 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_bwd_kernel(const float* __res
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // compiler only: no load of dgh_t above the poll
         if (!ok_s) poison = __builtin_nanf("");
-        const int mc0 = min(m0 + li, B - 1), mc1 = min(m0 + 16 + li, B - 1);   // rows past B repeat row B-1: never stored
-        f32x4 af[2][2][GPC];
-        auto load_chunk = [&](int c) {
+        GRU_STAMP(3);
+        const int mc = min(m0 + li, B - 1);                 // rows past B repeat row B-1: their sums are never stored
+        f32x4 af[NBUF][GPC];
+        auto load_chunk = [&](int c) {                      // every load of the handed-off bytes is sc1 (aux 16)
 #pragma unroll
             for (int i = 0; i < GPC; ++i) {
                 const int k = 16 * (ks * GPS + c * GPC + i) + 4 * lq;
-                af[c & 1][0][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hdst, (int)(((size_t)mc0 * J3 + k) * 4), 0, 16));
-                af[c & 1][1][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hdst, (int)(((size_t)mc1 * J3 + k) * 4), 0, 16));
+                af[c % NBUF][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hdst, (int)(((size_t)mc * J3 + k) * 4), 0, 16));
             }
         };
         f32x4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        load_chunk(0);
-        load_chunk(1);
+#pragma unroll
+        for (int c = 0; c < NBUF; ++c) load_chunk(c);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
 #pragma unroll
-            for (int i = 0; i < GPC; ++i)
+            for (int i = 0; i < GPC; ++i) {
+                const int gidx = c * GPC + i;
+                f32x4 b0, b1;
+                if (gidx < GR) { b0 = wf[gidx < GR ? gidx : 0][0]; b1 = wf[gidx < GR ? gidx : 0][1]; }
+                else {
+                    b0 = wl[((ks * GL + (gidx - GR)) * 2 + 0) * 64 + lane];
+                    b1 = wl[((ks * GL + (gidx - GR)) * 2 + 1) * 64 + lane];
+                }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c & 1][0][i][s], wf[c * GPC + i][s], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c & 1][1][i][s], wf[c * GPC + i][s], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c % NBUF][i][s], b0[s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c % NBUF][i][s], b1[s], acc1, 0, 0, 0);
                 }
-            if (c + 2 < NCH) load_chunk(c + 2);             // into the registers this chunk's MFMAs have just read
+            }
+            if (c + NBUF < NCH) load_chunk(c + NBUF);       // into the registers this chunk's MFMAs have just read
         }
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             red[(ks * 8 + v) * 64 + lane] = acc0[v];
             red[(ks * 8 + 4 + v) * 64 + lane] = acc1[v];
         }
+        GRU_STAMP(4);
         __syncthreads();
+        GRU_STAMP(5);
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < KS; ++w) v += red[(w * 8 + ks) * 64 + lane];
         d += v;                                             // red is rewritten only behind the next step's barriers
     }
+#undef GRU_STAMP
 }
 
 // dh (in/out): gradient w.r.t. h_{t+1} in, w.r.t. the direct h_t path out (the W_hh path is added by a GEMM)
@@ -759,7 +808,7 @@ LstWs lst_carve(const cic_listener_dims& d, void* base) {
     LstWs w;
     Carver c(base);
     const size_t B = d.B, J = d.J, E = d.E, Lp = d.Lp;
-    w.nsync = (int)(2 * ((B + 31) / 32) * (Lp + 1) + 1);     // forward counters, backward counters, error word
+    w.nsync = (int)(((B + 31) / 32 + (B + 15) / 16) * (Lp + 1) + 1);   // forward counters (32-row strips), backward counters (16-row strips), error word
     w.sync = reinterpret_cast<unsigned*>(c.i32((size_t)(w.nsync + 3) / 4 * 4));
     w.idx = c.i32(B * Lp);
     w.len = c.i32(B);
@@ -804,6 +853,10 @@ int check_ldims(const cic_listener_dims& d) {
 #ifdef CIC_DEVTOOLS
 extern "C" int cic_debug_gru_fused(int on) {
     g_gru_fused = on;
+    return 0;
+}
+extern "C" int cic_debug_set_gru_stamps(unsigned long long* buf) {
+    CIC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gru_stamps), &buf, sizeof(buf)));
     return 0;
 }
 #endif
@@ -941,7 +994,7 @@ static int listener_bwd_impl(const cic_listener_dims* dp, const cic_listener_par
     CIC_HIP(hipMemsetAsync(w.dS, 0, sizeof(float) * B * B, st));
     hipLaunchKernelGGL(contrastive_bwd_kernel, dim3(cic_cdiv(B, 256)), dim3(256), 0, st, w.S, B, d.margin,
                        d.max_violation, sel_s, sel_im, bio->g_rows, bio->g_scalar, w.arg_s, w.arg_im, w.dS,
-                       w.sync + (size_t)cic_cdiv(B, 32) * (Lp + 1), cic_cdiv(B, 32) * (Lp + 1));
+                       w.sync + (size_t)cic_cdiv(B, 32) * (Lp + 1), cic_cdiv(B, 16) * (Lp + 1));
     CIC_LAUNCH_CHECK();
     // S = im cap^T  ->  d_im = dS cap,  d_cap = dS^T im
     RUN(gemm_nn(w.dS, B, w.cap_emb, J, w.d_img, J, B, J, B, false, st));
@@ -966,11 +1019,17 @@ static int listener_bwd_impl(const cic_listener_dims* dp, const cic_listener_par
         int dev = 0, cus = 0;
         CIC_HIP(hipGetDevice(&dev));
         CIC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        seq_kernel = cic_cdiv(B, 32) * (J / 16) <= cus;
+        seq_kernel = cic_cdiv(B, 16) * (J / 32) <= cus;
     }
     if (seq_kernel) {
-        hipLaunchKernelGGL((gru_seq_bwd_kernel<24, 8>), dim3(cic_cdiv(B, 32) * (J / 16)), dim3(512), 0, st, w.h_all, p->w_hh,
-                           w.gi_all, w.gh_all, w.len, dh, w.dgi_all, w.dgh_all, w.sync, B, J, Lp, d.pool, w.d_pool, w.pool_arg);
+        static DeviceOnce attr_set;
+        if (attr_set.first())
+            CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_bwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)GRUB_LDS_BYTES));
+        unsigned* cnt_b = w.sync + (size_t)cic_cdiv(B, 32) * (Lp + 1);
+        hipLaunchKernelGGL((gru_seq_bwd_kernel<8>), dim3(cic_cdiv(B, 16) * (J / 32)), dim3(512), GRUB_LDS_BYTES, st, w.h_all, p->w_hh,
+                           w.gi_all, w.gh_all, w.len, dh, w.dgi_all, w.dgh_all, cnt_b, cnt_b + (size_t)cic_cdiv(B, 16) * (Lp + 1), B, J,
+                           Lp, d.pool, w.d_pool, w.pool_arg);
         CIC_LAUNCH_CHECK();
     }
     for (int t = Lp - 1; t >= 0 && !seq_kernel; --t) {

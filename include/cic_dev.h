@@ -38,6 +38,10 @@ int cic_debug_bptt_early_stop(int on);
 /* diagnostics: 2 (default) the whole GRU pass in one launch where the grid fits the chip, 1 one fused launch per step,
  * 0 every listener GRU step as a GEMM launch + a cell launch */
 int cic_debug_gru_fused(int on);
+/* diagnostics: phase stamps of the one-launch GRU BPTT loop (gru_seq_bwd_kernel): [workgroup][step][8] s_memrealtime values
+ * (100 MHz) written by lane 0 - 0 step start, 1 gate derivative stored, 2 drained + barrier, 3 hand-off counter reached,
+ * 4 MFMA chain done, 5 cross-wave sum barrier; NULL switches them off */
+int cic_debug_set_gru_stamps(unsigned long long* buf);
 /* diagnostics: 0 runs the speaker's a2c product and cell as two launches instead of the fused kernel */
 int cic_debug_a2c_cell_fused(int on);
 
