@@ -99,7 +99,7 @@ class DecodeIO(C.Structure):
 
 class DecodeBwdIO(C.Structure):
     _fields_ = [('d_onehot', c_ptr), ('dslp', c_ptr), ('grads', C.POINTER(SpeakerParams)), ('att_raw', c_ptr),
-                ('d_x0', c_ptr), ('phase', C.c_int)]
+                ('d_x0', c_ptr), ('phase', C.c_int), ('device_shared', C.c_int)]
 
 
 BWD_ALL, BWD_LOGIT, BWD_REST = 0, 1, 2

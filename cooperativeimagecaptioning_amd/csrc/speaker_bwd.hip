@@ -12,6 +12,7 @@
 namespace {
 
 CIC_SWITCH(g_bptt_early_stop, 1);   // development build: cic_debug_bptt_early_stop(0) = the products of every BPTT step run (A/B)
+CIC_SWITCH(g_bptt_seq, 1);           // development build: cic_debug_bptt_seq(0) = the BPTT loop as four launches per step (A/B, parity)
 
 
 constexpr int SNW = 16;   // waves per row workgroup of sampler_bwd_kernel
@@ -511,6 +512,350 @@ __global__ __launch_bounds__(1024) void attn_bwd_cols_kernel(const float* __rest
     if (rg == 0) reinterpret_cast<f32x4*>(d_att_h + (size_t)b * H)[col4] = acc;
 }
 
+// ---- the speaker's BPTT loop in ONE launch ------------------------------------------------------------------------------
+// Per time step the plain form launches four kernels (cell backward 5 us, d att_res = d in_transform a2c.W 7 us, attention
+// backward 7 us, dh = dpre h2h.W + d_att_h h2att.W 11 us; x T), each re-streaming its weights into a few fat workgroups.
+// Here 256 workgroups - a 16-row strip of the batch x a 16-column tile of the H = 512 hidden units, one per CU, all
+// resident - walk the whole loop (same scheme as the listener's gru_seq_bwd_kernel):
+//   * the COLUMNS jt*16 .. +16 of a2c.W [2H,H], h2h.W [5H,H] and h2att.W [A,H] stay in the workgroup as MFMA B fragments
+//     (v_mfma_f32_16x16x4_f32), the contraction index split over its 8 waves: h2h in registers (80 VGPRs per lane), a2c and
+//     h2att in LDS in fragment order (96 KB) - read from memory once instead of T times;
+//   * dh and dc never go to memory: after the cross-wave sum a lane of waves 0-3 holds dh of ONE (row, unit) and runs the
+//     cell backward of the previous step on it in place (five dpre values);
+//   * three hand-offs per step inside a strip (32 workgroups, kept on ONE XCD at B = 128: blockIdx % 8), each the
+//     write-through-store / drain / barrier / counter-add + one-poller / barrier / sc1-load form of gru_seq_kernel:
+//       1. dpre_t rows of the strip (A operand of both products),
+//       2. d att_res_t rows (what the attention backward of an image needs),
+//       3. d att_h_t rows (A operand of the h2att part);
+//     the slabs they travel in are the workspace slabs the batched gradient products read after the loop anyway;
+//   * a wave's K slice covers the SAME columns 3H + 128 ks .. of dpre for a2c.W and for the (a, b) rows of h2h.W, so those A
+//     fragments are loaded once for both products; the dh product over the 5H columns of dpre runs together with the
+//     a2c product (it does not wait for the attention), only the h2att part follows the third hand-off;
+//   * the attention backward of the strip's 16 images runs on the 16 even-numbered workgroups of the strip (8 waves x 64
+//     columns; the region features are requested before the second hand-off is waited for).
+// Steps at or beyond the decode's length L carry no gradient (d out = 0, no carry): zeros are stored, no hand-off runs.
+// Every spin is bounded (20 ms): a workgroup that gives up raises *err and poisons what it produces with NaN.
+struct BpttArgs {
+    const float *pre_all, *c_all, *alpha_all, *att_h_all, *p_att, *att;     // forward state [T,B,5H] [T+1,B,H] [T,B,K] [T,B,H] [B,K,H] x2
+    const uint8_t* out_keep;                                                // [T,B,H] or null
+    const float *a2c_w, *h2h_w, *h2att_w, *alpha_w;
+    const float* d_out_all;                                                 // [T,B,H]
+    float *dpre_all, *d_att_res_all, *d_att_h_all, *ddot_all;               // [T,B,5H] [T,B,H] [T,B,H] [T,B,K]
+    unsigned *cnt, *err;                                                    // [strips][T][3] counters (zeroed by the launcher), 1 word
+    const int32_t* L;                                                       // the decode's length on the device, or null
+    float scale;
+    int B, K, T;
+};
+constexpr int BPTT_GA = 8, BPTT_GI = 12, BPTT_GC = 4;      // k groups of 16 per wave: (a, b) gate columns / (i, f, o) / d_att_h
+constexpr size_t BPTT_LDS_BYTES = sizeof(float) * ((size_t)8 * (BPTT_GA + BPTT_GC) * 64 * 4 + 8 * 4 * 64 + 8 * 64);
+constexpr unsigned long long BPTT_SPIN_TICKS = 20ull * 100000ull;          // 20 ms of the 100 MHz s_memrealtime counter
+#ifdef CIC_DEVTOOLS
+__device__ unsigned long long* g_bptt_stamps = nullptr;    // development build: [workgroup][step][8] s_memrealtime stamps
+#endif
+typedef float f32x4acc_b __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_b __attribute__((ext_vector_type(4)));
+template <int KS>
+__global__ __launch_bounds__(KS * 64) void spk_bptt_seq_kernel(BpttArgs a) {
+    static_assert(KS == 8, "K slices of 128 / 192 / 64 columns per wave");
+    constexpr int H = 512, H5 = 5 * H, TJ = H / 16, GA = BPTT_GA, GI = BPTT_GI, GC = BPTT_GC;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    f32x4* wl = reinterpret_cast<f32x4*>(lds);            // [KS][GA + GC][64]: a2c fragments, then h2att fragments
+    float* red = lds + (size_t)KS * (GA + GC) * 64 * 4;   // [KS][4][64]
+    float* sp = red + KS * 4 * 64;                        // [KS][64] per-wave partial d alpha
+    __shared__ int ok_s;
+    const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int B = a.B, K = a.K, T = a.T;
+    const int strips = gridDim.x / TJ;
+    int strip = blockIdx.x / TJ, jt = blockIdx.x % TJ;
+    if (strips <= 8 && (8 % strips) == 0 && (TJ % (8 / strips)) == 0) {     // speed only: a strip on as few XCDs as possible
+        const int xs = 8 / strips, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        strip = xcd / xs;
+        jt = (xcd % xs) * (TJ / xs) + local;
+    }
+    const int m0 = strip * 16;
+    const int col = jt * 16 + li;
+    const bool owner = ks < 4;                            // waves 0-3 finish the 16 x 16 outputs: register ks of the tile
+    const int orow = m0 + 4 * lq + (ks & 3);
+    const int orc = orow < B ? orow : B - 1;
+    const int mc = min(m0 + li, B - 1);                   // A rows; rows past B repeat row B-1: their sums are never stored
+    unsigned* cnt = a.cnt + (size_t)strip * T * 3;
+    // ---- the weight tiles, once --------------------------------------------------------------------------------------
+    f32x4 wh_ab[GA], wh_ifo[GI];
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+        const int k = 128 * ks + 16 * i + 4 * lq;
+        f32x4 v;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            wh_ab[i][s] = a.h2h_w[(size_t)(3 * H + k + s) * H + col];
+            v[s] = a.a2c_w[(size_t)(k + s) * H + col];
+        }
+        wl[(ks * (GA + GC) + i) * 64 + lane] = v;
+        __builtin_amdgcn_sched_barrier(0);                // group by group: keeps the live addresses of this one-time gather few
+    }
+#pragma unroll
+    for (int i = 0; i < GI; ++i) {
+        const int k = 192 * ks + 16 * i + 4 * lq;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wh_ifo[i][s] = a.h2h_w[(size_t)(k + s) * H + col];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < GC; ++i) {
+        const int k = 64 * ks + 16 * i + 4 * lq;
+        f32x4 v;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = a.h2att_w[(size_t)(k + s) * H + col];
+        wl[(ks * (GA + GC) + GA + i) * 64 + lane] = v;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // attention backward: this wave's 64 columns (float4 column col4), lane -> (c = column quad, rg = region group)
+    const int ac = lane & 15, rg = lane >> 4;
+    const int col4 = 16 * ks + ac;
+    const f32x4 wa = reinterpret_cast<const f32x4*>(a.alpha_w)[col4];
+    const int img = m0 + (jt >> 1);
+    const bool att_wg = (jt & 1) == 0;
+    __syncthreads();
+    const int Lv = __builtin_amdgcn_readfirstlane(a.L ? *a.L : T);      // wave-uniform: the step loop stays scalar control flow
+    float dh = 0.f, dc = 0.f;                             // carried gradients of this lane's (row, unit) (owners)
+    float poison = 0.f;
+    unsigned long long* stamps = CIC_STAMP_BUF(g_bptt_stamps);
+#define BPTT_STAMP(i) if (stamps && tid == 0) stamps[((size_t)blockIdx.x * T + t) * 8 + (i)] = __builtin_amdgcn_s_memrealtime()
+    // publish what this workgroup stored (add != 0) and wait until `target` workgroups of the strip have published
+    auto handoff = [&](unsigned* c, unsigned target, bool add) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // EVERY storing wave drains before the signal
+        __syncthreads();
+        if (tid == 0) {
+            if (add) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            int ok = 1;
+            while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > BPTT_SPIN_TICKS) { ok = 0; break; }
+            }
+            ok_s = ok;
+            if (!ok) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // compiler only: no load of handed-off bytes above the poll
+        if (!ok_s) poison = __builtin_nanf("");
+    };
+    // the three hand-off slabs as buffer resources over all T steps, built once from scalar registers; a step's slab is
+    // the scalar offset of its loads and stores
+    auto uniform_rsrc = [](float* ptr, size_t bytes) {
+        const unsigned long long u = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo), 0, (int)bytes, 0x00020000);
+    };
+    const auto r_dpre = uniform_rsrc(a.dpre_all, (size_t)T * B * H5 * sizeof(float));
+    const auto r_dres = uniform_rsrc(a.d_att_res_all, (size_t)T * B * H * sizeof(float));
+    const auto r_dah = uniform_rsrc(a.d_att_h_all, (size_t)T * B * H * sizeof(float));
+    const int imc = img < B ? img : B - 1;
+    const auto r_att = uniform_rsrc(const_cast<float*>(a.att) + (size_t)imc * K * H, (size_t)K * H * sizeof(float));
+    const auto r_patt = uniform_rsrc(const_cast<float*>(a.p_att) + (size_t)imc * K * H, (size_t)K * H * sizeof(float));
+    for (int t = T - 1; t >= 0; --t) {
+        BPTT_STAMP(0);
+        // per-lane index values made opaque once per step: the address arithmetic that hangs on them is then redone next to
+        // each access instead of being hoisted out of the loop into ~100 registers held across all phases (that cost 160
+        // spilled VGPRs, most of them reloaded inside the MFMA phase of every step)
+        int lq_t = lq, mc_t = mc, orc_t = orc, orow_t = orow, col_t = col, col4_t = col4, rg_t = rg, lane_t = lane;
+        asm volatile("" : "+v"(lq_t), "+v"(mc_t), "+v"(orc_t), "+v"(orow_t), "+v"(col_t), "+v"(col4_t), "+v"(rg_t), "+v"(lane_t));
+        const size_t rowH = (size_t)t * B * H;
+        float* dres = a.d_att_res_all + rowH;
+        float* dah = a.d_att_h_all + rowH;
+        const int so5 = __builtin_amdgcn_readfirstlane((int)((size_t)t * B * H5 * sizeof(float)));   // slab t of dpre, of the [B,H] slabs
+        const int so1 = __builtin_amdgcn_readfirstlane((int)(rowH * sizeof(float)));
+        const bool live = t < Lv;
+        // ---- 1. cell backward of step t at (orow_t, col_t): cell_bwd_kernel on one element (waves 0-3) ----------------------
+        if (owner) {
+            const size_t e = (size_t)orc_t * H + col_t;
+            const float* pre = a.pre_all + (size_t)t * B * H5 + (size_t)orc_t * H5 + col_t;
+            const float pi = pre[0], pf = pre[H], po = pre[2 * H], pa = pre[3 * H], pb = pre[4 * H];
+            const float cp = a.c_all[rowH + e], cn = a.c_all[rowH + (size_t)B * H + e];
+            const float dout = a.d_out_all[rowH + e];
+            const float kf = a.out_keep ? (float)a.out_keep[rowH + e] * a.scale : 1.0f;
+            const float ig = fast_sigmoid(pi), fg = fast_sigmoid(pf), og = fast_sigmoid(po);
+            const float g = fmaxf(pa, pb);
+            const float tc = fast_tanh(cn);
+            const float dhh = dout * kf + dh;
+            const float dcc = dc + dhh * og * (1.0f - tc * tc);
+            float gi = dcc * g * ig * (1.0f - ig);
+            float gf = dcc * cp * fg * (1.0f - fg);
+            float go = dhh * tc * og * (1.0f - og);
+            const float dg = dcc * ig;
+            // torch.max(a, b) backward: larger gets it, exact tie splits it evenly
+            float ga = pa > pb ? dg : (pa == pb ? 0.5f * dg : 0.f);
+            float gb = pb > pa ? dg : (pa == pb ? 0.5f * dg : 0.f);
+            dc = dcc * fg;
+            if (poison != 0.f) { gi = poison; gf = poison; go = poison; ga = poison; gb = poison; }
+            if (orow_t < B) {
+                const int o = (int)(((size_t)orow_t * H5 + col_t) * 4);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gi), r_dpre, o, so5, 16);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gf), r_dpre, o + 4 * H, so5, 16);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, go), r_dpre, o + 8 * H, so5, 16);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ga), r_dpre, o + 12 * H, so5, 16);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gb), r_dpre, o + 16 * H, so5, 16);
+                if (!live) { dres[(size_t)orow_t * H + col_t] = 0.f; dah[(size_t)orow_t * H + col_t] = 0.f; }
+            }
+        }
+        if (!live) {            // grid-uniform: nothing but zeros flows through this step (dpre above came out as zeros)
+            if (jt == 0)
+                for (int i = tid; i < 16 * K; i += KS * 64)
+                    if (m0 + i / K < B) a.ddot_all[((size_t)t * B + m0 + i / K) * K + i % K] = 0.f;
+            dh = 0.f;
+            continue;
+        }
+        BPTT_STAMP(1);
+        handoff(cnt + t * 3 + 0, TJ, true);
+        BPTT_STAMP(2);
+        // ---- 2. d att_res = dpre[:, 3H:5H] a2c.W  and the dpre part of  dh = dpre h2h.W --------------------------------------
+        f32x4acc_b acc_res = {0.f, 0.f, 0.f, 0.f}, acc_dh = {0.f, 0.f, 0.f, 0.f};
+        {
+            // the wave's 20 k groups of dpre_t (8 of the (a, b) columns, 12 of the (i, f, o) columns; the latter only feed dh:
+            // not at t = 0) in chunks of 4, three chunks in flight
+            constexpr int GPC = 4, NBUF = 3;
+            const int nch = t > 0 ? (GA + GI) / GPC : GA / GPC;
+            f32x4 af[NBUF][GPC];
+            auto load_chunk = [&](int c) {
+#pragma unroll
+                for (int i = 0; i < GPC; ++i) {
+                    const int gidx = c * GPC + i;
+                    const int kcol = gidx < GA ? 3 * H + 128 * ks + 16 * gidx : 192 * ks + 16 * (gidx - GA);
+                    af[c % NBUF][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        r_dpre, (int)(((size_t)mc_t * H5 + kcol + 4 * lq_t) * 4), so5, 16));
+                }
+            };
+#pragma unroll
+            for (int c = 0; c < NBUF; ++c)
+                if (c < nch) load_chunk(c);
+#pragma unroll
+            for (int c = 0; c < (GA + GI) / GPC; ++c) {
+                if (c < nch) {                               // wave-uniform
+#pragma unroll
+                    for (int i = 0; i < GPC; ++i) {
+                        const int gidx = c * GPC + i;
+                        if (gidx < GA) {
+                            const f32x4 bw = wl[(ks * (GA + GC) + (gidx < GA ? gidx : 0)) * 64 + lane_t];
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) {
+                                acc_res = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c % NBUF][i][s], bw[s], acc_res, 0, 0, 0);
+                                acc_dh = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c % NBUF][i][s], wh_ab[gidx < GA ? gidx : 0][s], acc_dh, 0, 0, 0);
+                            }
+                        } else {
+#pragma unroll
+                            for (int s = 0; s < 4; ++s)
+                                acc_dh = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c % NBUF][i][s], wh_ifo[gidx >= GA ? gidx - GA : 0][s], acc_dh, 0, 0, 0);
+                        }
+                    }
+                    if (c + NBUF < nch) load_chunk(c + NBUF);
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) red[(ks * 4 + v) * 64 + lane_t] = acc_res[v];
+        __syncthreads();
+        if (owner) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < KS; ++w) v += red[(w * 4 + ks) * 64 + lane_t];
+            if (poison != 0.f) v = poison;
+            if (orow_t < B) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_dres, (int)(((size_t)orow_t * H + col_t) * 4), so1, 16);
+        }
+        BPTT_STAMP(3);
+        handoff(cnt + t * 3 + 1, TJ, true);
+        BPTT_STAMP(4);
+        // ---- 3. attention backward of image img (attn_bwd_cols_kernel, 8 waves x 64 columns) ----------------------------------
+        // Two passes over the image's regions, 36 registers each: att for d alpha, then p_att for d att_h (requested as soon
+        // as the att rows are consumed).  Buffer loads over the image's [K,H] block: one offset register per lane, the
+        // region group in the scalar offset, regions beyond K read as zeros (out of the resource's range).
+        const bool do_att = att_wg && img < B;
+        if (att_wg) {
+            constexpr int JMAX = 9;                          // regions 4 j + rg, K <= 36
+            const int vo = (rg_t * H + 4 * col4_t) * 4;
+            f32x4 rv[JMAX];
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j)
+                rv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_att, vo, 4 * j * H * 4, 0));
+            const f32x4 ah4 = reinterpret_cast<const f32x4*>(a.att_h_all + rowH + (size_t)imc * H)[col4_t];
+            const f32x4 dr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_dres, (int)(((size_t)imc * H + 4 * col4_t) * 4), so1, 16));
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j) {
+                float part = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part += dr[e] * rv[j][e];
+                part = sum8_dpp(part);
+                part += dpp_f32<DPP_ROW_MIRROR>(part);
+                const int k = 4 * j + rg_t;
+                if (ac == 0 && k < K) sp[ks * 64 + k] = part;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j)
+                rv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_patt, vo, 4 * j * H * 4, 0));
+            __syncthreads();                                 // (workgroup-uniform branch)
+            float dal = 0.f, al = 0.f;
+            if (lane < K) {
+#pragma unroll
+                for (int q = 0; q < KS; ++q) dal += sp[q * 64 + lane];
+                al = a.alpha_all[((size_t)t * B + imc) * K + lane];
+            }
+            const float cs = wave_sum_fast(al * dal);
+            float dd = al * (dal - cs);                      // 0 for lanes >= K
+            if (poison != 0.f) dd = poison;
+            if (ks == 0 && lane < K && do_att) a.ddot_all[((size_t)t * B + img) * K + lane] = dd;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j) {
+                const float dk = __shfl(dd, 4 * j + rg_t, 64);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float th = fast_tanh(rv[j][e] + ah4[e]);
+                    acc[e] += dk * (1.0f - th * th);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[e];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                acc[e] = v * wa[e];
+            }
+            if (rg_t == 0 && do_att)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_b, acc), r_dah, (int)(((size_t)img * H + 4 * col4_t) * 4), so1, 16);
+        }
+        BPTT_STAMP(5);
+        handoff(cnt + t * 3 + 2, TJ / 2, att_wg);
+        BPTT_STAMP(6);
+        if (t == 0) break;                                   // h_{-1} is the constant zero state: nothing flows further
+        // ---- 4. dh += d_att_h h2att.W, cross-wave sum -> this lane's dh of step t - 1 --------------------------------------------
+        {
+            f32x4 ac4[GC];
+#pragma unroll
+            for (int i = 0; i < GC; ++i)
+                ac4[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    r_dah, (int)(((size_t)mc_t * H + 64 * ks + 16 * i + 4 * lq_t) * 4), so1, 16));
+#pragma unroll
+            for (int i = 0; i < GC; ++i) {
+                const f32x4 bw = wl[(ks * (GA + GC) + GA + i) * 64 + lane_t];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc_dh = __builtin_amdgcn_mfma_f32_16x16x4f32(ac4[i][s], bw[s], acc_dh, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) red[(ks * 4 + v) * 64 + lane_t] = acc_dh[v];
+        __syncthreads();
+        if (owner) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < KS; ++w) v += red[(w * 4 + ks) * 64 + lane_t];
+            dh = poison != 0.f ? poison : v;
+        }
+        BPTT_STAMP(7);
+    }
+#undef BPTT_STAMP
+}
+
 // ---- feature gradients after the time loop ----------------------------------------------------
 //   d_att[b,k,:]   = sum_t alpha_t[b,k] * d_att_res_t[b,:]
 //   d_p_att[b,k,a] = w_a * sum_t ddot_t[b,k] * (1 - tanh^2(p_att[b,k,a] + att_h_t[b,a]))
@@ -649,6 +994,8 @@ struct SpkBws {
     float *dlogits, *d_out_all, *dpre_all, *d_att_h_all, *d_att_res_all, *ddot_all, *dh_a, *dh_b, *dc, *dx_all;
     float *d_att, *d_p_att, *d_attpre;
     float* dpre_img;   // [B,5H] image step of an FCModel decode
+    unsigned* sync;    // spk_bptt_seq_kernel: [strips of 16 rows][T][3] hand-off counters + error word (cleared by the launcher)
+    size_t nsync;
     size_t bytes;
 };
 SpkBws spk_bcarve(const cic_speaker_dims& d, void* base, bool own_dlogits) {
@@ -669,6 +1016,8 @@ SpkBws spk_bcarve(const cic_speaker_dims& d, void* base, bool own_dlogits) {
     w.d_p_att = c.f32(B * K * A);
     w.d_attpre = c.f32(B * K * H);
     w.dpre_img = c.f32(B * 5 * H);
+    w.nsync = (((B + 15) / 16) * T * 3 + 1 + 3) / 4 * 4;
+    w.sync = reinterpret_cast<unsigned*>(c.i32(w.nsync));
     w.bytes = c.used();
     return w;
 }
@@ -677,6 +1026,11 @@ SpkBws spk_bcarve(const cic_speaker_dims& d, void* base, bool own_dlogits) {
 
 #ifdef CIC_DEVTOOLS
 extern "C" int cic_debug_bptt_early_stop(int on) { g_bptt_early_stop = on; return 0; }
+extern "C" int cic_debug_bptt_seq(int on) { g_bptt_seq = on; return 0; }
+extern "C" int cic_debug_set_bptt_stamps(unsigned long long* buf) {
+    CIC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_bptt_stamps), &buf, sizeof(buf)));
+    return 0;
+}
 #endif
 
 extern "C" size_t cic_speaker_decode_bwd_ws_bytes(const cic_speaker_dims* d) {
@@ -744,7 +1098,33 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     // 3. BPTT over the cell + attention (only dh, dc are carried)
     float* dh_in = g.dh_a;
     float* dh_out = g.dh_b;
-    for (int t = T - 1; t >= 0; --t) {
+    // the flagship widths walk the loop in ONE launch (spk_bptt_seq_kernel): every workgroup resident at once, one per CU
+    bool seq_kernel = false;
+    if (g_bptt_seq && !ps && !fc && H == 512 && A == 512 && K >= 1 && K <= 36 && !bio->device_shared) {
+        int dev = 0, cus = 0;
+        CIC_HIP(hipGetDevice(&dev));
+        CIC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        seq_kernel = cic_cdiv(B, 16) * (H / 16) <= cus;
+    }
+    if (seq_kernel) {
+        static DeviceOnce attr_set;
+        if (attr_set.first())
+            CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spk_bptt_seq_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)BPTT_LDS_BYTES));
+        CIC_HIP(hipMemsetAsync(g.sync, 0, g.nsync * sizeof(unsigned), st));
+        BpttArgs ba = {};
+        ba.pre_all = w.pre_all; ba.c_all = w.c_all; ba.alpha_all = w.alpha_all; ba.att_h_all = w.att_h_all;
+        ba.p_att = w.p_att; ba.att = w.att; ba.out_keep = io->out_keep;
+        ba.a2c_w = p->a2c_w; ba.h2h_w = p->h2h_w; ba.h2att_w = p->h2att_w; ba.alpha_w = p->alpha_w;
+        ba.d_out_all = g.d_out_all; ba.dpre_all = g.dpre_all; ba.d_att_res_all = g.d_att_res_all;
+        ba.d_att_h_all = g.d_att_h_all; ba.ddot_all = g.ddot_all;
+        ba.cnt = g.sync; ba.err = g.sync + (size_t)cic_cdiv(B, 16) * T * 3;
+        ba.L = g_bptt_early_stop ? io->L : nullptr;
+        ba.scale = scale; ba.B = B; ba.K = K; ba.T = T;
+        hipLaunchKernelGGL((spk_bptt_seq_kernel<8>), dim3(cic_cdiv(B, 16) * (H / 16)), dim3(512), BPTT_LDS_BYTES, st, ba);
+        CIC_LAUNCH_CHECK();
+    }
+    for (int t = T - 1; t >= 0 && !seq_kernel; --t) {
         const uint8_t* ok = io->out_keep ? io->out_keep + (size_t)(t + (fc ? 1 : 0)) * B * H : nullptr;
         float* dpre = g.dpre_all + (size_t)t * B * 5 * H;
         if (ps) {

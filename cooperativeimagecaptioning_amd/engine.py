@@ -175,6 +175,7 @@ def speaker_decode_bwd(dims, params, fwd, grads, att_raw, d_onehot=None, dslp=No
     bio.d_onehot, bio.dslp, bio.att_raw, bio.d_x0 = _p(d_onehot), _p(dslp), _p(att_raw), _p(d_x0)
     bio.grads = C.pointer(gp)
     bio.phase = int(phase)
+    bio.device_shared = 1 if DEVICE_SHARED[0] else 0
     ws = fwd['ws']
     check(lib.cic_speaker_decode_bwd(C.byref(dims), C.byref(params), C.byref(fwd['io']), C.byref(bio),
                                      ws.data_ptr(), ws.numel(), ws_bwd.data_ptr(), ws_bwd.numel(), stream()),

@@ -372,6 +372,8 @@ typedef struct {
      * everything after that (reads the d out the first call left in ws_bwd).  Partial-sampling decodes make their
      * d logits inside the time loop: phase 0 only. */
     int phase;
+    int device_shared;        /* != 0: other processes run kernels on this device at the same time.  The BPTT loop is then
+                                 launched step by step (its one-launch form needs all its workgroups resident together) */
 } cic_decode_bwd_io;
 enum { CIC_BWD_ALL = 0, CIC_BWD_LOGIT = 1, CIC_BWD_REST = 2 };
 size_t cic_speaker_decode_bwd_ws_bytes(const cic_speaker_dims* d);

@@ -35,6 +35,12 @@ int cic_debug_gates_att_fused(int on);
 int cic_debug_early_stop(int on);
 /* ... and 0 = the products of every BPTT step run although steps at or beyond the decode's length carry no gradient */
 int cic_debug_bptt_early_stop(int on);
+/* diagnostics: 0 = the speaker's BPTT loop as four launches per step instead of spk_bptt_seq_kernel (A/B timing, parity) */
+int cic_debug_bptt_seq(int on);
+/* diagnostics: phase stamps of spk_bptt_seq_kernel, [workgroup][step][8] s_memrealtime values (100 MHz) of lane 0: 0 step start,
+ * 1 cell backward stored, 2 first hand-off passed, 3 products done + d att_res stored, 4 second hand-off passed, 5 attention
+ * backward done, 6 third hand-off passed, 7 dh summed; NULL switches them off */
+int cic_debug_set_bptt_stamps(unsigned long long* buf);
 /* diagnostics: 2 (default) the whole GRU pass in one launch where the grid fits the chip, 1 one fused launch per step,
  * 0 every listener GRU step as a GEMM launch + a cell launch */
 int cic_debug_gru_fused(int on);
