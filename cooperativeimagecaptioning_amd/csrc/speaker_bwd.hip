@@ -529,10 +529,14 @@ __global__ __launch_bounds__(1024) void attn_bwd_cols_kernel(const float* __rest
 //       3. d att_h_t rows (A operand of the h2att part);
 //     the slabs they travel in are the workspace slabs the batched gradient products read after the loop anyway;
 //   * a wave's K slice covers the SAME columns 3H + 128 ks .. of dpre for a2c.W and for the (a, b) rows of h2h.W, so those A
-//     fragments are loaded once for both products; the dh product over the 5H columns of dpre runs together with the
-//     a2c product (it does not wait for the attention), only the h2att part follows the third hand-off;
+//     fragments are loaded once for both products; the (i, f, o) columns of the dh product wait for nothing but dpre_t and
+//     run while the attention results are on their way, only the h2att part follows the third hand-off;
 //   * the attention backward of the strip's 16 images runs on the 16 even-numbered workgroups of the strip (8 waves x 64
-//     columns; the region features are requested before the second hand-off is waited for).
+//     columns, two passes of 36 registers: att for d alpha - requested before the second hand-off is waited for -, then p_att);
+//     the odd workgroups do not wait for the second hand-off at all.
+// Measured (tools/bptt_stamps.py): 15.3 us per step against 31 us for the four launches; what is left are three dependent
+// fabric round trips per step (store - drain - counter - poll - load: ~3 us each).  Moving more of the dh product in front of
+// the attention (prefetching its fragments across it) cost registers and made every phase slower: 16.1 us.
 // Steps at or beyond the decode's length L carry no gradient (d out = 0, no carry): zeros are stored, no hand-off runs.
 // Every spin is bounded (20 ms): a workgroup that gives up raises *err and poisons what it produces with NaN.
 struct BpttArgs {
@@ -622,12 +626,16 @@ __global__ __launch_bounds__(KS * 64) void spk_bptt_seq_kernel(BpttArgs a) {
     float poison = 0.f;
     unsigned long long* stamps = CIC_STAMP_BUF(g_bptt_stamps);
 #define BPTT_STAMP(i) if (stamps && tid == 0) stamps[((size_t)blockIdx.x * T + t) * 8 + (i)] = __builtin_amdgcn_s_memrealtime()
-    // publish what this workgroup stored (add != 0) and wait until `target` workgroups of the strip have published
-    auto handoff = [&](unsigned* c, unsigned target, bool add) {
+    // hand-off, producer side: what this workgroup stored becomes visible, then ONE lane counts the workgroup in (add != 0)
+    auto publish = [&](unsigned* c, bool add) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // EVERY storing wave drains before the signal
         __syncthreads();
+        if (tid == 0 && add) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // ... consumer side: ONE lane polls until `target` workgroups of the strip have published; loads of handed-off bytes
+    // (all sc1) come after it
+    auto wait_for = [&](unsigned* c, unsigned target) {
         if (tid == 0) {
-            if (add) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             int ok = 1;
             while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
@@ -707,48 +715,24 @@ __global__ __launch_bounds__(KS * 64) void spk_bptt_seq_kernel(BpttArgs a) {
             continue;
         }
         BPTT_STAMP(1);
-        handoff(cnt + t * 3 + 0, TJ, true);
+        publish(cnt + t * 3 + 0, true);
+        wait_for(cnt + t * 3 + 0, TJ);
         BPTT_STAMP(2);
-        // ---- 2. d att_res = dpre[:, 3H:5H] a2c.W  and the dpre part of  dh = dpre h2h.W --------------------------------------
+        // ---- 2. the (a, b) gate columns of dpre_t: d att_res = dpre[:, 3H:5H] a2c.W and their part of dh = dpre h2h.W -----------
         f32x4acc_b acc_res = {0.f, 0.f, 0.f, 0.f}, acc_dh = {0.f, 0.f, 0.f, 0.f};
         {
-            // the wave's 20 k groups of dpre_t (8 of the (a, b) columns, 12 of the (i, f, o) columns; the latter only feed dh:
-            // not at t = 0) in chunks of 4, three chunks in flight
-            constexpr int GPC = 4, NBUF = 3;
-            const int nch = t > 0 ? (GA + GI) / GPC : GA / GPC;
-            f32x4 af[NBUF][GPC];
-            auto load_chunk = [&](int c) {
+            f32x4 af[GA];
 #pragma unroll
-                for (int i = 0; i < GPC; ++i) {
-                    const int gidx = c * GPC + i;
-                    const int kcol = gidx < GA ? 3 * H + 128 * ks + 16 * gidx : 192 * ks + 16 * (gidx - GA);
-                    af[c % NBUF][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                        r_dpre, (int)(((size_t)mc_t * H5 + kcol + 4 * lq_t) * 4), so5, 16));
-                }
-            };
+            for (int i = 0; i < GA; ++i)
+                af[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    r_dpre, (int)(((size_t)mc_t * H5 + 3 * H + 128 * ks + 16 * i + 4 * lq_t) * 4), so5, 16));
 #pragma unroll
-            for (int c = 0; c < NBUF; ++c)
-                if (c < nch) load_chunk(c);
+            for (int i = 0; i < GA; ++i) {
+                const f32x4 bw = wl[(ks * (GA + GC) + i) * 64 + lane_t];
 #pragma unroll
-            for (int c = 0; c < (GA + GI) / GPC; ++c) {
-                if (c < nch) {                               // wave-uniform
-#pragma unroll
-                    for (int i = 0; i < GPC; ++i) {
-                        const int gidx = c * GPC + i;
-                        if (gidx < GA) {
-                            const f32x4 bw = wl[(ks * (GA + GC) + (gidx < GA ? gidx : 0)) * 64 + lane_t];
-#pragma unroll
-                            for (int s = 0; s < 4; ++s) {
-                                acc_res = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c % NBUF][i][s], bw[s], acc_res, 0, 0, 0);
-                                acc_dh = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c % NBUF][i][s], wh_ab[gidx < GA ? gidx : 0][s], acc_dh, 0, 0, 0);
-                            }
-                        } else {
-#pragma unroll
-                            for (int s = 0; s < 4; ++s)
-                                acc_dh = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c % NBUF][i][s], wh_ifo[gidx >= GA ? gidx - GA : 0][s], acc_dh, 0, 0, 0);
-                        }
-                    }
-                    if (c + NBUF < nch) load_chunk(c + NBUF);
+                for (int s = 0; s < 4; ++s) {
+                    acc_res = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bw[s], acc_res, 0, 0, 0);
+                    acc_dh = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], wh_ab[i][s], acc_dh, 0, 0, 0);
                 }
             }
         }
@@ -763,12 +747,12 @@ __global__ __launch_bounds__(KS * 64) void spk_bptt_seq_kernel(BpttArgs a) {
             if (orow_t < B) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_dres, (int)(((size_t)orow_t * H + col_t) * 4), so1, 16);
         }
         BPTT_STAMP(3);
-        handoff(cnt + t * 3 + 1, TJ, true);
-        BPTT_STAMP(4);
-        // ---- 3. attention backward of image img (attn_bwd_cols_kernel, 8 waves x 64 columns) ----------------------------------
-        // Two passes over the image's regions, 36 registers each: att for d alpha, then p_att for d att_h (requested as soon
-        // as the att rows are consumed).  Buffer loads over the image's [K,H] block: one offset register per lane, the
-        // region group in the scalar offset, regions beyond K read as zeros (out of the resource's range).
+        publish(cnt + t * 3 + 1, true);
+        // ---- 3. attention backward of image img (attn_bwd_cols_kernel, 8 waves x 64 columns) on the even workgroups -------------
+        // Two passes over the image's regions, 36 registers each: att for d alpha (requested before the second hand-off is
+        // waited for: it depends on nothing), then p_att for d att_h (requested as soon as the att rows are consumed).  Buffer
+        // loads over the image's [K,H] block: one offset register per lane, the region group in the scalar offset, regions
+        // beyond K read as zeros (out of the resource's range).  The odd workgroups go straight on to part 4.
         const bool do_att = att_wg && img < B;
         if (att_wg) {
             constexpr int JMAX = 9;                          // regions 4 j + rg, K <= 36
@@ -778,6 +762,8 @@ __global__ __launch_bounds__(KS * 64) void spk_bptt_seq_kernel(BpttArgs a) {
             for (int j = 0; j < JMAX; ++j)
                 rv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_att, vo, 4 * j * H * 4, 0));
             const f32x4 ah4 = reinterpret_cast<const f32x4*>(a.att_h_all + rowH + (size_t)imc * H)[col4_t];
+            wait_for(cnt + t * 3 + 1, TJ);
+            BPTT_STAMP(4);
             const f32x4 dr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_dres, (int)(((size_t)imc * H + 4 * col4_t) * 4), so1, 16));
 #pragma unroll
             for (int j = 0; j < JMAX; ++j) {
@@ -823,12 +809,26 @@ __global__ __launch_bounds__(KS * 64) void spk_bptt_seq_kernel(BpttArgs a) {
             }
             if (rg_t == 0 && do_att)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_b, acc), r_dah, (int)(((size_t)img * H + 4 * col4_t) * 4), so1, 16);
+            BPTT_STAMP(5);
+            publish(cnt + t * 3 + 2, true);
         }
-        BPTT_STAMP(5);
-        handoff(cnt + t * 3 + 2, TJ / 2, att_wg);
-        BPTT_STAMP(6);
         if (t == 0) break;                                   // h_{-1} is the constant zero state: nothing flows further
-        // ---- 4. dh += d_att_h h2att.W, cross-wave sum -> this lane's dh of step t - 1 --------------------------------------------
+        // ---- 4. the (i, f, o) gate columns of dpre_t: the rest of dh = dpre h2h.W (nothing of it waits for the attention: it runs
+        //         while the strip's attention results are on their way) ----------------------------------------------------------
+        {
+            f32x4 af[GI];
+#pragma unroll
+            for (int i = 0; i < GI; ++i)
+                af[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    r_dpre, (int)(((size_t)mc_t * H5 + 192 * ks + 16 * i + 4 * lq_t) * 4), so5, 16));
+#pragma unroll
+            for (int i = 0; i < GI; ++i)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc_dh = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], wh_ifo[i][s], acc_dh, 0, 0, 0);
+        }
+        BPTT_STAMP(6);
+        wait_for(cnt + t * 3 + 2, TJ / 2);
+        // ---- 5. dh += d_att_h h2att.W, cross-wave sum -> this lane's dh of step t - 1 --------------------------------------------
         {
             f32x4 ac4[GC];
 #pragma unroll

@@ -41,10 +41,17 @@ step()
 torch.cuda.synchronize()
 lib.cic_debug_set_bptt_stamps(None)
 s = buf.cpu().numpy().reshape(nwg, T, 8).astype(np.float64) * 0.01     # us
-names = ['cell', 'hand-off 1', 'products + d att_res', 'hand-off 2', 'attention', 'hand-off 3', 'h2att + sum']
+# workgroup -> column tile: with 8 strips a strip sits on one XCD (blockIdx % 8) and jt = blockIdx // 8
+jt = np.arange(nwg) // 8 if (B // 16) == 8 else np.arange(nwg) % 32
+even = (jt % 2) == 0
 for t in (T - 1, T - 2, 8, 1):
     row = s[:, t, :]
-    d = [row[:, i + 1] - row[:, i] for i in range(7)]
-    print('step %2d: ' % t + '  '.join('%s %.2f (p90 %.2f)' % (n, np.median(x), np.percentile(x, 90)) for n, x in zip(names, d)))
+    def md(x):
+        return '%.2f (p90 %.2f)' % (np.median(x), np.percentile(x, 90))
+    e, o = row[even], row[~even]
+    print('step %2d: cell %s | hand-off 1 %s | (a,b) products + d att_res %s' % (t, md(row[:, 1] - row[:, 0]), md(row[:, 2] - row[:, 1]), md(row[:, 3] - row[:, 2])))
+    print('         even workgroups: publish + wait 2 %s | attention %s | publish 3 + (i,f,o) product %s | wait 3 %s' % (
+        md(e[:, 4] - e[:, 3]), md(e[:, 5] - e[:, 4]), md(e[:, 6] - e[:, 5]), md(s[even, t, 7] - e[:, 6])))
+    print('         odd workgroups: publish 2 + (i,f,o) product %s | wait 3 + h2att + sum %s' % (md(o[:, 6] - o[:, 3]), md(o[:, 7] - o[:, 6])))
 per = (s[:, 1, 0] - s[:, T - 1, 0]) / (T - 2)
-print('per step (us): median %.2f;  loop %.1f us' % (np.median(per), s[:, 0, 6].max() - s[:, T - 1, 0].min()))
+print('per step (us): median %.2f;  loop %.1f us' % (np.median(per), s[:, 0, 3].max() - s[:, T - 1, 0].min()))
