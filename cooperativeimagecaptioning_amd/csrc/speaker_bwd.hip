@@ -860,10 +860,17 @@ __global__ __launch_bounds__(KS * 64) void spk_bptt_seq_kernel(BpttArgs a) {
 //   d_att[b,k,:]   = sum_t alpha_t[b,k] * d_att_res_t[b,:]
 //   d_p_att[b,k,a] = w_a * sum_t ddot_t[b,k] * (1 - tanh^2(p_att[b,k,a] + att_h_t[b,a]))
 //   d w_alpha[a]  += sum_{t,b,k} ddot_t[b,k] * tanh(...),   d b_alpha += sum ddot
-// One workgroup per image; the per-step row vectors (att_h_t, d_att_res_t) and scalars of that
-// image are staged once in LDS (dynamic, T*(A+H+2K) floats) and re-used by all K regions.
-// NW waves per image: wave w owns regions w, w+NW, ... (12 waves x 3 regions at K = 36)
-template <int NI, int NW>
+// NSPLIT workgroups per image (each takes every NSPLIT-th group of NW regions); the per-step row vectors (att_h_t,
+// d_att_res_t) and scalars of the image are staged once in LDS (dynamic) and re-used by all its regions.
+// The kernel is bound by its transcendentals (T x K x A = 295 k tanh per image), so the exponential is taken OUT of the
+// (region, step) loop: with x = e^{-2(p + h)} = e^{-2p} e^{-2h},
+//     1 - tanh^2(p + h) = 4 / (x + 2 + 1/x),      tanh(p + h) = (1/x - x) / (x + 2 + 1/x),
+// and e^{-2p}, e^{2p} are made once per (region, column), e^{-2h}, e^{2h} once per (step, column) while the rows are staged:
+// the inner loop is two products, two sums and ONE reciprocal per element (before: an exponential and a reciprocal).  The
+// exponents are clamped to +-40, so no factor overflows and no 0 x inf arises; where the clamp acts the true derivative
+// and the computed one are both below 1e-15.
+__device__ __forceinline__ float clamp40(float x) { return fminf(fmaxf(x, -40.0f), 40.0f); }
+template <int NI, int NW, int NSPLIT, bool FACT>   // FACT: the factorised exponentials (needs 2 T A floats of LDS); else tanh per element
 __global__ __launch_bounds__(NW * 64) void attn_bwd_feats_kernel(const float* __restrict__ p_att, const float* __restrict__ att_h_all,
                                                              const float* __restrict__ d_att_res_all,
                                                              const float* __restrict__ alpha_all,
@@ -873,16 +880,27 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_feats_kernel(const float* __
                                                              float* __restrict__ db_alpha, int T, int B, int K, int A,
                                                              int H) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* s_ah = lds;                     // [T][A]
-    float* s_dr = s_ah + (size_t)T * A;    // [T][H]
+    float* s_eh = lds;                     // [T][A] e^{-2 att_h}  (FACT; else att_h itself)
+    float* s_ehi = s_eh + (size_t)T * A;   // [T][A] e^{+2 att_h}  (FACT only)
+    float* s_dr = s_ehi + (FACT ? (size_t)T * A : 0);   // [T][H]
     float* s_al = s_dr + (size_t)T * H;    // [T][K]
     float* s_dd = s_al + (size_t)T * K;    // [T][K]
     float* s_dw = s_dd + (size_t)T * K;    // [NW][NI*256] cross-wave reduce of dw_alpha
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.x / NSPLIT, part = blockIdx.x % NSPLIT, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int A4 = A >> 2, H4 = H >> 2;
     for (int i = tid; i < T * A4; i += NW * 64) {
         const int t = i / A4, c = i % A4;
-        reinterpret_cast<f32x4*>(s_ah)[i] = reinterpret_cast<const f32x4*>(att_h_all + ((size_t)t * B + b) * A)[c];
+        const f32x4 ah = reinterpret_cast<const f32x4*>(att_h_all + ((size_t)t * B + b) * A)[c];
+        if (!FACT) { reinterpret_cast<f32x4*>(s_eh)[i] = ah; continue; }
+        f32x4 e, ei;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float z = clamp40(2.0f * ah[q]);
+            e[q] = __expf(-z);
+            ei[q] = __expf(z);
+        }
+        reinterpret_cast<f32x4*>(s_eh)[i] = e;
+        reinterpret_cast<f32x4*>(s_ehi)[i] = ei;
     }
     for (int i = tid; i < T * H4; i += NW * 64) {
         const int t = i / H4, c = i % H4;
@@ -905,27 +923,45 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_feats_kernel(const float* __
         wa[i] = c < A4 ? reinterpret_cast<const f32x4*>(w_alpha)[c] : z4;
         dw[i] = z4;
     }
-    for (int k = w; k < K; k += NW) {
-        f32x4 p[NI], dp[NI], da[NI];
+    for (int k = w + NW * part; k < K; k += NW * NSPLIT) {
+        f32x4 ep[NI], epi[NI], dp[NI], da[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int c = lane + 64 * i;
-            p[i] = c < A4 ? reinterpret_cast<const f32x4*>(p_att + ((size_t)b * K + k) * A)[c] : z4;
+            const f32x4 p = c < A4 ? reinterpret_cast<const f32x4*>(p_att + ((size_t)b * K + k) * A)[c] : z4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float z = clamp40(2.0f * p[q]);
+                ep[i][q] = FACT ? __expf(-z) : p[q];
+                epi[i][q] = FACT ? __expf(z) : 0.f;
+            }
             dp[i] = z4;
             da[i] = z4;
         }
         for (int t = 0; t < T; ++t) {
             const float al = s_al[t * K + k], dd = s_dd[t * K + k];
+            const float dd4 = 4.0f * dd;
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int c = lane + 64 * i;
                 if (c < A4) {
-                    const f32x4 ah = reinterpret_cast<const f32x4*>(s_ah + (size_t)t * A)[c];
+                    const f32x4 eh = reinterpret_cast<const f32x4*>(s_eh + (size_t)t * A)[c];
+                    if (FACT) {
+                        const f32x4 ehi = reinterpret_cast<const f32x4*>(s_ehi + (size_t)t * A)[c];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float th = fast_tanh(p[i][e] + ah[e]);
-                        dp[i][e] += dd * (1.0f - th * th);
-                        dw[i][e] += dd * th;
+                        for (int e = 0; e < 4; ++e) {
+                            const float x = ep[i][e] * eh[e], xi = epi[i][e] * ehi[e];
+                            const float r = __builtin_amdgcn_rcpf((x + 2.0f) + xi);
+                            dp[i][e] += dd4 * r;                 // dd * (1 - tanh^2)
+                            dw[i][e] += dd * ((xi - x) * r);     // dd * tanh
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float th = fast_tanh(ep[i][e] + eh[e]);
+                            dp[i][e] += dd * (1.0f - th * th);
+                            dw[i][e] += dd * th;
+                        }
                     }
                 }
                 if (c < H4) da[i] += al * reinterpret_cast<const f32x4*>(s_dr + (size_t)t * H)[c];
@@ -952,8 +988,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_feats_kernel(const float* __
         for (int ww = 0; ww < NW; ++ww) s += s_dw[((ww * NI + i) * 64 + l) * 4 + e];
         atomicAdd(dw_alpha + a, s);
     }
-    bsum = wave_sum(bsum);
-    if (lane == 0) atomicAdd(db_alpha, bsum);
+    if (part == 0) {
+        bsum = wave_sum(bsum);
+        if (lane == 0) atomicAdd(db_alpha, bsum);
+    }
 }
 
 // dE[it[t,b], :] += dx[t,b,:] * [E[it] > 0] * keep * scale        (AttModel.py:74-76 reversed)
@@ -1248,19 +1286,21 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     {
         const int mx = A > H ? A : H;
         const int NIv = mx <= 256 ? 1 : (mx <= 512 ? 2 : 4);
-        dim3 grid(B);
-#define GO(NI, NWF)                                                                                                  \
+        // two workgroups of 6 waves per image (3 regions per wave at K = 36): 256 workgroups at B = 128, one per CU
+#define GO(NI, NWF, NSP, FACT)                                                                                       \
     do {                                                                                                             \
-        const size_t shm = sizeof(float) * ((size_t)T * (A + H + 2 * K) + (size_t)NWF * NI * 256);                   \
+        const size_t shm = sizeof(float) * ((size_t)T * ((FACT ? 2 : 1) * A + H + 2 * K) + (size_t)NWF * NI * 256);  \
         CIC_REQUIRE(shm <= 160 * 1024);                                                                              \
-        CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_feats_kernel<NI, NWF>),                  \
+        CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_feats_kernel<NI, NWF, NSP, FACT>),       \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));                          \
-        hipLaunchKernelGGL((attn_bwd_feats_kernel<NI, NWF>), grid, dim3(NWF * 64), shm, st, w.p_att, w.att_h_all,    \
+        hipLaunchKernelGGL((attn_bwd_feats_kernel<NI, NWF, NSP, FACT>), dim3(B * NSP), dim3(NWF * 64), shm, st, w.p_att, w.att_h_all, \
                            g.d_att_res_all, w.alpha_all, g.ddot_all, p->alpha_w, g.d_att, g.d_p_att, gr->alpha_w,    \
                            gr->alpha_b, T, B, K, A, H);                                                              \
     } while (0)
-        // 12 waves per image (3 regions each at K = 36); the widest rows keep 4 waves (LDS budget)
-        if (NIv == 1) GO(1, 12); else if (NIv == 2) GO(2, 12); else GO(4, 4);
+        const bool fact = sizeof(float) * ((size_t)T * (2 * A + H + 2 * K) + (size_t)6 * 2 * 256) <= 160 * 1024;
+        if (NIv == 1) { if (fact) GO(1, 6, 2, true); else GO(1, 6, 2, false); }
+        else if (NIv == 2) { if (fact) GO(2, 6, 2, true); else GO(2, 6, 2, false); }
+        else GO(4, 4, 1, false);
 #undef GO
         CIC_LAUNCH_CHECK();
     }
