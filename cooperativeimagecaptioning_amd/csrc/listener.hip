@@ -15,8 +15,9 @@
 
 namespace {
 
-// 2 = the whole GRU pass as one launch with W_hh stationary in registers (gru_seq_kernel; needs one resident workgroup per
-// 32-row strip x 16-unit tile, else 1); 1 = one fused launch per step; 0 = a GEMM + a cell launch per step.
+// 2 = the whole GRU pass (and its BPTT loop) as one launch each with W_hh stationary in the workgroups (gru_seq_kernel,
+// gru_seq_bwd_kernel; need one resident workgroup per 16-row strip x 32-unit tile, else 1); 1 = one fused launch per step;
+// 0 = a GEMM + a cell launch per step.
 // Development build: cic_debug_gru_fused(n) selects (A/B measurement, bit-exactness tests of 2 against 1).
 CIC_SWITCH(g_gru_fused, 2);
 #ifdef CIC_DEVTOOLS
@@ -214,16 +215,15 @@ __global__ __launch_bounds__(KS * 64) void gru_step_fused_kernel(const float* __
     }
 }
 
-// ---- the whole GRU pass in ONE launch: recurrent weights stationary in registers ------------------------------------
-// gru_step_fused_kernel re-streams its 196 KB weight tile (3 gates x 16 units x J floats) in every one of the Lp steps
-// although it never changes: the tile is exactly what the 8 waves of the workgroup can HOLD - 96 VGPRs per lane.  This
-// kernel is that step kernel with the time loop inside: same workgroup decomposition (32-row strip x 16-unit tile, K split
-// over 8 waves, one workgroup per CU, all of them resident), same MFMA order, same cross-wave sums, same gate arithmetic
-// - so h and gh come out bit for bit as from the per-step launches -, but W_hh is read once, there are no launch
-// boundaries, and a step moves only the strip's h rows (128 KB per workgroup).
+// ---- the whole GRU pass in ONE launch: recurrent weights stationary in the workgroups --------------------------------
+// gru_step_fused_kernel re-streams its weight tile (3 gates x 16 units x J floats) in every one of the Lp steps although it
+// never changes.  This kernel is that step kernel with the time loop inside and the weight tile held by the workgroup: same
+// per-element arithmetic (K split over 8 waves, same MFMA order, same cross-wave sums, same gate arithmetic) - so h and gh
+// come out bit for bit as from the per-step launches -, but W_hh is read once, there are no launch boundaries, and a step
+// moves only the strip's h rows (one workgroup per CU, all of them resident).
 //
-// What a step t >= 1 needs from OTHER workgroups is h_t of its own 32-row strip, written by the 64 workgroups of that
-// strip in step t-1.  Hand-off per strip and step (MI355X_MICROARCH.md, inter-workgroup visibility, first row of the sc1
+// What a step t >= 1 needs from OTHER workgroups is h_t of its own strip, written by the workgroups of that strip in
+// step t-1.  Hand-off per strip and step (MI355X_MICROARCH.md, inter-workgroup visibility, first row of the sc1
 // table; hipMalloc'ed memory, one workgroup per CU):
 //   producer: every lane stores its h element write-through (buffer_store ... sc1), every wave drains (s_waitcnt
 //             vmcnt(0)), workgroup barrier, ONE lane adds 1 to the strip's counter of step t+1 (agent-scope atomic);
@@ -234,44 +234,56 @@ __global__ __launch_bounds__(KS * 64) void gru_step_fused_kernel(const float* __
 // by the launcher, which otherwise uses the per-step kernel).  Every spin is bounded by a wall-clock budget: a workgroup
 // that gives up raises *err and poisons its outputs with NaN (the loss then says so) instead of hanging the device.
 constexpr unsigned long long GRU_SPIN_TICKS = 20ull * 100000ull;     // 20 ms of the 100 MHz s_memrealtime counter
+// Tiling (r3): a workgroup owns a 16-row strip x a 32-unit tile (its backward twin's shape): 8 strips x 32 tiles at B = 128, so
+// that the 32 workgroups of a strip share ONE XCD (blockIdx % 8: the hand-off stays inside an L2's reach; speed only) and a
+// step moves 64 KB of h rows per workgroup instead of 128.  The weight tile (3 gates x 32 units x J floats = 393 KB) is split:
+// GRUF_WR of a wave's 48 fragments in registers, the rest in LDS in fragment order.  Per element the arithmetic is unchanged
+// (same K slice per wave, same MFMA order, same cross-wave order), so the pass is still bit-identical to the per-step kernel.
+constexpr int GRUF_WR = 33, GRUF_WL = 48 - GRUF_WR;
+constexpr size_t GRUF_LDS_BYTES = sizeof(float) * ((size_t)8 * GRUF_WL * 64 * 4 + 2 * 8 * 8 * 64);
 template <int GPS, int KS>
 __global__ __launch_bounds__(KS * 64) void gru_seq_kernel(float* __restrict__ h_all, const float* __restrict__ W,
                                                           const float* __restrict__ b_hh, const float* __restrict__ gi_all,
                                                           const int32_t* __restrict__ len, float* __restrict__ gh_all,
-                                                          unsigned* __restrict__ sync, int B, int J, int Lp) {
-    static_assert(KS == 8, "8 accumulator registers (2 row tiles x 4) dealt one per wave");
-    __shared__ float red[2 * KS * 8 * 64];
+                                                          unsigned* __restrict__ cnt_base, unsigned* __restrict__ err, int B, int J, int Lp) {
+    static_assert(KS == 8 && GPS == 8, "J = 1024: 8 k groups of 16 per wave; 8 accumulator registers (2 unit tiles x 4) dealt one per wave");
+    constexpr int WR = GRUF_WR, WL = GRUF_WL;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    f32x4* wl = reinterpret_cast<f32x4*>(lds);            // [KS][WL][64] B fragments
+    float* red = lds + (size_t)KS * WL * 64 * 4;          // [2][KS][8][64]
     __shared__ int ok_s;
     const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
-    const int tiles_j = J / 16, strips = gridDim.x / tiles_j;
+    const int tiles_j = J / 32, strips = gridDim.x / tiles_j;
     int strip = blockIdx.x / tiles_j, jt = blockIdx.x % tiles_j;
     if (strips <= 8 && (8 % strips) == 0 && (tiles_j % (8 / strips)) == 0) {
         // speed only: blocks b and b + 8 share an XCD - the workgroups of a strip (they exchange h among themselves) on as few
-        // XCDs as possible (the poll of a step: 3.9 -> 2.4 us in the backward twin, tools/gru_stamps.py)
+        // XCDs as possible
         const int xs = 8 / strips, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
         strip = xcd / xs;
         jt = (xcd % xs) * (tiles_j / xs) + local;
     }
-    const int m0 = strip * 32;
-    const int col = jt * 16 + li;
-    const int orow = m0 + 16 * (ks >> 2) + 4 * lq + (ks & 3);
+    const int m0 = strip * 16;
+    const int col = jt * 32 + 16 * (ks >> 2) + li;        // the output this wave finishes: register ks & 3 of unit tile ks >> 2
+    const int orow = m0 + 4 * lq + (ks & 3);
     const int orc = orow < B ? orow : B - 1;
     const int ln = len[orc];
-    unsigned* cnt = sync + (size_t)strip * (Lp + 1);      // cnt[t]: workgroups of this strip that have published h_t
-    unsigned* err = sync + ((size_t)gridDim.x / tiles_j + (B + 15) / 16) * (Lp + 1);   // behind the forward and the backward counters
+    unsigned* cnt = cnt_base + (size_t)strip * (Lp + 1);  // cnt[t]: workgroups of this strip that have published h_t
     const size_t slab = (size_t)B * J;
-    // the weight tile, once: B fragments of the three gates for this wave's K slice
-    f32x4 wf[3][GPS];
+    // the weight tile, once: B fragments f = (gate g, unit tile ct, k group i) of this wave's K slice
+    f32x4 wf[WR];
 #pragma unroll
-    for (int g = 0; g < 3; ++g) {
-        const float* wrow = W + ((size_t)g * J + col) * J;
-#pragma unroll
-        for (int i = 0; i < GPS; ++i) wf[g][i] = *reinterpret_cast<const f32x4*>(wrow + 16 * (ks * GPS + i) + 4 * lq);
+    for (int f = 0; f < 48; ++f) {
+        const int g = f / 16, ct = (f / 8) & 1, i = f & 7;
+        const float* wrow = W + ((size_t)g * J + jt * 32 + 16 * ct + li) * J;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(wrow + 16 * (ks * GPS + i) + 4 * lq);
+        if (f < WR) wf[f < WR ? f : 0] = v;
+        else wl[(ks * WL + (f - WR)) * 64 + lane] = v;
     }
     const float bh0 = b_hh[col], bh1 = b_hh[J + col], bh2 = b_hh[2 * J + col];
     float poison = 0.f;
     if (orow < B) h_all[(size_t)orow * J + col] = 0.f;    // h_0 (read by the backward pass; this kernel never reads it)
+    __syncthreads();
     for (int t = 0; t < Lp; ++t) {
         const float* gi = gi_all + (size_t)t * B * 3 * J;
         float* gh_out = gh_all + (size_t)t * B * 3 * J;
@@ -298,29 +310,29 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_kernel(float* __restrict__ h_
             // h_t of the strip: every load of the handed-off bytes is sc1 (aux 16)
             const auto hsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(h_all + (size_t)t * slab), 0,
                                                                 (int)(slab * sizeof(float)), 0x00020000);
-            f32x4 af[2][GPS];
+            f32x4 af[GPS];
+            const int mc = min(m0 + li, B - 1);             // rows past B repeat row B-1: their sums are never stored
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                const int mc = min(m0 + 16 * rt + li, B - 1);
-#pragma unroll
-                for (int i = 0; i < GPS; ++i) {
-                    const int k = 16 * (ks * GPS + i) + 4 * lq;
-                    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(hsrc, (int)(((size_t)mc * J + k) * 4), 0, 16);
-                    af[rt][i] = __builtin_bit_cast(f32x4, raw);     // rows past B repeat row B-1: their sums are never stored
-                }
+            for (int i = 0; i < GPS; ++i) {
+                const int k = 16 * (ks * GPS + i) + 4 * lq;
+                af[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hsrc, (int)(((size_t)mc * J + k) * 4), 0, 16));
             }
             hp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hsrc, (int)(((size_t)orc * J + col) * 4), 0, 16));
-            __builtin_amdgcn_sched_barrier(0);      // all 16 KB of the wave's h rows are requested before the first MFMA waits
+            __builtin_amdgcn_sched_barrier(0);      // all of the wave's h rows are requested before the first MFMA waits
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
                 f32x4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < GPS; ++i)
+                for (int i = 0; i < GPS; ++i) {
+                    const int f0 = g * 16 + i, f1 = g * 16 + 8 + i;
+                    const f32x4 b0 = f0 < WR ? wf[f0 < WR ? f0 : 0] : wl[(ks * WL + (f0 < WR ? 0 : f0 - WR)) * 64 + lane];
+                    const f32x4 b1 = f1 < WR ? wf[f1 < WR ? f1 : 0] : wl[(ks * WL + (f1 < WR ? 0 : f1 - WR)) * 64 + lane];
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][i][s], wf[g][i][s], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][i][s], wf[g][i][s], acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], b0[s], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], b1[s], acc1, 0, 0, 0);
                     }
+                }
                 float* rb = red + (g & 1) * (KS * 8 * 64);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
@@ -808,7 +820,7 @@ LstWs lst_carve(const cic_listener_dims& d, void* base) {
     LstWs w;
     Carver c(base);
     const size_t B = d.B, J = d.J, E = d.E, Lp = d.Lp;
-    w.nsync = (int)(((B + 31) / 32 + (B + 15) / 16) * (Lp + 1) + 1);   // forward counters (32-row strips), backward counters (16-row strips), error word
+    w.nsync = (int)(2 * ((B + 15) / 16) * (Lp + 1) + 1);   // forward counters, backward counters (16-row strips each), error word
     w.sync = reinterpret_cast<unsigned*>(c.i32((size_t)(w.nsync + 3) / 4 * 4));
     w.idx = c.i32(B * Lp);
     w.len = c.i32(B);
@@ -931,11 +943,15 @@ static int listener_fwd_impl(const cic_listener_dims* dp, const cic_listener_par
         int dev = 0, cus = 0;
         CIC_HIP(hipGetDevice(&dev));
         CIC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        seq_kernel = cic_cdiv(B, 32) * (J / 16) <= cus;
+        seq_kernel = cic_cdiv(B, 16) * (J / 32) <= cus;
     }
     if (seq_kernel) {
-        hipLaunchKernelGGL((gru_seq_kernel<8, 8>), dim3(cic_cdiv(B, 32) * (J / 16)), dim3(512), 0, st, w.h_all, p->w_hh, p->b_hh,
-                           w.gi_all, w.len, w.gh_all, w.sync, B, J, Lp);
+        static DeviceOnce attr_set;
+        if (attr_set.first())
+            CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_kernel<8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)GRUF_LDS_BYTES));
+        hipLaunchKernelGGL((gru_seq_kernel<8, 8>), dim3(cic_cdiv(B, 16) * (J / 32)), dim3(512), GRUF_LDS_BYTES, st, w.h_all, p->w_hh, p->b_hh,
+                           w.gi_all, w.len, w.gh_all, w.sync, w.sync + 2 * (size_t)cic_cdiv(B, 16) * (Lp + 1), B, J, Lp);
         CIC_LAUNCH_CHECK();
     } else {
         CIC_HIP(hipMemsetAsync(w.h_all, 0, sizeof(float) * B * J, st));
@@ -994,7 +1010,7 @@ static int listener_bwd_impl(const cic_listener_dims* dp, const cic_listener_par
     CIC_HIP(hipMemsetAsync(w.dS, 0, sizeof(float) * B * B, st));
     hipLaunchKernelGGL(contrastive_bwd_kernel, dim3(cic_cdiv(B, 256)), dim3(256), 0, st, w.S, B, d.margin,
                        d.max_violation, sel_s, sel_im, bio->g_rows, bio->g_scalar, w.arg_s, w.arg_im, w.dS,
-                       w.sync + (size_t)cic_cdiv(B, 32) * (Lp + 1), cic_cdiv(B, 16) * (Lp + 1));
+                       w.sync + (size_t)cic_cdiv(B, 16) * (Lp + 1), cic_cdiv(B, 16) * (Lp + 1));
     CIC_LAUNCH_CHECK();
     // S = im cap^T  ->  d_im = dS cap,  d_cap = dS^T im
     RUN(gemm_nn(w.dS, B, w.cap_emb, J, w.d_img, J, B, J, B, false, st));
@@ -1026,7 +1042,7 @@ static int listener_bwd_impl(const cic_listener_dims* dp, const cic_listener_par
         if (attr_set.first())
             CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_bwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)GRUB_LDS_BYTES));
-        unsigned* cnt_b = w.sync + (size_t)cic_cdiv(B, 32) * (Lp + 1);
+        unsigned* cnt_b = w.sync + (size_t)cic_cdiv(B, 16) * (Lp + 1);
         hipLaunchKernelGGL((gru_seq_bwd_kernel<8>), dim3(cic_cdiv(B, 16) * (J / 32)), dim3(512), GRUB_LDS_BYTES, st, w.h_all, p->w_hh,
                            w.gi_all, w.gh_all, w.len, dh, w.dgi_all, w.dgh_all, cnt_b, cnt_b + (size_t)cic_cdiv(B, 16) * (Lp + 1), B, J,
                            Lp, d.pool, w.d_pool, w.pool_arg);
