@@ -99,7 +99,7 @@ class DecodeIO(C.Structure):
 
 class DecodeBwdIO(C.Structure):
     _fields_ = [('d_onehot', c_ptr), ('dslp', c_ptr), ('grads', C.POINTER(SpeakerParams)), ('att_raw', c_ptr),
-                ('d_x0', c_ptr), ('phase', C.c_int), ('device_shared', C.c_int)]
+                ('d_x0', c_ptr), ('phase', C.c_int), ('device_shared', C.c_int), ('dslp_scale', c_ptr)]
 
 
 BWD_ALL, BWD_LOGIT, BWD_REST = 0, 1, 2
@@ -145,7 +145,7 @@ class ListenerIO(C.Structure):
 
 class ListenerBwdIO(C.Structure):
     _fields_ = [('g_rows', c_ptr), ('g_scalar', c_ptr), ('grads', C.POINTER(ListenerParams)),
-                ('d_onehot', c_ptr)]
+                ('d_onehot', c_ptr), ('g_scale', C.c_float)]
 
 
 SAMPLE_NONE, SAMPLE_GREEDY, SAMPLE_MULTINOMIAL, SAMPLE_GUMBEL_ST, SAMPLE_MULTINOMIAL_ST, SAMPLE_TEACHER = range(6)

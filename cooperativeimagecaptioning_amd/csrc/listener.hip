@@ -766,43 +766,49 @@ __global__ __launch_bounds__(64) void contrastive_sum_kernel(const float* __rest
     }
     if (threadIdx.x == 0) *out_sum = s;
 }
-// dS from per-row upstream gradients g_rows[i] (scalar loss: all equal).  dS must be zeroed first.
+// dS from per-row upstream gradients g_rows[i] (scalar loss: all equal), one thread per entry of dS: what the reference's
+// autograd scatters (row i: +g at its hardest negative(s), -g on the diagonal) is gathered per (i, j) - no zero-fill of dS
+// before, no atomics, a fixed summation order.
 __global__ __launch_bounds__(256) void contrastive_bwd_kernel(const float* __restrict__ S, int B, float margin,
                                                               int max_violation, int sel_s, int sel_im,
                                                               const float* __restrict__ g_rows, const float* __restrict__ g_scalar,
-                                                              const int32_t* __restrict__ arg_s,
+                                                              float g_scale, const int32_t* __restrict__ arg_s,
                                                               const int32_t* __restrict__ arg_im, float* __restrict__ dS,
                                                               unsigned* __restrict__ sync_bwd, int nsync_bwd) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     // hand-off counters of gru_seq_bwd_kernel (the first kernel of the backward pass clears them: a second backward pass
     // over the same forward state starts from zero as well)
-    for (int k = i; k < nsync_bwd; k += gridDim.x * blockDim.x) sync_bwd[k] = 0u;
-    if (i >= B) return;
-    const float g = g_rows ? g_rows[i] : *g_scalar;
-    const float d = S[(size_t)i * B + i];
+    for (int k = idx; k < nsync_bwd; k += gridDim.x * blockDim.x) sync_bwd[k] = 0u;
+    if (idx >= B * B) return;
+    const int i = idx / B, j = idx % B;
+    auto G = [&](int r) { return (g_rows ? g_rows[r] : *g_scalar) * g_scale; };
+    float v = 0.f;
     if (max_violation) {
-        if (sel_s && arg_s[i] >= 0) {
-            atomicAdd(dS + (size_t)i * B + arg_s[i], g);
-            atomicAdd(dS + (size_t)i * B + i, -g);
-        }
-        if (sel_im && arg_im[i] >= 0) {
-            atomicAdd(dS + (size_t)arg_im[i] * B + i, g);
-            atomicAdd(dS + (size_t)i * B + i, -g);
+        // row r: dS[r][arg_s[r]] += g_r, dS[arg_im[r]][r] += g_r, dS[r][r] -= g_r for each of the two that exists
+        if (sel_s && arg_s[i] == j) v += G(i);
+        if (sel_im && arg_im[j] == i) v += G(j);
+        if (i == j) {
+            if (sel_s && arg_s[i] >= 0) v -= G(i);
+            if (sel_im && arg_im[i] >= 0) v -= G(i);
         }
     } else {
-        const float gb = g / (float)B;
-        for (int j = 0; j < B; ++j) {
-            if (j == i) continue;
-            if (sel_s && margin + S[(size_t)i * B + j] - d > 0.f) {
-                atomicAdd(dS + (size_t)i * B + j, gb);
-                atomicAdd(dS + (size_t)i * B + i, -gb);
-            }
-            if (sel_im && margin + S[(size_t)j * B + i] - d > 0.f) {
-                atomicAdd(dS + (size_t)j * B + i, gb);
-                atomicAdd(dS + (size_t)i * B + i, -gb);
+        // row r, every c != r: margin + S[r][c] - S[r][r] > 0: dS[r][c] += g_r / B, dS[r][r] -= g_r / B;
+        //                      margin + S[c][r] - S[r][r] > 0: dS[c][r] += g_r / B, dS[r][r] -= g_r / B
+        const float inv_b = 1.0f / (float)B;
+        if (i != j) {
+            const float sij = S[(size_t)i * B + j];
+            if (sel_s && margin + sij - S[(size_t)i * B + i] > 0.f) v += G(i) * inv_b;
+            if (sel_im && margin + sij - S[(size_t)j * B + j] > 0.f) v += G(j) * inv_b;
+        } else {
+            const float d = S[(size_t)i * B + i], gb = G(i) * inv_b;
+            for (int c = 0; c < B; ++c) {
+                if (c == i) continue;
+                if (sel_s && margin + S[(size_t)i * B + c] - d > 0.f) v -= gb;
+                if (sel_im && margin + S[(size_t)c * B + i] - d > 0.f) v -= gb;
             }
         }
     }
+    dS[idx] = v;
 }
 
 struct LstWs {
@@ -1007,10 +1013,9 @@ static int listener_bwd_impl(const cic_listener_dims* dp, const cic_listener_par
     int rc;
 #define RUN(x) if ((rc = (x)) != 0) return rc
     const int sel_s = io->only_one_retrieval != 1, sel_im = io->only_one_retrieval != 2;
-    CIC_HIP(hipMemsetAsync(w.dS, 0, sizeof(float) * B * B, st));
-    hipLaunchKernelGGL(contrastive_bwd_kernel, dim3(cic_cdiv(B, 256)), dim3(256), 0, st, w.S, B, d.margin,
-                       d.max_violation, sel_s, sel_im, bio->g_rows, bio->g_scalar, w.arg_s, w.arg_im, w.dS,
-                       w.sync + (size_t)cic_cdiv(B, 16) * (Lp + 1), cic_cdiv(B, 16) * (Lp + 1));
+    hipLaunchKernelGGL(contrastive_bwd_kernel, dim3(cic_cdiv(B * B, 256)), dim3(256), 0, st, w.S, B, d.margin,
+                       d.max_violation, sel_s, sel_im, bio->g_rows, bio->g_scalar, bio->g_scale != 0.f ? bio->g_scale : 1.0f,
+                       w.arg_s, w.arg_im, w.dS, w.sync + (size_t)cic_cdiv(B, 16) * (Lp + 1), cic_cdiv(B, 16) * (Lp + 1));
     CIC_LAUNCH_CHECK();
     // S = im cap^T  ->  d_im = dS cap,  d_cap = dS^T im
     RUN(gemm_nn(w.dS, B, w.cap_emb, J, w.d_img, J, B, J, B, false, st));

@@ -61,10 +61,17 @@ __global__ __launch_bounds__(SNW * 64) __attribute__((amdgpu_waves_per_eu(RV <= 
                                                           int u_philox, uint64_t u_seed, uint64_t u_elem0,
                                                           // != 0: the forward masked column seq[b, t-1] of row (t >= 1, b)
                                                           // to -inf before the log-softmax (AttModel.py:438-442)
-                                                          int decoding_constraint) {
+                                                          int decoding_constraint,
+                                                          // [1] factor on dslp (the upstream gradient of the loss) or null
+                                                          const float* __restrict__ dslp_scale,
+                                                          // hand-off counters of spk_bptt_seq_kernel, cleared here (this
+                                                          // launch precedes it on the stream) or null
+                                                          unsigned* __restrict__ zsync, int nzsync) {
     constexpr int NT = SNW * 64;
     __shared__ float sh[SNW];
     const int row = blockIdx.x, t = row / B, b = row % B, tid = threadIdx.x;
+    if (blockIdx.x == 0 && zsync)
+        for (int i = tid; i < nzsync; i += NT) zsync[i] = 0u;
     // the constrained column carries log p = -inf: y = 0, p = 0, no gradient (lse_all was taken without it; a row kernel
     // that stored log-probs wrote -inf there itself)
     const int cons = (decoding_constraint && seq && t >= 1) ? seq[(size_t)b * T + (t - 1)] : -1;
@@ -76,7 +83,7 @@ __global__ __launch_bounds__(SNW * 64) __attribute__((amdgpu_waves_per_eu(RV <= 
     // the log-prob that was gathered: the fed token, or the label under teacher forcing (scheduled sampling
     // may feed a different token than the target)
     const int it = target ? (int)target[(size_t)(t + 1) * B + b] : it_all[(size_t)(t + 1) * B + b];
-    const float ds = (dslp && t < L) ? dslp[(size_t)b * T + t] : 0.f;
+    const float ds = (dslp && t < L) ? dslp[(size_t)b * T + t] * (dslp_scale ? *dslp_scale : 1.0f) : 0.f;
     const bool st_mode = (mode == CIC_SAMPLE_GUMBEL_ST || mode == CIC_SAMPLE_MULTINOMIAL_ST);
     const bool unf = st_mode && g && seq && t < L && seq[(size_t)b * T + t] > 0;
     const int nq = (V1 + 3) >> 2;
@@ -1104,6 +1111,7 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     CIC_REQUIRE(!ps || (io->soft_raw && io->xpre && io->seq && (io->mode != CIC_SAMPLE_GUMBEL_PS || io->U)));
     const int phase = bio->phase;
     CIC_REQUIRE(phase == CIC_BWD_ALL || ((phase == CIC_BWD_LOGIT || phase == CIC_BWD_REST) && !ps));
+    CIC_REQUIRE(!bio->dslp_scale || !ps);     // the in-loop sampler backward of partial sampling takes dslp as it is
     const bool do_logit = phase != CIC_BWD_REST, do_rest = phase != CIC_BWD_LOGIT;
     GemmCtx st(cic_s(s), d.compute_dtype == CIC_DTYPE_BF16 ? CIC_PRECISION_BF16 : CIC_PRECISION_F32);
     const int B = d.B, K = d.K, H = d.H, E = d.E, A = d.A, T = d.T, V1 = d.V + 1, D = d.D;
@@ -1119,7 +1127,8 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         const int64_t* tgt = io->mode == CIC_SAMPLE_TEACHER ? io->pick : nullptr;
 #define GO(RV) hipLaunchKernelGGL((sampler_bwd_kernel<RV>), grid, blk, 0, st, w.logp_all, io->U, bio->d_onehot, w.it_all, \
                                   tgt, io->seq, bio->dslp, io->L, io->mode, io->temp, g.dlogits, T, B, V1, w.lse_all,        \
-                                  io->u_philox, io->u_seed, io->u_offset * 4ull, io->decoding_constraint)
+                                  io->u_philox, io->u_seed, io->u_offset * 4ull, io->decoding_constraint, bio->dslp_scale,   \
+                                  g.sync, (int)g.nsync)
         if (V1 <= 4096) GO(1); else if (V1 <= 12288) GO(3); else if (V1 <= 32768) GO(8);
         else { cic_set_error("vocabulary too large"); return 1; }
 #undef GO
@@ -1149,7 +1158,7 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         if (attr_set.first())
             CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spk_bptt_seq_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)BPTT_LDS_BYTES));
-        CIC_HIP(hipMemsetAsync(g.sync, 0, g.nsync * sizeof(unsigned), st));
+        // (the hand-off counters were cleared by sampler_bwd_kernel: the logit phase always precedes this one)
         BpttArgs ba = {};
         ba.pre_all = w.pre_all; ba.c_all = w.c_all; ba.alpha_all = w.alpha_all; ba.att_h_all = w.att_h_all;
         ba.p_att = w.p_att; ba.att = w.att; ba.out_keep = io->out_keep;

@@ -164,7 +164,7 @@ def speaker_decode_io(dims, params, att_pre, mode, temp=1.0, att_masks=None, att
 
 
 def speaker_decode_bwd(dims, params, fwd, grads, att_raw, d_onehot=None, dslp=None, ws_bwd=None, grad_params=None,
-                       d_x0=None, phase=0):
+                       d_x0=None, phase=0, dslp_scale=None):
     """Accumulates parameter gradients of one decode into `grads` (dict of tensors keyed like
     the parameters).  fwd: the dict returned by speaker_decode_fwd."""
     nbytes = lib.cic_speaker_decode_bwd_ws_bytes(C.byref(dims))
@@ -176,6 +176,7 @@ def speaker_decode_bwd(dims, params, fwd, grads, att_raw, d_onehot=None, dslp=No
     bio.grads = C.pointer(gp)
     bio.phase = int(phase)
     bio.device_shared = 1 if DEVICE_SHARED[0] else 0
+    bio.dslp_scale = _p(dslp_scale)      # f32[1] on the device: dslp is multiplied by it inside the sampler backward
     ws = fwd['ws']
     check(lib.cic_speaker_decode_bwd(C.byref(dims), C.byref(params), C.byref(fwd['io']), C.byref(bio),
                                      ws.data_ptr(), ws.numel(), ws_bwd.data_ptr(), ws_bwd.numel(), stream()),
@@ -250,9 +251,10 @@ def listener_fwd(dims, params, fc_feats, labels=None, masks=None, seq=None, stv=
     return out
 
 
-def listener_bwd(dims, params, fwd, g_rows=None, g_scalar=None, grads=None, d_onehot=None):
+def listener_bwd(dims, params, fwd, g_rows=None, g_scalar=None, grads=None, d_onehot=None, g_scale=1.0):
     bio = ListenerBwdIO()
     bio.g_rows, bio.g_scalar = _p(g_rows), _p(g_scalar)
+    bio.g_scale = float(g_scale)
     gp = listener_params(grads) if grads is not None else None
     bio.grads = C.pointer(gp) if gp is not None else None
     bio.d_onehot = _p(d_onehot)

@@ -218,8 +218,7 @@ class AlternatingJointModel(nn.Module):
                 d_onehot = cg._buf.get('d_onehot', (T, B, cg.vocab_size + 1), torch.float32, dev) if spk_grad else None
 
                 def bwd_listener(go, gen=gen, d_onehot=d_onehot):
-                    vse.run_backward(gen, g_scalar=(go * dw).reshape(1).contiguous(), param_grads=lst_grad,
-                                     d_onehot=d_onehot)
+                    vse.run_backward(gen, g_scalar=go.reshape(1), g_scale=dw, param_grads=lst_grad, d_onehot=d_onehot)
                 bwd_listener.is_listener = True
                 if spk_grad or lst_grad:
                     bwd_steps.append(bwd_listener)
@@ -258,8 +257,8 @@ class AlternatingJointModel(nn.Module):
             sample = None            # a partial-sampling decode without a CIDEr term: already queued above
         if sample is not None and spk_grad and (dslp is not None or getattr(sample, 'd_onehot', None) is not None):
             def bwd_speaker(go, logit_ready=None, sample=sample, dslp=dslp):
-                cg.decode_backward(sample, d_onehot=getattr(sample, 'd_onehot', None),
-                                   dslp=(dslp * go) if dslp is not None else None, logit_grads_ready=logit_ready)
+                cg.decode_backward(sample, d_onehot=getattr(sample, 'd_onehot', None), dslp=dslp,
+                                   dslp_scale=go if dslp is not None else None, logit_grads_ready=logit_ready)
             bwd_speaker.is_speaker = True
             bwd_steps.append(bwd_speaker)
 

@@ -212,14 +212,21 @@ class AttModel(nn.Module):
         self._ws[ws_key] = fwd['ws']
         return dims, params, fwd, (mode, att_raw, grad, ws_key)
 
-    def decode_backward(self, res, d_onehot=None, dslp=None, logit_grads_ready=None):
+    def decode_backward(self, res, d_onehot=None, dslp=None, logit_grads_ready=None, dslp_scale=None):
         """logit_grads_ready: called between the logit layer's backward and the BPTT loop (data-parallel runs start the
         all-reduce of the logit bucket there; only when this decode is the last one writing the logit gradient)."""
         fl = self.flat()
         if dslp is not None:
             dslp = self._buf.stage(('dslp_in', res.dims.T), dslp.contiguous(), torch.float32)
         key = ('bwd', res.dims.B, res.dims.K, res.dims.T)
-        kw = dict(d_onehot=d_onehot, dslp=dslp)
+        if dslp_scale is not None:
+            # the upstream gradient of the loss as a device scalar: applied inside the sampler backward (partial-sampling
+            # decodes run their sampler backward inside the time loop and take dslp as it is)
+            dslp_scale = dslp_scale.reshape(1)
+            if res.soft is not None or dslp is None or dslp_scale.dtype != torch.float32:
+                dslp = dslp * dslp_scale if dslp is not None else None
+                dslp_scale = None
+        kw = dict(d_onehot=d_onehot, dslp=dslp, dslp_scale=dslp_scale)
         if logit_grads_ready is not None and res.soft is None:
             self._ws[key] = engine.speaker_decode_bwd(res.dims, res.params, res.fwd, fl.grad_tensors(), res.att_raw,
                                                       ws_bwd=self._ws.get(key), phase=_lib.BWD_LOGIT, **kw)

@@ -159,8 +159,10 @@ class FCModel(nn.Module):
         return self._decode(fc_feats, mode, temp, T=T, pick=pick, first_token=first_token, grad=grad, tag=tag,
                             decoding_constraint=dc)
 
-    def decode_backward(self, res, d_onehot=None, dslp=None, logit_grads_ready=None):
+    def decode_backward(self, res, d_onehot=None, dslp=None, logit_grads_ready=None, dslp_scale=None):
         assert d_onehot is None and dslp is not None, 'the fc speaker receives gradient through its log-probabilities only'
+        if dslp_scale is not None:
+            dslp = dslp * dslp_scale
         self._decode_backward(res, dslp=dslp.contiguous())
         if logit_grads_ready is not None:
             logit_grads_ready()

@@ -132,14 +132,15 @@ class VSEFCModel(nn.Module):
         self._ws[key] = fwd['ws']
         return ListenerResult(fwd, dims, params)
 
-    def run_backward(self, res, g_scalar=None, g_rows=None, param_grads=True, d_onehot=None):
+    def run_backward(self, res, g_scalar=None, g_rows=None, param_grads=True, d_onehot=None, g_scale=1.0):
+        """g_scale: a host factor on the upstream gradient (a loss weight), applied inside the first backward kernel."""
         fl = self.flat()
         if g_scalar is not None:
             g_scalar = self._buf.stage('g_scalar', g_scalar.reshape(1), torch.float32)
         if g_rows is not None:
             g_rows = self._buf.stage('g_rows', g_rows.contiguous(), torch.float32)
         engine.listener_bwd(res.dims, res.params, res.fwd, g_rows=g_rows, g_scalar=g_scalar,
-                            grads=fl.grad_tensors() if param_grads else None, d_onehot=d_onehot)
+                            grads=fl.grad_tensors() if param_grads else None, d_onehot=d_onehot, g_scale=g_scale)
 
     def forward(self, fc_feats, att_feats, seq, masks, whole_batch=False, only_one_retrieval='off'):
         """models/VSEFCModel.py:230-241."""

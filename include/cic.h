@@ -374,6 +374,9 @@ typedef struct {
     int phase;
     int device_shared;        /* != 0: other processes run kernels on this device at the same time.  The BPTT loop is then
                                  launched step by step (its one-launch form needs all its workgroups resident together) */
+    const float* dslp_scale;  /* [1] on the device or NULL: dslp is multiplied by it (the upstream gradient of the scalar loss:
+                                 loss.backward() hands it over as a device scalar; no elementwise launch for dslp * go).  Not with
+                                 partial-sampling decodes */
 } cic_decode_bwd_io;
 enum { CIC_BWD_ALL = 0, CIC_BWD_LOGIT = 1, CIC_BWD_REST = 2 };
 size_t cic_speaker_decode_bwd_ws_bytes(const cic_speaker_dims* d);
@@ -452,6 +455,7 @@ typedef struct {
     const cic_listener_params* grads; /* accumulated into (+=); NULL = no parameter gradients */
     float* d_onehot;              /* out [T, B, V+1] gradient w.r.t. the one-hot rows of the generated
                                      tokens (time-major), or NULL */
+    float g_scale;                /* factor on g_rows / g_scalar (a loss weight); 0 counts as 1 */
 } cic_listener_bwd_io;
 
 size_t cic_listener_ws_bytes(const cic_listener_dims* d);
