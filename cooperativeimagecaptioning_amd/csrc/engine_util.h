@@ -67,6 +67,7 @@ int cic_finalize_len2(Dual<const int> any_unfinished, int T, Dual<int> L, int nb
 int cic_sample_finish2(const cic_sampler_args* a, const float* part_a, int part_rows_a, float* lse_a,
                        const cic_sampler_args* b, const float* part_b, int part_rows_b, float* lse_b, int np, hipStream_t st);
 // dropout of the embedded regions with ragged region counts: rows beyond an image's own regions become 0
+int cic_apply_keep2(const float* x, Dual<const uint8_t> keep, float p_drop, Dual<float> y, int64_t n, hipStream_t st);
 int cic_att_keep_rows(const float* x, const uint8_t* keep, float p_drop, const float* masks, float* y, int B, int K, int H,
                       hipStream_t st);
 int cic_relu_keep_fwd(const float* xpre, const uint8_t* keep, float p_drop, float* x, int64_t n, hipStream_t st);

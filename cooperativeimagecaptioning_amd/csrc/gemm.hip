@@ -2257,8 +2257,9 @@ int launch_shape(const cic_gemm_args& g, bool vec, bool want_tail, hipStream_t s
         if (ks >= 2) full = tiles - tail; else ks = 1;
     }
     const int grid = full + (tiles - full) * ks;
-    if (ks > 1 && !g.accumulate) {
-        // the sliced tiles sum into C: zero the rows x columns they cover (whole C when everything is tail)
+    if (ks > 1 && !g.accumulate && !g.c_is_zero) {
+        // the sliced tiles sum into C: zero the rows x columns they cover (whole C when everything is tail), unless the caller
+        // (or the kernel that produced the operands) has cleared C already
         if (full == 0) {
             CIC_HIP(hipMemset2DAsync(g.C, sizeof(float) * g.ldc, 0, sizeof(float) * g.N, g.M, st));
         } else {

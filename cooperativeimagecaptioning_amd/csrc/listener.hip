@@ -400,7 +400,10 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_bwd_kernel(const float* __res
                                                               float* __restrict__ dgi_all, float* __restrict__ dgh_all,
                                                               unsigned* __restrict__ cnt_base, unsigned* __restrict__ err,
                                                               int B, int J, int Lp, int pool, const float* __restrict__ d_pool,
-                                                              const int32_t* __restrict__ pool_arg) {
+                                                              const int32_t* __restrict__ pool_arg,
+                                                              // [Lp,B,zero_n] cleared on the way (zero_n <= J: the K-sliced product
+                                                              // dx_emb = dgi W_ih after the loop adds into it), or null
+                                                              float* __restrict__ zero_lbe, int zero_n) {
     static_assert(KS == 8, "8 accumulator registers (2 column tiles x 4) dealt one per wave");
     constexpr int GPS = GRUB_GPS, GR = GRUB_GR, GL = GRUB_GL;
     constexpr int GPC = 4, NCH = GPS / GPC, NBUF = 3;     // the A rows arrive in chunks of GPC groups, NBUF chunks in flight
@@ -457,6 +460,7 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_bwd_kernel(const float* __res
         float* dgi = dgi_all + (size_t)t * gslab;
         float* dgh = dgh_all + (size_t)t * gslab;
         const auto hdst = __builtin_amdgcn_make_buffer_rsrc(dgh, 0, (int)(gslab * sizeof(float)), 0x00020000);
+        if (zero_lbe && orow < B && col < zero_n) zero_lbe[((size_t)t * B + orow) * zero_n + col] = 0.f;
         if (t >= smax) {
             // no caption of the strip reaches step t: zero gate gradients, d passes through (no pooled term either)
             if (orow < B) {
@@ -1050,7 +1054,7 @@ static int listener_bwd_impl(const cic_listener_dims* dp, const cic_listener_par
         unsigned* cnt_b = w.sync + (size_t)cic_cdiv(B, 16) * (Lp + 1);
         hipLaunchKernelGGL((gru_seq_bwd_kernel<8>), dim3(cic_cdiv(B, 16) * (J / 32)), dim3(512), GRUB_LDS_BYTES, st, w.h_all, p->w_hh,
                            w.gi_all, w.gh_all, w.len, dh, w.dgi_all, w.dgh_all, cnt_b, cnt_b + (size_t)cic_cdiv(B, 16) * (Lp + 1), B, J,
-                           Lp, d.pool, w.d_pool, w.pool_arg);
+                           Lp, d.pool, w.d_pool, w.pool_arg, E <= J ? w.dx_emb : nullptr, E);
         CIC_LAUNCH_CHECK();
     }
     for (int t = Lp - 1; t >= 0 && !seq_kernel; --t) {
@@ -1069,7 +1073,7 @@ static int listener_bwd_impl(const cic_listener_dims* dp, const cic_listener_par
     }
     if ((g && g->embed_w) || bio->d_onehot) {
         // dx_emb = dgi W_ih            [Lp*B, 3J] x [3J, E]
-        RUN(gemm_nn(w.dgi_all, 3 * J, p->w_ih, E, w.dx_emb, E, Lp * B, E, 3 * J, false, st));
+        RUN(gemm_nn(w.dgi_all, 3 * J, p->w_ih, E, w.dx_emb, E, Lp * B, E, 3 * J, false, st, true, seq_kernel && E <= J));   // (cleared by the BPTT kernel)
         if (g && g->embed_w) {
             const int64_t n = (int64_t)Lp * B * E;
             hipLaunchKernelGGL(embed_st_bwd_kernel, dim3(cic_cdiv(n, 256)), dim3(256), 0, st, w.dx_emb, w.idx, w.val,

@@ -66,12 +66,17 @@ __global__ __launch_bounds__(SNW * 64) __attribute__((amdgpu_waves_per_eu(RV <= 
                                                           const float* __restrict__ dslp_scale,
                                                           // hand-off counters of spk_bptt_seq_kernel, cleared here (this
                                                           // launch precedes it on the stream) or null
-                                                          unsigned* __restrict__ zsync, int nzsync) {
+                                                          unsigned* __restrict__ zsync, int nzsync,
+                                                          // [T*B, zrow_n] cleared here for the K-sliced product d out = d logits W
+                                                          // that follows (its partial tiles are added into it), or null
+                                                          float* __restrict__ zrow, int zrow_n) {
     constexpr int NT = SNW * 64;
     __shared__ float sh[SNW];
     const int row = blockIdx.x, t = row / B, b = row % B, tid = threadIdx.x;
     if (blockIdx.x == 0 && zsync)
         for (int i = tid; i < nzsync; i += NT) zsync[i] = 0u;
+    if (zrow)
+        for (int i = tid; i < zrow_n; i += NT) zrow[(size_t)row * zrow_n + i] = 0.f;
     // the constrained column carries log p = -inf: y = 0, p = 0, no gradient (lse_all was taken without it; a row kernel
     // that stored log-probs wrote -inf there itself)
     const int cons = (decoding_constraint && seq && t >= 1) ? seq[(size_t)b * T + (t - 1)] : -1;
@@ -552,6 +557,7 @@ struct BpttArgs {
     const float *a2c_w, *h2h_w, *h2att_w, *alpha_w;
     const float* d_out_all;                                                 // [T,B,H]
     float *dpre_all, *d_att_res_all, *d_att_h_all, *ddot_all;               // [T,B,5H] [T,B,H] [T,B,H] [T,B,K]
+    float* zero_tbh;                                                        // [T,B,H] cleared on the way (d x of the batched product after the loop) or null
     unsigned *cnt, *err;                                                    // [strips][T][3] counters (zeroed by the launcher), 1 word
     const int32_t* L;                                                       // the decode's length on the device, or null
     float scale;
@@ -712,6 +718,7 @@ __global__ __launch_bounds__(KS * 64) void spk_bptt_seq_kernel(BpttArgs a) {
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ga), r_dpre, o + 12 * H, so5, 16);
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gb), r_dpre, o + 16 * H, so5, 16);
                 if (!live) { dres[(size_t)orow_t * H + col_t] = 0.f; dah[(size_t)orow_t * H + col_t] = 0.f; }
+                if (a.zero_tbh) a.zero_tbh[rowH + (size_t)orow_t * H + col_t] = 0.f;
             }
         }
         if (!live) {            // grid-uniform: nothing but zeros flows through this step (dpre above came out as zeros)
@@ -1128,14 +1135,14 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
 #define GO(RV) hipLaunchKernelGGL((sampler_bwd_kernel<RV>), grid, blk, 0, st, w.logp_all, io->U, bio->d_onehot, w.it_all, \
                                   tgt, io->seq, bio->dslp, io->L, io->mode, io->temp, g.dlogits, T, B, V1, w.lse_all,        \
                                   io->u_philox, io->u_seed, io->u_offset * 4ull, io->decoding_constraint, bio->dslp_scale,   \
-                                  g.sync, (int)g.nsync)
+                                  g.sync, (int)g.nsync, g.d_out_all, H)
         if (V1 <= 4096) GO(1); else if (V1 <= 12288) GO(3); else if (V1 <= 32768) GO(8);
         else { cic_set_error("vocabulary too large"); return 1; }
 #undef GO
         CIC_LAUNCH_CHECK();
     }
     // 2. logit layer, batched over time: d_out = dlogits W,  dW += dlogits^T out,  db += colsum
-    if (!ps && do_logit) RUN(gemm_nn(g.dlogits, V1, p->logit_w, H, g.d_out_all, H, T * B, H, V1, false, st));
+    if (!ps && do_logit) RUN(gemm_nn(g.dlogits, V1, p->logit_w, H, g.d_out_all, H, T * B, H, V1, false, st, true, true));   // (cleared by the sampler backward)
 
     // 2b. the logit layer's weight gradient needs only d logits and the saved outputs (a side stream for it beside the
     //     latency-bound BPTT loop measured slower than one stream - its workgroups hold the CUs the loop's short kernels
@@ -1167,6 +1174,7 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         ba.d_att_h_all = g.d_att_h_all; ba.ddot_all = g.ddot_all;
         ba.cnt = g.sync; ba.err = g.sync + (size_t)cic_cdiv(B, 16) * T * 3;
         ba.L = g_bptt_early_stop ? io->L : nullptr;
+        ba.zero_tbh = (E == H && !ps) ? g.dx_all : nullptr;       // the K-sliced d x product after the loop adds into it
         ba.scale = scale; ba.B = B; ba.K = K; ba.T = T;
         hipLaunchKernelGGL((spk_bptt_seq_kernel<8>), dim3(cic_cdiv(B, 16) * (H / 16)), dim3(512), BPTT_LDS_BYTES, st, ba);
         CIC_LAUNCH_CHECK();
@@ -1279,7 +1287,7 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         RUN(cic_colsum_f32(g.dpre_img, B, 5 * H, 5 * H, gr->h2h_b, 1, s));
     }
     // token embedding: dx = dpre i2h.W, scattered into the embedding rows
-    if (!ps) RUN(gemm_nn(g.dpre_all, 5 * H, p->i2h_w, E, g.dx_all, E, T * B, E, 5 * H, false, st));
+    if (!ps) RUN(gemm_nn(g.dpre_all, 5 * H, p->i2h_w, E, g.dx_all, E, T * B, E, 5 * H, false, st, true, seq_kernel && E == H));
     {
         // partial sampling: only step 0 reads an embedding row (<bos>); steps >= 1 used soft_raw[t-1] @ embed
         const int rows = ps ? B : T * B;

@@ -211,11 +211,18 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
                            BH4, B, T + 1, 5 * H, d.V + 1);
         CIC_LAUNCH_CHECK();
     }
+    // a pair over the same embedded regions, no ragged masks: both dropouts in one launch
+    const bool keep2 = nb == 2 && !fc && !io[0]->att_masks && !io[1]->att_masks && io[0]->att_pre == io[1]->att_pre &&
+                       (io[0]->att_keep != nullptr) == (io[1]->att_keep != nullptr);
+    if (keep2)
+        RUN(cic_apply_keep2(io[0]->att_pre, Dual<const uint8_t>{io[0]->att_keep, io[1]->att_keep}, io[0]->att_keep ? p_drop : 0.f,
+                            Dual<float>{w[0].att, w[1].att}, (int64_t)B * K * H, st));
     for (int q = 0; q < nb; ++q) {
         if (!fc) {
             // att = dropout(relu(att_embed(att_raw)));  p_att = ctx2att(att)      (AttModel.py:315,319)
             // with att_masks: only an image's own region rows are embedded, the padded rows are 0   (:44-51)
-            if (io[q]->att_masks) {
+            if (keep2) {
+            } else if (io[q]->att_masks) {
                 RUN(cic_att_keep_rows(io[q]->att_pre, io[q]->att_keep, io[q]->att_keep ? p_drop : 0.f, io[q]->att_masks, w[q].att,
                                       B, K, H, st));
             } else {

@@ -462,6 +462,21 @@ __global__ __launch_bounds__(256) void apply_keep_kernel(const float* __restrict
     reinterpret_cast<f32x4*>(y)[idx] = v;
 }
 
+// ... for the two decodes of a pair in ONE launch (blockIdx.y picks the decode: same x, its own mask and output)
+__global__ __launch_bounds__(256) void apply_keep2_kernel(const float* __restrict__ x, Dual<const uint8_t> keep, float scale,
+                                                          Dual<float> y, int64_t n4) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n4) return;
+    const uint8_t* kq = keep.sel(blockIdx.y != 0);
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[idx];
+    if (kq) {
+        const uint32_t kp = *reinterpret_cast<const uint32_t*>(kq + idx * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * ((float)((kp >> (8 * e)) & 0xffu) * scale);
+    }
+    reinterpret_cast<f32x4*>(y.sel(blockIdx.y != 0))[idx] = v;
+}
+
 // Ragged region counts (att_masks != None): pack_wrapper (models/AttModel.py:30-51) embeds only the first
 // len_b = sum_k att_masks[b,k] region rows of image b and pads the rest back with ZEROS, so rows k >= len_b of the
 // embedded features are 0 (not relu(bias)):  y[b,k,:] = k < len_b ? x * keep * scale : 0
@@ -1230,6 +1245,13 @@ extern "C" int cic_apply_keep(const float* x, const uint8_t* keep, float p_drop,
     CIC_REQUIRE(x && y && n > 0 && (n & 3) == 0);
     hipLaunchKernelGGL(apply_keep_kernel, dim3(cic_cdiv(n / 4, 256)), dim3(256), 0, cic_s(s), x, keep,
                        1.0f / (1.0f - p_drop), y, n / 4);
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+
+int cic_apply_keep2(const float* x, Dual<const uint8_t> keep, float p_drop, Dual<float> y, int64_t n, hipStream_t st) {
+    CIC_REQUIRE(x && y.a && y.b && n > 0 && (n & 3) == 0);
+    hipLaunchKernelGGL(apply_keep2_kernel, dim3(cic_cdiv(n / 4, 256), 2), dim3(256), 0, st, x, keep, 1.0f / (1.0f - p_drop), y, n / 4);
     CIC_LAUNCH_CHECK();
     return 0;
 }

@@ -135,6 +135,7 @@ class AttModel(nn.Module):
     def decode(self, att_feats, att_masks, mode, temp=1.0, **kw):
         """One AttModel.sample / AttModel.forward pass on the device -> DecodeResult."""
         dims, params, io, (mode, att_raw, grad, ws_key) = self._decode_io(att_feats, att_masks, mode, temp, **kw)
+        self.noise.flush()
         engine.speaker_decode_launch(dims, params, io)
         return DecodeResult(io, mode, dims, params, att_raw, grad)
 
@@ -146,6 +147,7 @@ class AttModel(nn.Module):
         rb = self._decode_io(att_feats, att_masks, att_pre=att_pre, **spec_b)
         (dims, params, ia, (ma, att_raw, ga, _)), (dims_b, _, ib, (mb, _, gb, _)) = ra, rb
         assert (dims.B, dims.K, dims.T) == (dims_b.B, dims_b.K, dims_b.T), 'paired decodes share their shapes'
+        self.noise.flush()                       # the dropout masks of both decodes: one launch
         engine.speaker_decode_fwd_pair(dims, params, ia, ib)
         self.last_pair_fused = engine.speaker_decode_pair_fused(dims, ia, ib)   # reported by bench.py / train.py
         return DecodeResult(ia, ma, dims, params, att_raw, ga), DecodeResult(ib, mb, dims_b, params, att_raw, gb)

@@ -17,9 +17,19 @@ class NoiseSource:
         self.counter = 0          # Philox offset in units of 2^32 calls: one fresh sub-stream per tensor
         self.override = None      # {tag: {att_keep,x_keep,out_keep,gumbel_u,pick}} numpy/torch arrays
         self._buf = {}            # persistent device buffers
+        self._pending = []        # dropout masks requested but not yet drawn: (mask, p, Philox offset); see flush()
 
     def manual_seed(self, seed):
         self.seed, self.counter = int(seed), 0
+
+    def flush(self):
+        """Draw the dropout masks requested since the last flush (callers: right before the decode engine is launched)."""
+        pend, self._pending = self._pending, []
+        while pend:
+            p = pend[0][1]
+            chunk = [x for x in pend if x[1] == p][:8]          # one launch takes up to 8 masks of one keep probability
+            pend = [x for x in pend if not any(x is c for c in chunk)]
+            ops.dropout_keep_multi_([m for m, _, _ in chunk], p, self.seed, [o for _, _, o in chunk])
 
     def _next_offset(self):
         self.counter += 1
@@ -63,7 +73,9 @@ class NoiseSource:
             # the three masks of the decode in one launch, each from its own Philox sub-stream
             keys = (('att_keep', (B, K, H)), ('x_keep', (T + 1, B, E)), ('out_keep', (T + 1, B, H)))
             masks = [self._get((tag, key), shape, torch.uint8, device) for key, shape in keys]
-            ops.dropout_keep_multi_(masks, p, self.seed, [self._next_offset() for _ in keys])
+            # drawn by flush(): the masks of ALL decodes of a launch (a decode pair: six) come from one kernel launch; each
+            # keeps the Philox sub-stream it is assigned here, so the numbers do not depend on how launches are grouped
+            self._pending += [(m, p, self._next_offset()) for m in masks]
             out.update({key: t for (key, _), t in zip(keys, masks)})
         if need_u and u_in_kernel:
             out['u_stream'] = (self.seed, self._next_offset())
