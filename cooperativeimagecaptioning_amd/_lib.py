@@ -94,7 +94,8 @@ class DecodeIO(C.Structure):
                 ('ss_u', c_ptr), ('ss_prob', C.c_float),
                 ('ss_pick', c_ptr), ('fc_mode', C.c_int), ('x0', c_ptr), ('first_token', c_ptr),
                 ('seq', c_ptr), ('slp', c_ptr), ('stv', c_ptr), ('L', c_ptr),
-                ('u_philox', C.c_int), ('u_seed', C.c_uint64), ('u_offset', C.c_uint64), ('timer', c_ptr)]
+                ('u_philox', C.c_int), ('u_seed', C.c_uint64), ('u_offset', C.c_uint64), ('timer', c_ptr),
+                ('device_shared', C.c_int)]
 
 
 class DecodeBwdIO(C.Structure):

@@ -33,6 +33,7 @@ struct SpkWs {
     uint16_t *att_bf, *p_att_bf;              // bf16 copies of att / p_att (compute_dtype bf16 only)
     float *part, *lse_all;                    // row partials of one step's logits [6][B][nparts]; [T,B] log-sum-exp rows
     uint16_t* logit_parts;                    // [3][V+1][H] bf16: the logit weights cut into their parts once per decode
+    unsigned* tsync;                          // spk_teacher_seq_kernel: [strips of 16 rows][T][3] hand-off counters + error word
     size_t bytes;
 };
 SpkWs spk_carve(const cic_speaker_dims& d, void* base);
@@ -67,6 +68,17 @@ int cic_finalize_len2(Dual<const int> any_unfinished, int T, Dual<int> L, int nb
 int cic_sample_finish2(const cic_sampler_args* a, const float* part_a, int part_rows_a, float* lse_a,
                        const cic_sampler_args* b, const float* part_b, int part_rows_b, float* lse_b, int np, hipStream_t st);
 // dropout of the embedded regions with ragged region counts: rows beyond an image's own regions become 0
+// the teacher-forced recurrence of a decode as ONE launch (speaker_fwd.hip: spk_teacher_seq_kernel)
+struct TeacherSeqLaunch {
+    const float *h2h_w, *h2att_w, *h2att_b, *a2c_w, *a2c_b, *alpha_w, *alpha_b, *p_att, *att, *masks;
+    const uint8_t* out_keep;
+    float *pre_all, *h_all, *c_all, *att_h_all, *att_res_all, *alpha_all, *dot_all, *out_all;
+    unsigned* sync;           // cic_cdiv(B, 16) * T * 3 + 1 words
+    float scale;
+    int B, K, T;
+};
+bool cic_teacher_seq_ok(int B, int K, int H, int A, int E);
+int cic_teacher_seq(const TeacherSeqLaunch& L, hipStream_t st);
 int cic_apply_keep2(const float* x, Dual<const uint8_t> keep, float p_drop, Dual<float> y, int64_t n, hipStream_t st);
 int cic_att_keep_rows(const float* x, const uint8_t* keep, float p_drop, const float* masks, float* y, int B, int K, int H,
                       hipStream_t st);

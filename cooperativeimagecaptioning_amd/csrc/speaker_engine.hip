@@ -10,6 +10,7 @@ namespace {
 
 CIC_SWITCH(g_early_stop, 1);         // development build: cic_debug_early_stop(0) = every step of a decode runs in full (A/B)
 CIC_SWITCH(g_gates_att_fused, 1);   // development build: cic_debug_gates_att_fused(0) = separate h2att launch (A/B timing)
+CIC_SWITCH(g_teacher_seq, 1);       // development build: cic_debug_teacher_seq(0) = the teacher-forced recurrence as three launches per step (A/B, parity)
 
 __global__ void fill_i32_kernel(int32_t* p, int n, int32_t v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(256) void decode_init_kernel(DecodeInit a, DecodeIn
 #ifdef CIC_DEVTOOLS
 extern "C" int cic_debug_gates_att_fused(int on) { g_gates_att_fused = on; return 0; }
 extern "C" int cic_debug_early_stop(int on) { g_early_stop = on; return 0; }
+extern "C" int cic_debug_teacher_seq(int on) { g_teacher_seq = on; return 0; }
 #endif
 
 int cic_fill_i32(int32_t* p, int n, int32_t v, hipStream_t st) {
@@ -100,6 +102,7 @@ SpkWs spk_carve(const cic_speaker_dims& d, void* base) {
     w.part = c.f32((size_t)CIC_PART_PLANES * CIC_PART_MAX_ENTRIES);
     w.lse_all = c.f32(T * B);
     w.logit_parts = c.u16(3 * V1 * H);
+    w.tsync = reinterpret_cast<unsigned*>(c.i32((((B + 15) / 16) * T * 3 + 1 + 3) / 4 * 4));
     w.bytes = c.used();
     return w;
 }
@@ -262,13 +265,28 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     // rows after it (one LDS-tiled GEMM instead of T walker launches and T sampler launches).
     const bool teacher_batched = nb == 1 && !fc && !ps && io[0]->mode == CIC_SAMPLE_TEACHER && io[0]->pick &&
                                  !(io[0]->ss_u && io[0]->ss_prob > 0.f) && (int64_t)T * B <= CIC_PART_MAX_ENTRIES;
+    // ... and at the flagship widths the recurrence itself is ONE launch (spk_teacher_seq_kernel): x_t i2h^T + bias of all steps as
+    // one batched product, then h2h / h2att / a2c tiles stationary in 16-row x 16-unit workgroups with in-strip hand-offs
+    const bool teacher_seq = teacher_batched && g_teacher_seq && !bf && !io[0]->device_shared && cic_teacher_seq_ok(B, K, H, A, E);
     if (teacher_batched) {
         RUN(cic_teacher_tokens(io[0]->pick, w[0].it_all, w[0].unfinished, w[0].any_unf, io[0]->seq, T, B, st));
-        if (T > 1) {
-            const uint8_t* xk1 = io[0]->x_keep ? io[0]->x_keep + (size_t)B * E : nullptr;
-            RUN(cic_embed_fwd2(p->embed_w, Dual<const int32_t>{w[0].it_all + B, nullptr}, Dual<const uint8_t>{xk1, nullptr},
-                               xk1 ? p_drop : 0.f, Dual<float>{w[0].x_all + (size_t)B * E, nullptr}, (T - 1) * B, 1, E, st, 0));
+        const int t_first = teacher_seq ? 0 : 1;          // (the per-step loop embeds step 0 itself)
+        if (T > t_first) {
+            const uint8_t* xk1 = io[0]->x_keep ? io[0]->x_keep + (size_t)t_first * B * E : nullptr;
+            RUN(cic_embed_fwd2(p->embed_w, Dual<const int32_t>{w[0].it_all + (size_t)t_first * B, nullptr}, Dual<const uint8_t>{xk1, nullptr},
+                               xk1 ? p_drop : 0.f, Dual<float>{w[0].x_all + (size_t)t_first * B * E, nullptr}, (T - t_first) * B, 1, E, st, 0));
         }
+    }
+    if (teacher_seq) {
+        RUN(gemm_nt(w[0].x_all, E, p->i2h_w, E, w[0].pre_all, 5 * H, T * B, 5 * H, E, w[0].bias_ih, false, false, st));
+        TeacherSeqLaunch L = {};
+        L.h2h_w = p->h2h_w; L.h2att_w = p->h2att_w; L.h2att_b = p->h2att_b; L.a2c_w = p->a2c_w; L.a2c_b = p->a2c_b;
+        L.alpha_w = p->alpha_w; L.alpha_b = p->alpha_b; L.p_att = w[0].p_att; L.att = w[0].att; L.masks = io[0]->att_masks;
+        L.out_keep = io[0]->out_keep;
+        L.pre_all = w[0].pre_all; L.h_all = w[0].h_all; L.c_all = w[0].c_all; L.att_h_all = w[0].att_h_all;
+        L.att_res_all = w[0].att_res_all; L.alpha_all = w[0].alpha_all; L.dot_all = w[0].dot_all; L.out_all = w[0].out_all;
+        L.sync = w[0].tsync; L.scale = 1.0f / (1.0f - p_drop); L.B = B; L.K = K; L.T = T;
+        RUN(cic_teacher_seq(L, st));
     }
     // The logit weights are read unchanged by every step's logit product: cut them into their three bf16 parts once per
     // decode (8 us) instead of once per weight tile and workgroup inside the walker (cic_gemm_args.B_parts; bit-identical)
@@ -276,7 +294,7 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     if (presplit_logit) RUN(cic_split_bf16x3(p->logit_w, (int64_t)V1 * H, w[0].logit_parts, s));
     bool early_stop = g_early_stop && !fc && !ps && !teacher_batched;
     for (int q = 0; q < nb; ++q) early_stop = early_stop && !io[q]->first_token;
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < T && !teacher_seq; ++t) {
         const Dual<float> x = SLAB(x_all, B * E), att_h = SLAB(att_h_all, B * A), att_res = SLAB(att_res_all, B * H),
                           pre = SLAB(pre_all, B * 5 * H), out = SLAB(out_all, B * H), logp = SLAB(logp_all, B * V1);
         const Dual<const float> h = CSLAB(h_all, B * H), c = CSLAB(c_all, B * H);

@@ -420,6 +420,289 @@ __global__ __launch_bounds__(KS * 64) void a2c_cell_fused_kernel(Dual<const floa
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The teacher-forced recurrence (AttModel.forward with ss_prob = 0, models/AttModel.py:103-148) in ONE launch.
+// With the fed tokens known in advance nothing in the recurrence waits for a logit: x_t i2h^T of ALL steps is one batched
+// product before the loop, and what remains per step - h h2h^T and h h2att^T, the attention, att_res a2c^T and the cell - is
+// the forward twin of spk_bptt_seq_kernel: 16-row strips x 16-unit tiles, one workgroup per CU, all resident,
+//   * the weight rows of the workgroup's units stay in it as MFMA B fragments (v_mfma_f32_16x16x4_f32), K = H split over
+//     8 waves: the five h2h tiles and the h2att tile in registers (96 VGPRs per lane), the two a2c tiles in LDS (64 KB);
+//   * the cell state c never leaves the lane that owns (row, unit); h_t, the attention query and the attention result travel
+//     through the activation slabs the backward pass reads anyway, with three in-strip hand-offs per step (write-through
+//     stores, drain, barrier, counter add + one poller, barrier, sc1 loads; 32 workgroups of a strip on ONE XCD at B = 128);
+//   * the attention of the strip's 16 images runs on its even workgroups (8 waves x 64 columns, two passes of 36 registers:
+//     p_att for the scores - requested before the first hand-off is waited for -, then att for the weighted sum).
+// Per step: 3 launches of 20 + 9 + 9 us become ~13 us.  Every spin is bounded (20 ms): a workgroup that gives up raises *err and
+// poisons what it produces with NaN.
+// ---------------------------------------------------------------------------------------------
+struct TeacherSeqArgs {
+    const float *h2h_w, *h2att_w, *h2att_b, *a2c_w, *a2c_b, *alpha_w, *alpha_b;
+    const float *p_att, *att, *masks;                         // [B,K,H] x2, [B,K] or null
+    const uint8_t* out_keep;                                  // [T,B,H] or null
+    float *pre_all, *h_all, *c_all, *att_h_all, *att_res_all, *alpha_all, *dot_all, *out_all;   // the decode's activation slabs
+    unsigned *cnt, *err;                                      // [strips][T][3] counters (zeroed by the launcher), 1 word
+    float scale;
+    int B, K, T;
+};
+constexpr size_t TEACHER_LDS_BYTES = sizeof(float) * ((size_t)8 * 8 * 64 * 4 + 8 * 6 * 4 * 64 + 8 * 64);
+constexpr unsigned long long TEACHER_SPIN_TICKS = 20ull * 100000ull;      // 20 ms of the 100 MHz s_memrealtime counter
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <int KS>
+__global__ __launch_bounds__(KS * 64) void spk_teacher_seq_kernel(TeacherSeqArgs a) {
+    static_assert(KS == 8, "K = 512 split over 8 waves: 4 k groups of 16 each");
+    constexpr int H = 512, H5 = 5 * H, TJ = H / 16, GP = 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    f32x4* wl = reinterpret_cast<f32x4*>(lds);            // [KS][2 a2c tiles][GP][64]
+    float* red = lds + (size_t)KS * 2 * GP * 64 * 4;      // [KS][6 tiles][4][64]
+    float* sp = red + KS * 6 * 4 * 64;                    // [KS][64] per-wave partial scores
+    __shared__ int ok_s;
+    const int tid = threadIdx.x, lane = tid & 63, ks = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    const int B = a.B, K = a.K, T = a.T;
+    const int strips = gridDim.x / TJ;
+    int strip = blockIdx.x / TJ, jt = blockIdx.x % TJ;
+    if (strips <= 8 && (8 % strips) == 0 && (TJ % (8 / strips)) == 0) {     // speed only: a strip on as few XCDs as possible
+        const int xs = 8 / strips, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        strip = xcd / xs;
+        jt = (xcd % xs) * (TJ / xs) + local;
+    }
+    const int m0 = strip * 16;
+    const int col = jt * 16 + li;
+    const bool owner = ks < 4;                            // waves 0-3 finish the 16 x 16 outputs: register ks of every tile
+    const int orow = m0 + 4 * lq + (ks & 3);
+    const int orc = orow < B ? orow : B - 1;
+    const int mc = min(m0 + li, B - 1);                   // A rows; rows past B repeat row B-1: their sums are never stored
+    unsigned* cnt = a.cnt + (size_t)strip * T * 3;
+    // ---- the weight tiles, once: B fragments (k = 16 (4 ks + i) + 4 lq + s, n = unit li of the tile) -----------------------------
+    f32x4 wh[6][GP];
+#pragma unroll
+    for (int tau = 0; tau < 6; ++tau) {
+        const float* wrow = tau < 5 ? a.h2h_w + ((size_t)tau * H + col) * H : a.h2att_w + (size_t)col * H;
+#pragma unroll
+        for (int i = 0; i < GP; ++i) wh[tau][i] = *reinterpret_cast<const f32x4*>(wrow + 16 * (GP * ks + i) + 4 * lq);
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const float* wrow = a.a2c_w + ((size_t)g * H + col) * H;
+#pragma unroll
+        for (int i = 0; i < GP; ++i)
+            wl[((ks * 2 + g) * GP + i) * 64 + lane] = *reinterpret_cast<const f32x4*>(wrow + 16 * (GP * ks + i) + 4 * lq);
+    }
+    const float b_att = a.h2att_b[col], b_a0 = a.a2c_b[col], b_a1 = a.a2c_b[H + col];
+    // attention: this wave's 64 columns (float4 column col4), lane -> (ac = column quad, rg = region group)
+    const int ac = lane & 15, rg = lane >> 4;
+    const int col4 = 16 * ks + ac;
+    const f32x4 wa = reinterpret_cast<const f32x4*>(a.alpha_w)[col4];
+    const float b_alpha = a.alpha_b[0];
+    const int img = m0 + (jt >> 1);
+    const bool att_wg = (jt & 1) == 0;
+    const int imc = img < B ? img : B - 1;
+    const bool do_att = att_wg && img < B;
+    auto uniform_rsrc = [](const float* ptr, size_t bytes) {
+        const unsigned long long u = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo), 0, (int)bytes, 0x00020000);
+    };
+    const auto r_h = uniform_rsrc(a.h_all, (size_t)(T + 1) * B * H * sizeof(float));
+    const auto r_ah = uniform_rsrc(a.att_h_all, (size_t)T * B * H * sizeof(float));
+    const auto r_res = uniform_rsrc(a.att_res_all, (size_t)T * B * H * sizeof(float));
+    const auto r_patt = uniform_rsrc(a.p_att + (size_t)imc * K * H, (size_t)K * H * sizeof(float));
+    const auto r_att = uniform_rsrc(a.att + (size_t)imc * K * H, (size_t)K * H * sizeof(float));
+    __syncthreads();
+    float c_state = 0.f;                                  // c_{t-1} of this lane's (row, unit) (owners); init_hidden: zeros
+    float poison = 0.f;
+    auto publish = [&](unsigned* c, bool add) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // EVERY storing wave drains before the signal
+        __syncthreads();
+        if (tid == 0 && add) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto wait_for = [&](unsigned* c, unsigned target) {
+        if (tid == 0) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            int ok = 1;
+            while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > TEACHER_SPIN_TICKS) { ok = 0; break; }
+            }
+            ok_s = ok;
+            if (!ok) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // compiler only: no load of handed-off bytes above the poll
+        if (!ok_s) poison = __builtin_nanf("");
+    };
+    for (int t = 0; t < T; ++t) {
+        // per-lane index values made opaque once per step (see spk_bptt_seq_kernel: keeps address arithmetic out of registers)
+        int lq_t = lq, mc_t = mc, orc_t = orc, orow_t = orow, col_t = col, col4_t = col4, rg_t = rg, lane_t = lane;
+        asm volatile("" : "+v"(lq_t), "+v"(mc_t), "+v"(orc_t), "+v"(orow_t), "+v"(col_t), "+v"(col4_t), "+v"(rg_t), "+v"(lane_t));
+        const size_t rowH = (size_t)t * B * H;
+        const int so_h = __builtin_amdgcn_readfirstlane((int)(rowH * sizeof(float)));      // slab t of the [B,H] slabs
+        float* pre = a.pre_all + (size_t)t * B * H5 + (size_t)orc_t * H5 + col_t;
+        // this step's x_t i2h^T + bias (written before the launch) and dropout mask: requested first, used last
+        float px[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        float kf = 1.0f;
+        if (owner) {
+#pragma unroll
+            for (int g = 0; g < 5; ++g) px[g] = pre[g * H];
+            if (a.out_keep) kf = (float)a.out_keep[rowH + (size_t)orc_t * H + col_t] * a.scale;
+        }
+        // ---- 1. h_{t-1} h2h^T (five gate tiles) and the attention query h_{t-1} h2att^T + b ---------------------------------------
+        float hs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (t > 0) {
+            wait_for(cnt + (t - 1) * 3 + 2, TJ);            // h_{t-1} of the strip (slab t of h_all)
+            f32x4 af[GP];
+#pragma unroll
+            for (int i = 0; i < GP; ++i)
+                af[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    r_h, (int)(((size_t)mc_t * H + 16 * (GP * ks + i) + 4 * lq_t) * 4), so_h, 16));
+            f32x4acc acc[6];
+#pragma unroll
+            for (int tau = 0; tau < 6; ++tau) acc[tau] = f32x4acc{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < GP; ++i)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int tau = 0; tau < 6; ++tau)
+                        acc[tau] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], wh[tau][i][s], acc[tau], 0, 0, 0);
+#pragma unroll
+            for (int tau = 0; tau < 6; ++tau)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) red[((ks * 6 + tau) * 4 + v) * 64 + lane_t] = acc[tau][v];
+            __syncthreads();
+            if (owner) {
+#pragma unroll
+                for (int tau = 0; tau < 6; ++tau) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int w = 0; w < KS; ++w) v += red[((w * 6 + tau) * 4 + ks) * 64 + lane_t];
+                    hs[tau] = v;
+                }
+            }
+        }
+        if (owner && orow_t < B) {
+            float q = hs[5] + b_att;
+            if (poison != 0.f) q = poison;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, q), r_ah, (int)(((size_t)orow_t * H + col_t) * 4), so_h, 16);
+        }
+        publish(cnt + t * 3 + 0, true);
+        // ---- 2. attention of image img on the even workgroups (attn_fwd_cols_kernel, 8 waves x 64 columns) ---------------------------
+        if (att_wg) {
+            constexpr int JMAX = 9;                          // regions 4 j + rg, K <= 36
+            const int vo = (rg_t * H + 4 * col4_t) * 4;
+            f32x4 rv[JMAX];
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j)
+                rv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_patt, vo, 4 * j * H * 4, 0));
+            wait_for(cnt + t * 3 + 0, TJ);
+            const f32x4 ah = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_ah, (int)(((size_t)imc * H + 4 * col4_t) * 4), so_h, 16));
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j) {
+                float part = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part += wa[e] * fast_tanh(rv[j][e] + ah[e]);
+                part = sum8_dpp(part);
+                part += dpp_f32<DPP_ROW_MIRROR>(part);
+                const int k = 4 * j + rg_t;
+                if (ac == 0 && k < K) sp[ks * 64 + k] = part;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j)
+                rv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_att, vo, 4 * j * H * 4, 0));
+            __syncthreads();                                 // (workgroup-uniform branch)
+            float dot = -INFINITY;
+            if (lane < K) {
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < KS; ++q) s += sp[q * 64 + lane];
+                dot = s + b_alpha;
+            }
+            const float mx = wave_max_fast(dot);
+            const float ex = lane < K ? __expf(dot - mx) : 0.f;
+            const float sum = wave_sum_fast(ex);
+            float al = ex * (1.0f / sum);
+            if (a.masks) {   // weight = weight * mask; weight /= weight.sum()   (AttModel.py:481-483)
+                al = lane < K ? al * a.masks[(size_t)imc * K + lane] : 0.f;
+                const float ms = wave_sum_fast(al);
+                al = al * (1.0f / ms);
+            }
+            if (poison != 0.f) al = poison;
+            if (ks == 0 && lane < K && do_att) {
+                a.alpha_all[((size_t)t * B + img) * K + lane] = al;
+                a.dot_all[((size_t)t * B + img) * K + lane] = dot;
+            }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j) {
+                const float aj = __shfl(al, 4 * j + rg_t, 64);      // lanes >= K hold 0
+                acc += aj * rv[j];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[e];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                acc[e] = v;
+            }
+            if (rg_t == 0 && do_att)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc), r_res, (int)(((size_t)img * H + 4 * col4_t) * 4), so_h, 16);
+            publish(cnt + t * 3 + 1, true);
+        }
+        // ---- 3. in_transform += att_res a2c^T + b, the cell, h_t --------------------------------------------------------------------------
+        wait_for(cnt + t * 3 + 1, TJ / 2);
+        float av0 = 0.f, av1 = 0.f;
+        {
+            f32x4 af[GP];
+#pragma unroll
+            for (int i = 0; i < GP; ++i)
+                af[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    r_res, (int)(((size_t)mc_t * H + 16 * (GP * ks + i) + 4 * lq_t) * 4), so_h, 16));
+            f32x4acc a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < GP; ++i) {
+                const f32x4 b0 = wl[((ks * 2 + 0) * GP + i) * 64 + lane_t], b1 = wl[((ks * 2 + 1) * GP + i) * 64 + lane_t];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], b0[s], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], b1[s], a1, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                red[((ks * 6 + 0) * 4 + v) * 64 + lane_t] = a0[v];
+                red[((ks * 6 + 1) * 4 + v) * 64 + lane_t] = a1[v];
+            }
+            __syncthreads();
+            if (owner) {
+#pragma unroll
+                for (int w = 0; w < KS; ++w) {
+                    av0 += red[((w * 6 + 0) * 4 + ks) * 64 + lane_t];
+                    av1 += red[((w * 6 + 1) * 4 + ks) * 64 + lane_t];
+                }
+            }
+        }
+        if (owner) {
+            const float pi = px[0] + hs[0], pf = px[1] + hs[1], po = px[2] + hs[2];
+            const float pa = (px[3] + hs[3]) + (av0 + b_a0), pb = (px[4] + hs[4]) + (av1 + b_a1);     // in_transform halves (:521-522)
+            const float ig = fast_sigmoid(pi), fg = fast_sigmoid(pf), og = fast_sigmoid(po);
+            float c2 = fg * c_state + ig * fmaxf(pa, pb);          // :523-526
+            float h2 = og * fast_tanh(c2);                         // :527
+            if (poison != 0.f) { c2 = poison; h2 = poison; }
+            c_state = c2;
+            if (orow_t < B) {
+                pre[0] = pi; pre[H] = pf; pre[2 * H] = po; pre[3 * H] = pa; pre[4 * H] = pb;      // kept for the backward pass
+                const size_t e = (size_t)orow_t * H + col_t;
+                a.c_all[rowH + (size_t)B * H + e] = c2;
+                a.out_all[rowH + e] = a.out_keep ? h2 * kf : h2;  // :529
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h2), r_h, (int)(e * 4),
+                                                      so_h + (int)((size_t)B * H * sizeof(float)), 16);
+            }
+        }
+        if (t + 1 < T) publish(cnt + t * 3 + 2, true);
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // K7 token embedding: x = dropout(relu(E[it]))   (models/AttModel.py:74-76,399)
 // ---------------------------------------------------------------------------------------
@@ -1381,6 +1664,33 @@ extern "C" int cic_finalize_len(const int* any_unfinished, int T, int* L, cic_st
 int cic_finalize_len2(Dual<const int> any_unfinished, int T, Dual<int> L, int nb, hipStream_t st) {
     CIC_REQUIRE(any_unfinished.a && L.a && T > 0 && (nb == 1 || (nb == 2 && any_unfinished.b && L.b)));
     hipLaunchKernelGGL(finalize_len_kernel, dim3(nb), dim3(64), 0, st, any_unfinished, T, L);
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+
+
+// the teacher-forced recurrence as one launch (see spk_teacher_seq_kernel); pre_all must hold x_t i2h^T + bias of every step
+bool cic_teacher_seq_ok(int B, int K, int H, int A, int E) {
+    if (!(H == 512 && A == 512 && K >= 1 && K <= 36)) return false;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    return cic_cdiv(B, 16) * (H / 16) <= cus;
+}
+int cic_teacher_seq(const TeacherSeqLaunch& L, hipStream_t st) {
+    static DeviceOnce attr_set;
+    if (attr_set.first())
+        CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spk_teacher_seq_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)TEACHER_LDS_BYTES));
+    const int strips = cic_cdiv(L.B, 16);
+    CIC_HIP(hipMemsetAsync(L.sync, 0, sizeof(unsigned) * ((size_t)strips * L.T * 3 + 1), st));
+    TeacherSeqArgs a = {};
+    a.h2h_w = L.h2h_w; a.h2att_w = L.h2att_w; a.h2att_b = L.h2att_b; a.a2c_w = L.a2c_w; a.a2c_b = L.a2c_b;
+    a.alpha_w = L.alpha_w; a.alpha_b = L.alpha_b; a.p_att = L.p_att; a.att = L.att; a.masks = L.masks; a.out_keep = L.out_keep;
+    a.pre_all = L.pre_all; a.h_all = L.h_all; a.c_all = L.c_all; a.att_h_all = L.att_h_all; a.att_res_all = L.att_res_all;
+    a.alpha_all = L.alpha_all; a.dot_all = L.dot_all; a.out_all = L.out_all;
+    a.cnt = L.sync; a.err = L.sync + (size_t)strips * L.T * 3;
+    a.scale = L.scale; a.B = L.B; a.K = L.K; a.T = L.T;
+    hipLaunchKernelGGL((spk_teacher_seq_kernel<8>), dim3(strips * 32), dim3(512), TEACHER_LDS_BYTES, st, a);
     CIC_LAUNCH_CHECK();
     return 0;
 }

@@ -157,6 +157,7 @@ def speaker_decode_io(dims, params, att_pre, mode, temp=1.0, att_masks=None, att
     if timer is not None:
         io.timer = timer.handle
     io.ss_u, io.ss_prob, io.ss_pick = _p(ss_u), float(ss_prob), _p(ss_pick)
+    io.device_shared = 1 if DEVICE_SHARED[0] else 0
     io.seq, io.slp, io.stv, io.L = _p(out['seq']), _p(out['slp']), _p(out['stv']), _p(out['L'])
     out['io'] = io
     out['_keep'] = (att_pre, att_masks, att_keep, x_keep, out_keep, U, pick, first_token, ss_u, ss_pick, ps_u, fc_x0)   # alive until the backward call

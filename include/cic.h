@@ -335,6 +335,9 @@ typedef struct {
     int u_philox;
     uint64_t u_seed, u_offset;
     cic_timer* timer;         /* optional in-situ timing of this decode's kernels (forward and backward), or NULL */
+    int device_shared;        /* != 0: other processes run kernels on this device at the same time.  The teacher-forced
+                                 recurrence is then launched step by step (its one-launch form needs all its workgroups
+                                 resident together) */
 } cic_decode_io;
 
 /* Bytes of workspace a decode needs; the same workspace must be handed, untouched, to

@@ -33,6 +33,8 @@ int cic_debug_gemm_tail_split(int on);
 int cic_debug_gates_att_fused(int on);
 /* diagnostics: 0 = the decode engines run every step in full even after every caption has ended (A/B of the early stop) */
 int cic_debug_early_stop(int on);
+/* diagnostics: 0 = the teacher-forced recurrence (AttModel.forward) as three launches per step instead of spk_teacher_seq_kernel */
+int cic_debug_teacher_seq(int on);
 /* ... and 0 = the products of every BPTT step run although steps at or beyond the decode's length carry no gradient */
 int cic_debug_bptt_early_stop(int on);
 /* diagnostics: 0 = the speaker's BPTT loop as four launches per step instead of spk_bptt_seq_kernel (A/B timing, parity) */

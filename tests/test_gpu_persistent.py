@@ -7,6 +7,8 @@
   * spk_bptt_seq_kernel - the speaker's BPTT loop (cell, a2c product, attention, h2h + h2att product; three hand-offs per
     step) as ONE launch - same tokens and loss, every gradient within 1e-5 of its largest element of the four-launches-per-
     step loop, with full-length captions, captions that end early and ragged region masks (tools/bptt_seq_check.py);
+  * spk_teacher_seq_kernel - the teacher-forced recurrence of AttModel.forward (BASELINE configs[1]) as ONE launch - loss and
+    gradients of the MLE step against the three-launches-per-step form (tools/teacher_seq_check.py);
   * the device-side early stop of the decode loops (AttModel.py:401-408) must leave tokens, lengths, loss and gradients
     of a full-width joint step exactly as the full loops give them (tools/early_stop_check.py)."""
 import json
@@ -48,3 +50,14 @@ def test_one_launch_speaker_bptt_loop_equals_the_per_step_loop():
     for case in ('full_length', 'early_end', 'ragged_regions'):
         assert doc[case]['forward_equal'] and doc[case]['finite'] and doc[case]['max_grad_rel_diff'] < 1e-5
     assert doc['early_end']['L'] < 16
+
+
+@pytest.mark.timeout(600)
+def test_one_launch_teacher_forced_recurrence_equals_the_per_step_launches():
+    doc = _run('teacher_seq_check.py', '--iters', '5')
+    assert doc['teacher_seq_check'] == 'ok'
+    for B in (64, 128):
+        assert doc[f'B{B}_uneven_load']['mismatches'] == 0
+        for case in ('plain', 'ragged_regions'):
+            d = doc[f'B{B}_{case}']
+            assert d['finite'] and d['loss_rel_diff'] < 2e-6 and d['max_grad_rel_diff'] < 1e-5 and d['n_grad_buffers'] > 0
