@@ -138,11 +138,13 @@ def test_paired_decodes_equal_sequential_decodes(B, dims):
     engine.speaker_decode_fwd_pair(d, params, a1, b1)
     torch.cuda.synchronize()
     assert 0 < int(a0['L']) <= T and 0 < int(b0['L']) <= T
-    # the workspace ends with the row partials of the last step, the [T,B] log-sum-exp rows and the pre-split logit weights
+    # the workspace ends with the row partials of the last step, the [T,B] log-sum-exp rows, the pre-split logit weights and the
+    # (here unused) hand-off counters of the one-launch teacher-forced recurrence
     # (engine_util.h: SpkWs; a pair keeps those in decode a's workspace only)
     lse_b = (T * B * 4 + 255) // 256 * 256
     parts_b = (3 * (d.V + 1) * d.H * 2 + 255) // 256 * 256
-    tail = 6 * 16384 * 4 + lse_b + parts_b
+    tsync_b = ((((B + 15) // 16) * T * 3 + 1 + 3) // 4 * 4 * 4 + 255) // 256 * 256     # hand-off counters of the teacher-forced kernel
+    tail = 6 * 16384 * 4 + lse_b + parts_b + tsync_b
     for x, y in ((a0, a1), (b0, b1)):
         for k in ('seq', 'L'):
             assert torch.equal(x[k], y[k]), k
