@@ -267,7 +267,9 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
                                  !(io[0]->ss_u && io[0]->ss_prob > 0.f) && (int64_t)T * B <= CIC_PART_MAX_ENTRIES;
     // ... and at the flagship widths the recurrence itself is ONE launch (spk_teacher_seq_kernel): x_t i2h^T + bias of all steps as
     // one batched product, then h2h / h2att / a2c tiles stationary in 16-row x 16-unit workgroups with in-strip hand-offs
-    const bool teacher_seq = teacher_batched && g_teacher_seq && !bf && !io[0]->device_shared && cic_teacher_seq_ok(B, K, H, A, E);
+    // (bf16 variant: the f32 copies of att / p_att hold the bf16-rounded values, so the kernel's attention computes what the packed
+    // copies would give; the batched x i2h^T product follows the variant's one-part precision like every batched product)
+    const bool teacher_seq = teacher_batched && g_teacher_seq && !io[0]->device_shared && cic_teacher_seq_ok(B, K, H, A, E);
     if (teacher_batched) {
         RUN(cic_teacher_tokens(io[0]->pick, w[0].it_all, w[0].unfinished, w[0].any_unf, io[0]->seq, T, B, st));
         const int t_first = teacher_seq ? 0 : 1;          // (the per-step loop embeds step 0 itself)
