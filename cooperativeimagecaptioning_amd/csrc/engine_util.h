@@ -61,7 +61,7 @@ int cic_a2c_cell_fused(Dual<const float> att_res, const float* Wa, const float* 
 int cic_logsoftmax_sample2(const cic_sampler_args* a, const cic_sampler_args* b, hipStream_t st);
 // the sampler on the row partials of the step's logits (no pass over the vocabulary); writes the rows' lse
 int cic_teacher_tokens(const int64_t* pick, int32_t* it_all, int32_t* unfinished, int32_t* any_unf, int32_t* seq, int T, int B,
-                       hipStream_t st);
+                       hipStream_t st, unsigned* zsync = nullptr, int nzsync = 0);
 int cic_teacher_finish_all(const float* part, int np, int part_rows, const float* logits, int ld, const int64_t* pick,
                            float* lse_all, float* slp, int T, int B, hipStream_t st);
 int cic_finalize_len2(Dual<const int> any_unfinished, int T, Dual<int> L, int nb, hipStream_t st);

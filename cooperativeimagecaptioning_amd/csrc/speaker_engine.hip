@@ -271,7 +271,8 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     // copies would give; the batched x i2h^T product follows the variant's one-part precision like every batched product)
     const bool teacher_seq = teacher_batched && g_teacher_seq && !io[0]->device_shared && cic_teacher_seq_ok(B, K, H, A, E);
     if (teacher_batched) {
-        RUN(cic_teacher_tokens(io[0]->pick, w[0].it_all, w[0].unfinished, w[0].any_unf, io[0]->seq, T, B, st));
+        RUN(cic_teacher_tokens(io[0]->pick, w[0].it_all, w[0].unfinished, w[0].any_unf, io[0]->seq, T, B, st, w[0].tsync,
+                               cic_cdiv(B, 16) * T * 3 + 1));
         const int t_first = teacher_seq ? 0 : 1;          // (the per-step loop embeds step 0 itself)
         if (T > t_first) {
             const uint8_t* xk1 = io[0]->x_keep ? io[0]->x_keep + (size_t)t_first * B * E : nullptr;

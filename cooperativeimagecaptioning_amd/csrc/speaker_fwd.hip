@@ -1283,8 +1283,11 @@ __global__ __launch_bounds__(256) void sample_finish_kernel(FinishArgs a0, Finis
 // after the recurrence (cic_speaker_decode_fwd).
 __global__ __launch_bounds__(256) void teacher_tokens_kernel(const int64_t* __restrict__ pick, int32_t* __restrict__ it_all,
                                                              int32_t* __restrict__ unfinished, int32_t* __restrict__ any_unf,
-                                                             int32_t* __restrict__ seq, int T, int B) {
+                                                             int32_t* __restrict__ seq, int T, int B,
+                                                             unsigned* __restrict__ zsync, int nzsync) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    // hand-off counters of spk_teacher_seq_kernel (this launch precedes it on the stream), or null
+    for (int i = b; i < nzsync; i += gridDim.x * blockDim.x) zsync[i] = 0u;
     if (b >= B) return;
     int unf = 1;
     for (int t = 1; t <= T; ++t) {
@@ -1607,9 +1610,10 @@ extern "C" int cic_logit_partials(const float* logits, int M, int N, int ld, con
 }
 
 int cic_teacher_tokens(const int64_t* pick, int32_t* it_all, int32_t* unfinished, int32_t* any_unf, int32_t* seq, int T, int B,
-                       hipStream_t st) {
+                       hipStream_t st, unsigned* zsync, int nzsync) {
     CIC_REQUIRE(pick && it_all && unfinished && any_unf && seq && T > 0 && B > 0);
-    hipLaunchKernelGGL(teacher_tokens_kernel, dim3(cic_cdiv(B, 256)), dim3(256), 0, st, pick, it_all, unfinished, any_unf, seq, T, B);
+    hipLaunchKernelGGL(teacher_tokens_kernel, dim3(cic_cdiv(B, 256)), dim3(256), 0, st, pick, it_all, unfinished, any_unf, seq, T, B,
+                       zsync, zsync ? nzsync : 0);
     CIC_LAUNCH_CHECK();
     return 0;
 }
@@ -1682,7 +1686,7 @@ int cic_teacher_seq(const TeacherSeqLaunch& L, hipStream_t st) {
         CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spk_teacher_seq_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)TEACHER_LDS_BYTES));
     const int strips = cic_cdiv(L.B, 16);
-    CIC_HIP(hipMemsetAsync(L.sync, 0, sizeof(unsigned) * ((size_t)strips * L.T * 3 + 1), st));
+    // (the hand-off counters were cleared by cic_teacher_tokens, which precedes this launch on the stream)
     TeacherSeqArgs a = {};
     a.h2h_w = L.h2h_w; a.h2att_w = L.h2att_w; a.h2att_b = L.h2att_b; a.a2c_w = L.a2c_w; a.a2c_b = L.a2c_b;
     a.alpha_w = L.alpha_w; a.alpha_b = L.alpha_b; a.p_att = L.p_att; a.att = L.att; a.masks = L.masks; a.out_keep = L.out_keep;
