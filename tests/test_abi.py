@@ -78,3 +78,38 @@ def test_product_library_has_no_debug_switches_or_global_state():
     out = subprocess.run(['nm', '-D', '--defined-only', _lib._LIB_PATH], capture_output=True, text=True).stdout
     writable = [ln for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in 'BbDd' and 'g_' in ln.split()[2]]
     assert not writable, writable
+
+
+def test_ctypes_structs_have_the_layout_of_the_header():
+    """Every ctypes struct of the binding against its C twin in include/cic.h, field by field: a C program (gcc) prints
+    sizeof and every offsetof, and the numbers must equal ctypes' - a field added to one side only, or added in a different
+    place, fails here instead of truncating a pointer on the GPU."""
+    import ctypes as C
+    import subprocess
+    import tempfile
+    from cooperativeimagecaptioning_amd import _lib
+    pairs = {'GemmArgs': 'cic_gemm_args', 'SamplerArgs': 'cic_sampler_args', 'SpeakerDims': 'cic_speaker_dims',
+             'SpeakerParams': 'cic_speaker_params', 'DecodeIO': 'cic_decode_io', 'DecodeBwdIO': 'cic_decode_bwd_io',
+             'BeamIO': 'cic_beam_io', 'CiderdArgs': 'cic_ciderd_args', 'ListenerDims': 'cic_listener_dims',
+             'ListenerParams': 'cic_listener_params', 'ListenerIO': 'cic_listener_io', 'ListenerBwdIO': 'cic_listener_bwd_io'}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "cic.h"', 'int main(void) {']
+    for py, c in pairs.items():
+        cls = getattr(_lib, py)
+        lines.append(f'  printf("{py} sizeof %zu\\n", sizeof({c}));')
+        for name, _ in cls._fields_:
+            lines.append(f'  printf("{py} {name} %zu\\n", offsetof({c}, {name}));')
+    lines += ['  return 0;', '}']
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, 'layout.c'), os.path.join(d, 'layout')
+        open(src, 'w').write('\n'.join(lines))
+        r = subprocess.run(['gcc', '-std=c11', '-I', os.path.join(ROOT, 'include'), src, '-o', exe], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]        # a ctypes field the header does not have does not compile
+        out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
+    bad = []
+    for ln in out.splitlines():
+        py, name, val = ln.split()
+        cls = getattr(_lib, py)
+        want = C.sizeof(cls) if name == 'sizeof' else getattr(cls, name).offset
+        if int(val) != want:
+            bad.append((py, name, int(val), want))
+    assert not bad, bad

@@ -295,3 +295,16 @@ def test_reference_checkpoint_layout_loads_including_the_prev_submodules(tmp_pat
     m2 = models.AlternatingJointModel(opt2)
     for k, v in m2.state_dict().items():
         assert torch.equal(v, sd[k]), k
+
+
+def test_bench_reads_the_logit_walkers_in_step_duration_from_the_committed_trace():
+    """bench.py prices roofline_mfma at the longer of its live event bracket and the in-step average of the committed
+    rocprofv3 trace (profiles/r03_step_breakdown.md): the lookup finds the kernel's row and returns its 'avg us' cell."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('cic_bench', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    us = bench.trace_kernel_us('gemm_ldsb2bf_walk_kernel')
+    assert us is not None and 15.0 < us < 60.0
+    assert bench.trace_kernel_us('no_such_kernel') is None
+    assert 0.05 < bench.pmc_mfma_util() < 0.5
