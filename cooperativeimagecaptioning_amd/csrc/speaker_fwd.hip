@@ -375,13 +375,16 @@ __global__ __launch_bounds__(KS * 64) void a2c_cell_fused_kernel(Dual<const floa
             af[rt][i] = m < B0 ? a : z4;
         }
     }
-    f32x4 bf[GPS];
-    auto load_b = [&](int g) {
+    // both maxout halves' weight tiles are requested up front (the second one used to be requested behind the first one's MFMAs:
+    // a dependent round trip), both products run back to back, ONE barrier covers both cross-wave sums; per element the
+    // arithmetic and its order are unchanged
+    f32x4 bf[2][GPS];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
         const float* wrow = Wa + ((size_t)g * H + col) * H;
 #pragma unroll
-        for (int i = 0; i < GPS; ++i) bf[i] = *reinterpret_cast<const f32x4*>(wrow + 16 * (ks * GPS + i) + 4 * lq);
-    };
-    load_b(0);
+        for (int i = 0; i < GPS; ++i) bf[g][i] = *reinterpret_cast<const f32x4*>(wrow + 16 * (ks * GPS + i) + 4 * lq);
+    }
     float av[2];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
@@ -390,17 +393,20 @@ __global__ __launch_bounds__(KS * 64) void a2c_cell_fused_kernel(Dual<const floa
         for (int i = 0; i < GPS; ++i)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][i][s], bf[i][s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][i][s], bf[i][s], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][i][s], bf[g][i][s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][i][s], bf[g][i][s], acc1, 0, 0, 0);
             }
-        if (g < 1) load_b(1);
         float* rb = red + g * (KS * 8 * 64);
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             rb[(ks * 8 + v) * 64 + lane] = acc0[v];
             rb[(ks * 8 + 4 + v) * 64 + lane] = acc1[v];
         }
-        __syncthreads();
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const float* rb = red + g * (KS * 8 * 64);
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < KS; ++w) v += rb[(w * 8 + ks) * 64 + lane];
