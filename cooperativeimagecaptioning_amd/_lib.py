@@ -103,7 +103,7 @@ class DecodeBwdIO(C.Structure):
                 ('d_x0', c_ptr), ('phase', C.c_int), ('device_shared', C.c_int), ('dslp_scale', c_ptr)]
 
 
-BWD_ALL, BWD_LOGIT, BWD_REST = 0, 1, 2
+BWD_ALL, BWD_LOGIT, BWD_REST, BWD_LOOP, BWD_TAIL = 0, 1, 2, 3, 4
 
 
 class BeamIO(C.Structure):

@@ -231,9 +231,9 @@ __global__ __launch_bounds__(KS * 64) void gru_step_fused_kernel(const float* __
 //             reads tiles_j, workgroup barrier, then EVERY load of the handed-off rows is a buffer_load ... sc1.
 // No fence on either side; the counters are zeroed by the token-preparation kernel that precedes this launch on the
 // stream.  Nothing here depends on dispatch order or placement; it needs every workgroup RESIDENT (grid <= CUs, checked
-// by the launcher, which otherwise uses the per-step kernel).  Every spin is bounded by a wall-clock budget: a workgroup
+// by the launcher, which otherwise uses the per-step kernel).  Every spin is bounded by a wall-clock budget (1 s): a workgroup
 // that gives up raises *err and poisons its outputs with NaN (the loss then says so) instead of hanging the device.
-constexpr unsigned long long GRU_SPIN_TICKS = 20ull * 100000ull;     // 20 ms of the 100 MHz s_memrealtime counter
+constexpr unsigned long long GRU_SPIN_TICKS = 1000ull * 100000ull;   // 1 s of the 100 MHz s_memrealtime counter
 // Tiling (r3): a workgroup owns a 16-row strip x a 32-unit tile (its backward twin's shape): 8 strips x 32 tiles at B = 128, so
 // that the 32 workgroups of a strip share ONE XCD (blockIdx % 8: the hand-off stays inside an L2's reach; speed only) and a
 // step moves 64 KB of h rows per workgroup instead of 128.  The weight tile (3 gates x 32 units x J floats = 393 KB) is split:

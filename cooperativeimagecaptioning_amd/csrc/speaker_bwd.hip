@@ -550,7 +550,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_cols_kernel(const float* __rest
 // fabric round trips per step (store - drain - counter - poll - load: ~3 us each).  Moving more of the dh product in front of
 // the attention (prefetching its fragments across it) cost registers and made every phase slower: 16.1 us.
 // Steps at or beyond the decode's length L carry no gradient (d out = 0, no carry): zeros are stored, no hand-off runs.
-// Every spin is bounded (20 ms): a workgroup that gives up raises *err and poisons what it produces with NaN.
+// Every spin is bounded (1 s): a workgroup that gives up raises *err and poisons what it produces with NaN.
 struct BpttArgs {
     const float *pre_all, *c_all, *alpha_all, *att_h_all, *p_att, *att;     // forward state [T,B,5H] [T+1,B,H] [T,B,K] [T,B,H] [B,K,H] x2
     const uint8_t* out_keep;                                                // [T,B,H] or null
@@ -565,7 +565,7 @@ struct BpttArgs {
 };
 constexpr int BPTT_GA = 8, BPTT_GI = 12, BPTT_GC = 4;      // k groups of 16 per wave: (a, b) gate columns / (i, f, o) / d_att_h
 constexpr size_t BPTT_LDS_BYTES = sizeof(float) * ((size_t)8 * (BPTT_GA + BPTT_GC) * 64 * 4 + 8 * 4 * 64 + 8 * 64);
-constexpr unsigned long long BPTT_SPIN_TICKS = 20ull * 100000ull;          // 20 ms of the 100 MHz s_memrealtime counter
+constexpr unsigned long long BPTT_SPIN_TICKS = 1000ull * 100000ull;        // 1 s of the 100 MHz s_memrealtime counter
 #ifdef CIC_DEVTOOLS
 __device__ unsigned long long* g_bptt_stamps = nullptr;    // development build: [workgroup][step][8] s_memrealtime stamps
 #endif
@@ -1117,9 +1117,12 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     CIC_REQUIRE(!bio->d_onehot || io->seq);
     CIC_REQUIRE(!ps || (io->soft_raw && io->xpre && io->seq && (io->mode != CIC_SAMPLE_GUMBEL_PS || io->U)));
     const int phase = bio->phase;
-    CIC_REQUIRE(phase == CIC_BWD_ALL || ((phase == CIC_BWD_LOGIT || phase == CIC_BWD_REST) && !ps));
+    CIC_REQUIRE(phase == CIC_BWD_ALL || ((phase == CIC_BWD_LOGIT || phase == CIC_BWD_REST) && !ps) ||
+                ((phase == CIC_BWD_LOOP || phase == CIC_BWD_TAIL) && !ps && !fc));
     CIC_REQUIRE(!bio->dslp_scale || !ps);     // the in-loop sampler backward of partial sampling takes dslp as it is
-    const bool do_logit = phase != CIC_BWD_REST, do_rest = phase != CIC_BWD_LOGIT;
+    const bool do_logit = phase == CIC_BWD_ALL || phase == CIC_BWD_LOGIT;
+    const bool do_loop = phase == CIC_BWD_ALL || phase == CIC_BWD_REST || phase == CIC_BWD_LOOP;
+    const bool do_tail = phase == CIC_BWD_ALL || phase == CIC_BWD_REST || phase == CIC_BWD_TAIL;
     GemmCtx st(cic_s(s), d.compute_dtype == CIC_DTYPE_BF16 ? CIC_PRECISION_BF16 : CIC_PRECISION_F32);
     const int B = d.B, K = d.K, H = d.H, E = d.E, A = d.A, T = d.T, V1 = d.V + 1, D = d.D;
     const float scale = 1.0f / (1.0f - d.p_drop);
@@ -1148,7 +1151,7 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     //     latency-bound BPTT loop measured slower than one stream - its workgroups hold the CUs the loop's short kernels
     //     need; not for partial sampling, whose d logits are made inside the loop)
     if (!ps && do_logit) RUN(gemm_tn(g.dlogits, V1, w.out_all, H, gr->logit_w, H, V1, H, T * B, true, st, gr->logit_b));
-    if (!do_rest) return 0;        // CIC_BWD_LOGIT: the logit layer's gradient is final; d out waits in ws_bwd
+    if (!do_loop && !do_tail) return 0;        // CIC_BWD_LOGIT: the logit layer's gradient is final; d out waits in ws_bwd
     // 3. BPTT over the cell + attention (only dh, dc are carried)
     float* dh_in = g.dh_a;
     float* dh_out = g.dh_b;
@@ -1160,7 +1163,7 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         CIC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         seq_kernel = cic_cdiv(B, 16) * (H / 16) <= cus;
     }
-    if (seq_kernel) {
+    if (seq_kernel && do_loop) {
         static DeviceOnce attr_set;
         if (attr_set.first())
             CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spk_bptt_seq_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1179,7 +1182,7 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         hipLaunchKernelGGL((spk_bptt_seq_kernel<8>), dim3(cic_cdiv(B, 16) * (H / 16)), dim3(512), BPTT_LDS_BYTES, st, ba);
         CIC_LAUNCH_CHECK();
     }
-    for (int t = T - 1; t >= 0 && !seq_kernel; --t) {
+    for (int t = T - 1; t >= 0 && !seq_kernel && do_loop; --t) {
         const uint8_t* ok = io->out_keep ? io->out_keep + (size_t)(t + (fc ? 1 : 0)) * B * H : nullptr;
         float* dpre = g.dpre_all + (size_t)t * B * 5 * H;
         if (ps) {
@@ -1265,6 +1268,7 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
             }
         }
     }
+    if (!do_tail) return 0;        // CIC_BWD_LOOP: dpre / d att_res / d att_h / ddot of every step wait in ws_bwd
     if (ps) {
         RUN(gemm_tn(g.dlogits, V1, w.out_all, H, gr->logit_w, H, V1, H, T * B, true, st, gr->logit_b));
     }

@@ -438,7 +438,7 @@ __global__ __launch_bounds__(KS * 64) void a2c_cell_fused_kernel(Dual<const floa
 //     stores, drain, barrier, counter add + one poller, barrier, sc1 loads; 32 workgroups of a strip on ONE XCD at B = 128);
 //   * the attention of the strip's 16 images runs on its even workgroups (8 waves x 64 columns, two passes of 36 registers:
 //     p_att for the scores - requested before the first hand-off is waited for -, then att for the weighted sum).
-// Per step: 3 launches of 20 + 9 + 9 us become ~13 us.  Every spin is bounded (20 ms): a workgroup that gives up raises *err and
+// Per step: 3 launches of 20 + 9 + 9 us become ~13 us.  Every spin is bounded (1 s): a workgroup that gives up raises *err and
 // poisons what it produces with NaN.
 // ---------------------------------------------------------------------------------------------
 struct TeacherSeqArgs {
@@ -451,7 +451,7 @@ struct TeacherSeqArgs {
     int B, K, T;
 };
 constexpr size_t TEACHER_LDS_BYTES = sizeof(float) * ((size_t)8 * 8 * 64 * 4 + 8 * 6 * 4 * 64 + 8 * 64);
-constexpr unsigned long long TEACHER_SPIN_TICKS = 20ull * 100000ull;      // 20 ms of the 100 MHz s_memrealtime counter
+constexpr unsigned long long TEACHER_SPIN_TICKS = 1000ull * 100000ull;    // 1 s of the 100 MHz s_memrealtime counter
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 template <int KS>
 __global__ __launch_bounds__(KS * 64) void spk_teacher_seq_kernel(TeacherSeqArgs a) {

@@ -100,6 +100,9 @@ class AttModel(nn.Module):
         self._ws = {}
         self._buf = BufCache()
         self.timer = None            # engine.KernelTimer: in-step kernel timing of this model's decodes (bench.py)
+        # data-parallel runs (optimizer.overlap_gradient_exchange): makes the stream wait for gradient exchanges in flight; called
+        # right before the one-launch BPTT loop, which needs every CU for itself
+        self.exchange_barrier = None
 
     # ---- engine plumbing -----------------------------------------------------------------
     def flat(self):
@@ -214,9 +217,10 @@ class AttModel(nn.Module):
         self._ws[ws_key] = fwd['ws']
         return dims, params, fwd, (mode, att_raw, grad, ws_key)
 
-    def decode_backward(self, res, d_onehot=None, dslp=None, logit_grads_ready=None, dslp_scale=None):
-        """logit_grads_ready: called between the logit layer's backward and the BPTT loop (data-parallel runs start the
-        all-reduce of the logit bucket there; only when this decode is the last one writing the logit gradient)."""
+    def decode_backward(self, res, d_onehot=None, dslp=None, logit_grads_ready=None, dslp_scale=None, before_loop=None):
+        """logit_grads_ready: called once the logit layer's gradient is final and the BPTT loop has run (data-parallel runs start
+        the all-reduce of the logit bucket there; only when this decode is the last one writing the logit gradient);
+        before_loop: called right before the BPTT loop (data-parallel runs let exchanges in flight land there)."""
         fl = self.flat()
         if dslp is not None:
             dslp = self._buf.stage(('dslp_in', res.dims.T), dslp.contiguous(), torch.float32)
@@ -230,12 +234,24 @@ class AttModel(nn.Module):
                 dslp_scale = None
         kw = dict(d_onehot=d_onehot, dslp=dslp, dslp_scale=dslp_scale)
         if logit_grads_ready is not None and res.soft is None:
+            # data-parallel runs: the logit layer's gradient is final after the first phase.  The BPTT loop is ONE launch that
+            # fills every CU (a collective cannot run beside it): exchanges already in flight land first (before_loop), the loop
+            # runs, and the logit bucket starts behind it, under the batched weight-gradient products of the last phase.
             self._ws[key] = engine.speaker_decode_bwd(res.dims, res.params, res.fwd, fl.grad_tensors(), res.att_raw,
                                                       ws_bwd=self._ws.get(key), phase=_lib.BWD_LOGIT, **kw)
+            if before_loop is None:
+                before_loop = getattr(self, 'exchange_barrier', None)
+            if before_loop is not None:
+                before_loop()
+            engine.speaker_decode_bwd(res.dims, res.params, res.fwd, fl.grad_tensors(), res.att_raw,
+                                      ws_bwd=self._ws[key], phase=_lib.BWD_LOOP, **kw)
             logit_grads_ready()
             engine.speaker_decode_bwd(res.dims, res.params, res.fwd, fl.grad_tensors(), res.att_raw,
-                                      ws_bwd=self._ws[key], phase=_lib.BWD_REST, **kw)
+                                      ws_bwd=self._ws[key], phase=_lib.BWD_TAIL, **kw)
             return
+        barrier = before_loop if before_loop is not None else getattr(self, 'exchange_barrier', None)
+        if barrier is not None:
+            barrier()             # (data-parallel runs: see optimizer.overlap_gradient_exchange)
         self._ws[key] = engine.speaker_decode_bwd(res.dims, res.params, res.fwd, fl.grad_tensors(), res.att_raw,
                                                   ws_bwd=self._ws.get(key), **kw)
         if logit_grads_ready is not None:

@@ -107,6 +107,12 @@ class FlatAdam:
             if dist.get_backend() == 'gloo':
                 self._pending[name].wait()
 
+    def wait_pending(self):
+        """Make the current stream wait for the exchanges of this step that are in flight (stream-ordered on RCCL: the host does
+        not block).  The handles stay pending; step() waits again, which is then a no-op."""
+        for h in self._pending.values():
+            h.wait()
+
     def all_reduce_grads(self):
         """Every bucket summed over the ranks (one collective per bucket); returns the 1/world scale that is folded
         into the Adam kernel."""
@@ -289,6 +295,13 @@ def overlap_gradient_exchange(model, optimizer_dict):
         model.speaker_logit_grads_ready = lambda: None if spk.defer_exchange else spk.begin_all_reduce('logit')
     else:
         model.speaker_logit_grads_ready = None
+    # The speaker's BPTT loop is ONE launch that needs every CU (spk_bptt_seq_kernel): a collective that holds CUs would keep
+    # part of its workgroups from becoming resident while the rest spin for them.  Its backward therefore lets the exchanges in
+    # flight (the listener's bucket, started a few launches earlier) land first - a stream-side wait, no host block.
+    cg = getattr(model, 'caption_generator', None)
+    if cg is not None:
+        agents = [o for o in (lst, spk) if o is not None]
+        cg.exchange_barrier = lambda: [o.wait_pending() for o in agents]
 
 
 def zeroing_optimizer(opt, optimizer_dict, optimizer):

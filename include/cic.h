@@ -372,8 +372,11 @@ typedef struct {
     /* 0: the whole backward pass.  Data-parallel callers split it in two calls on the same arguments so that the
      * logit layer's gradient (19.4 MB of the speaker's 57.8 MB, final before the time loop starts) can travel
      * under the BPTT loop:  CIC_BWD_LOGIT = d logits, d out and grads->logit_w / logit_b only;  CIC_BWD_REST =
-     * everything after that (reads the d out the first call left in ws_bwd).  Partial-sampling decodes make their
-     * d logits inside the time loop: phase 0 only. */
+     * everything after that (reads the d out the first call left in ws_bwd); CIC_BWD_REST itself in two calls:
+     * CIC_BWD_LOOP = the BPTT loop only (one launch at the flagship widths: it fills every CU, so a collective does not run
+     * beside it - the host lets pending exchanges land before it and starts the logit bucket after it), CIC_BWD_TAIL = the
+     * batched weight gradients after the loop.  Partial-sampling decodes make their d logits inside the time loop: phase 0
+     * only; LOOP / TAIL not for the fc speaker. */
     int phase;
     int device_shared;        /* != 0: other processes run kernels on this device at the same time.  The BPTT loop is then
                                  launched step by step (its one-launch form needs all its workgroups resident together) */
@@ -381,7 +384,7 @@ typedef struct {
                                  loss.backward() hands it over as a device scalar; no elementwise launch for dslp * go).  Not with
                                  partial-sampling decodes */
 } cic_decode_bwd_io;
-enum { CIC_BWD_ALL = 0, CIC_BWD_LOGIT = 1, CIC_BWD_REST = 2 };
+enum { CIC_BWD_ALL = 0, CIC_BWD_LOGIT = 1, CIC_BWD_REST = 2, CIC_BWD_LOOP = 3, CIC_BWD_TAIL = 4 };
 size_t cic_speaker_decode_bwd_ws_bytes(const cic_speaker_dims* d);
 /* autograd of cic_speaker_decode_fwd: straight-through sampler, logit layer, BPTT through
  * Att2in2Core/Attention, embeddings, ctx2att, att_embed.  io must be the struct of the
