@@ -61,3 +61,11 @@ def test_one_launch_teacher_forced_recurrence_equals_the_per_step_launches():
         for case in ('plain', 'ragged_regions'):
             d = doc[f'B{B}_{case}']
             assert d['finite'] and d['loss_rel_diff'] < 2e-6 and d['max_grad_rel_diff'] < 1e-5 and d['n_grad_buffers'] > 0
+
+
+@pytest.mark.timeout(900)
+def test_one_launch_loops_at_a_batch_that_is_not_a_multiple_of_their_16_row_strips():
+    doc = _run('gru_seq_check.py', '--iters', '2', '--batch', '100')
+    assert doc['gru_seq_check'] == 'ok' and doc['uneven_load']['mismatches'] == 0 and doc['uneven_load']['backward_mismatches'] == 0
+    doc = _run('bptt_seq_check.py', '--iters', '2', '--batch', '100')
+    assert doc['bptt_seq_check'] == 'ok' and doc['uneven_load']['mismatches'] == 0
