@@ -301,6 +301,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(cic_gemm_args g, int 
 //                          (the hardware transpose read hands every lane 4 consecutive k of its row; no transposing store).
 // Same workgroup / tail / epilogue scheme as gemm_kernel.
 // ---------------------------------------------------------------------------------------------
+#ifdef CIC_DEVTOOLS
+__device__ unsigned long long* g_bfx_stamps = nullptr;   // development build: phase times of gemm_bfx_kernel's K loop
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -405,23 +408,34 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bfx_kernel(cic_gemm_args g, 
     const int per = (nk_all + nslice - 1) / nslice;
     const int kt0 = slice * per;
     const int nk = min(nk_all, kt0 + per);
+    // development build: cumulative phase times of the K loop per wave (cic_debug_set_bfx_stamps): [workgroup][wave][8] =
+    // waiting at the first barrier, store phase (incl. the wait for the tile's global loads), second barrier, load issue, MFMAs,
+    // K tiles, start, end  (100 MHz ticks)
+    unsigned long long* stamps = CIC_STAMP_BUF(g_bfx_stamps);
+    unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = 0, tstart = 0;
+    if (stamps) tstart = tprev = __builtin_amdgcn_s_memrealtime();
+#define BFX_T(i) if (stamps) { const unsigned long long tn = __builtin_amdgcn_s_memrealtime(); tacc[i] += tn - tprev; tprev = tn; }
+    auto load_tiles = [&](int kt) {
+        LA_::load(ra, g.A, g.lda, m0, g.M, kt * BK, K, tid);
+        LB_::load(rb, g.B, g.ldb, n0, g.N, kt * BK, K, tid);
+    };
     if (kt0 < nk) {
-        LA_::load(ra, g.A, g.lda, m0, g.M, kt0 * BK, K, tid);
-        LB_::load(rb, g.B, g.ldb, n0, g.N, kt0 * BK, K, tid);
+        load_tiles(kt0);
 #pragma unroll 1
         for (int kt = kt0; kt < nk; ++kt) {
             __syncthreads();   // everyone is done reading the previous tile
+            BFX_T(0)
             TA::store(ra, LA, tid);
             TB::store(rb, LB, tid);
             if (do_colsum) {
 #pragma unroll
                 for (int i = 0; i < LA_::NV; ++i) cs4 += ra[i];
             }
+            BFX_T(1)
             __syncthreads();
-            if (kt + 1 < nk) {   // next tile in flight under the MFMAs
-                LA_::load(ra, g.A, g.lda, m0, g.M, (kt + 1) * BK, K, tid);
-                LB_::load(rb, g.B, g.ldb, n0, g.N, (kt + 1) * BK, K, tid);
-            }
+            BFX_T(2)
+            if (kt + 1 < nk) load_tiles(kt + 1);   // next tile in flight under the MFMAs
+            BFX_T(3)
 #pragma unroll
             for (int s = 0; s < BK / 16; ++s) {
                 bf16x8 af[TM][NP], bf[TN][NP];
@@ -446,7 +460,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bfx_kernel(cic_gemm_args g, 
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][pa], bf[j][pb], acc[i][j], 0, 0, 0);
                     }
             }
+            if (stamps) { asm volatile("" :: "v"(acc[0][0][0])); BFX_T(4) }
         }
+    }
+#undef BFX_T
+    if (stamps && lane == 0) {
+        unsigned long long* o = stamps + ((size_t)blockIdx.x * (THREADS / 64) + wave) * 8;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) o[i] = tacc[i];
+        o[5] = (unsigned long long)(nk - kt0); o[6] = tstart; o[7] = __builtin_amdgcn_s_memrealtime();
     }
     if (do_colsum) {                    // block-uniform
         constexpr int QR = BM / 4, GROUPS = THREADS / QR;
@@ -2357,6 +2379,10 @@ extern "C" int cic_debug_gemm_tail_split(int on) {
     return 0;
 }
 
+extern "C" int cic_debug_set_bfx_stamps(unsigned long long* buf) {
+    CIC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_bfx_stamps), &buf, sizeof(buf)));
+    return 0;
+}
 extern "C" int cic_debug_set_stamps(unsigned long long* buf) {
     CIC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)));
     return 0;

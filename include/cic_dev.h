@@ -29,6 +29,9 @@ int cic_debug_set_attn_stamps(unsigned long long* buf);
  * bit 27: the logit walker without its fused vocabulary epilogue (the row partials then come from cic_logit_partials);
  * bit 28: the LDS-tiled products on the f32-input MFMA only (no bf16-part kernel) */
 int cic_debug_gemm_tail_split(int on);
+/* diagnostics: cumulative phase times of gemm_bfx_kernel's K loop, [workgroup][wave][8] 100 MHz ticks: waiting at the first barrier,
+ * store phase (incl. the wait for the tile's global loads), second barrier, load issue, MFMAs, K tiles, start, end; NULL = off */
+int cic_debug_set_bfx_stamps(unsigned long long* buf);
 /* diagnostics: 0 = the decode engines launch the attention query product on its own (A/B timing of the column split) */
 int cic_debug_gates_att_fused(int on);
 /* diagnostics: 0 = the decode engines run every step in full even after every caption has ended (A/B of the early stop) */
