@@ -245,7 +245,10 @@ template <int GPS, int KS>
 __global__ __launch_bounds__(KS * 64) void gru_seq_kernel(float* __restrict__ h_all, const float* __restrict__ W,
                                                           const float* __restrict__ b_hh, const float* __restrict__ gi_all,
                                                           const int32_t* __restrict__ len, float* __restrict__ gh_all,
-                                                          unsigned* __restrict__ cnt_base, unsigned* __restrict__ err, int B, int J, int Lp) {
+                                                          unsigned* __restrict__ cnt_base, unsigned* __restrict__ err, int B, int J, int Lp,
+                                                          int row0, int row_end) {
+    // rows [row0, row_end) of the batch: a batch of more than CUs / 32 strips is walked in row blocks, one launch each (rows are
+    // independent of each other); B stays the row count of the slabs
     static_assert(KS == 8 && GPS == 8, "J = 1024: 8 k groups of 16 per wave; 8 accumulator registers (2 unit tiles x 4) dealt one per wave");
     constexpr int WR = GRUF_WR, WL = GRUF_WL;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -263,12 +266,12 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_kernel(float* __restrict__ h_
         strip = xcd / xs;
         jt = (xcd % xs) * (tiles_j / xs) + local;
     }
-    const int m0 = strip * 16;
+    const int m0 = row0 + strip * 16;
     const int col = jt * 32 + 16 * (ks >> 2) + li;        // the output this wave finishes: register ks & 3 of unit tile ks >> 2
     const int orow = m0 + 4 * lq + (ks & 3);
-    const int orc = orow < B ? orow : B - 1;
+    const int orc = orow < row_end ? orow : row_end - 1;
     const int ln = len[orc];
-    unsigned* cnt = cnt_base + (size_t)strip * (Lp + 1);  // cnt[t]: workgroups of this strip that have published h_t
+    unsigned* cnt = cnt_base + (size_t)(row0 / 16 + strip) * (Lp + 1);  // cnt[t]: workgroups of this strip that have published h_t
     const size_t slab = (size_t)B * J;
     // the weight tile, once: B fragments f = (gate g, unit tile ct, k group i) of this wave's K slice
     f32x4 wf[WR];
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_kernel(float* __restrict__ h_
     }
     const float bh0 = b_hh[col], bh1 = b_hh[J + col], bh2 = b_hh[2 * J + col];
     float poison = 0.f;
-    if (orow < B) h_all[(size_t)orow * J + col] = 0.f;    // h_0 (read by the backward pass; this kernel never reads it)
+    if (orow < row_end) h_all[(size_t)orow * J + col] = 0.f;    // h_0 (read by the backward pass; this kernel never reads it)
     __syncthreads();
     for (int t = 0; t < Lp; ++t) {
         const float* gi = gi_all + (size_t)t * B * 3 * J;
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_kernel(float* __restrict__ h_
             const auto hsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(h_all + (size_t)t * slab), 0,
                                                                 (int)(slab * sizeof(float)), 0x00020000);
             f32x4 af[GPS];
-            const int mc = min(m0 + li, B - 1);             // rows past B repeat row B-1: their sums are never stored
+            const int mc = min(m0 + li, row_end - 1);       // rows past the block repeat its last row: their sums are never stored
 #pragma unroll
             for (int i = 0; i < GPS; ++i) {
                 const int k = 16 * (ks * GPS + i) + 4 * lq;
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_kernel(float* __restrict__ h_
                 ghv[g] = v + (g == 0 ? bh0 : (g == 1 ? bh1 : bh2));
             }
         }
-        if (orow < B) {
+        if (orow < row_end) {
             const size_t o = (size_t)orow * 3 * J + col;
             gh_out[o] = ghv[0];
             gh_out[o + J] = ghv[1];
@@ -403,7 +406,8 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_bwd_kernel(const float* __res
                                                               const int32_t* __restrict__ pool_arg,
                                                               // [Lp,B,zero_n] cleared on the way (zero_n <= J: the K-sliced product
                                                               // dx_emb = dgi W_ih after the loop adds into it), or null
-                                                              float* __restrict__ zero_lbe, int zero_n) {
+                                                              float* __restrict__ zero_lbe, int zero_n, int row0, int row_end) {
+    // rows [row0, row_end) of the batch (see gru_seq_kernel)
     static_assert(KS == 8, "8 accumulator registers (2 column tiles x 4) dealt one per wave");
     constexpr int GPS = GRUB_GPS, GR = GRUB_GR, GL = GRUB_GL;
     constexpr int GPC = 4, NCH = GPS / GPC, NBUF = 3;     // the A rows arrive in chunks of GPC groups, NBUF chunks in flight
@@ -423,16 +427,16 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_bwd_kernel(const float* __res
         strip = xcd / xs;
         jt = (xcd % xs) * (tiles_j / xs) + local;
     }
-    const int m0 = strip * 16;
+    const int m0 = row0 + strip * 16;
     const int col = jt * 32 + 16 * (ks >> 2) + li;          // the output this wave finishes: register ks & 3 of column tile ks >> 2
     const int orow = m0 + 4 * lq + (ks & 3);
-    const int orc = orow < B ? orow : B - 1;
+    const int orc = orow < row_end ? orow : row_end - 1;
     const int ln = len[orc];
     const int J3 = 3 * J;
-    unsigned* cnt = cnt_base + (size_t)strip * (Lp + 1);    // cnt[t]: workgroups of this strip that have published dgh_t
+    unsigned* cnt = cnt_base + (size_t)(row0 / 16 + strip) * (Lp + 1);    // cnt[t]: workgroups of this strip that have published dgh_t
     if (tid == 0) smax_s = 0;
     __syncthreads();
-    if (tid < 16) atomicMax(&smax_s, len[min(m0 + tid, B - 1)]);
+    if (tid < 16) atomicMax(&smax_s, len[min(m0 + tid, row_end - 1)]);
     // the weight tile, once: B fragments (k = 16*group + 4*lq + s, n = column li of tile ct) of this wave's K slice
     f32x4 wf[GR][2];
 #pragma unroll
@@ -460,10 +464,10 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_bwd_kernel(const float* __res
         float* dgi = dgi_all + (size_t)t * gslab;
         float* dgh = dgh_all + (size_t)t * gslab;
         const auto hdst = __builtin_amdgcn_make_buffer_rsrc(dgh, 0, (int)(gslab * sizeof(float)), 0x00020000);
-        if (zero_lbe && orow < B && col < zero_n) zero_lbe[((size_t)t * B + orow) * zero_n + col] = 0.f;
+        if (zero_lbe && orow < row_end && col < zero_n) zero_lbe[((size_t)t * B + orow) * zero_n + col] = 0.f;
         if (t >= smax) {
             // no caption of the strip reaches step t: zero gate gradients, d passes through (no pooled term either)
-            if (orow < B) {
+            if (orow < row_end) {
                 dgi[o] = 0.f; dgi[o + J] = 0.f; dgi[o + 2 * J] = 0.f;
                 dgh[o] = 0.f; dgh[o + J] = 0.f; dgh[o + 2 * J] = 0.f;
             }
@@ -497,7 +501,7 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_bwd_kernel(const float* __res
                 dprev = d * z;
             }
             if (poison != 0.f) { gir = poison; giz = poison; gin = poison; ghn = poison; }
-            if (orow < B) {
+            if (orow < row_end) {
                 dgi[o] = gir; dgi[o + J] = giz; dgi[o + 2 * J] = gin;
                 // dgh_t is handed to the strip's other workgroups: write-through stores
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gir), hdst, (int)(o * 4), 0, 16);
@@ -527,7 +531,7 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_bwd_kernel(const float* __res
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // compiler only: no load of dgh_t above the poll
         if (!ok_s) poison = __builtin_nanf("");
         GRU_STAMP(3);
-        const int mc = min(m0 + li, B - 1);                 // rows past B repeat row B-1: their sums are never stored
+        const int mc = min(m0 + li, row_end - 1);           // rows past the block repeat its last row: their sums are never stored
         f32x4 af[NBUF][GPC];
         auto load_chunk = [&](int c) {                      // every load of the handed-off bytes is sc1 (aux 16)
 #pragma unroll
@@ -947,22 +951,28 @@ static int listener_fwd_impl(const cic_listener_dims* dp, const cic_listener_par
     RUN(gemm_nt(w.x_emb, E, p->w_ih, E, w.gi_all, 3 * J, Lp * B, 3 * J, E, p->b_ih, false, false, st));
     const bool fused_step = g_gru_fused && J == 1024;       // the flagship width: one launch per step (see the kernel)
     bool seq_kernel = false;
+    int seq_rows = 0;
     if (g_gru_fused >= 2 && J == 1024 && !io->device_shared) {
         // the one-launch form needs every workgroup resident at once: one per CU (512 threads holding the weight tile in
         // ~200 VGPRs each fill a CU's register file)
         int dev = 0, cus = 0;
         CIC_HIP(hipGetDevice(&dev));
         CIC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        seq_kernel = cic_cdiv(B, 16) * (J / 32) <= cus;
+        seq_rows = (cus / (J / 32)) * 16;            // rows one launch can walk with every workgroup resident
+        seq_kernel = seq_rows >= 16;
     }
     if (seq_kernel) {
         static DeviceOnce attr_set;
         if (attr_set.first())
             CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_kernel<8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)GRUF_LDS_BYTES));
-        hipLaunchKernelGGL((gru_seq_kernel<8, 8>), dim3(cic_cdiv(B, 16) * (J / 32)), dim3(512), GRUF_LDS_BYTES, st, w.h_all, p->w_hh, p->b_hh,
-                           w.gi_all, w.len, w.gh_all, w.sync, w.sync + 2 * (size_t)cic_cdiv(B, 16) * (Lp + 1), B, J, Lp);
-        CIC_LAUNCH_CHECK();
+        for (int row0 = 0; row0 < B; row0 += seq_rows) {      // (B = 128: one launch; B = 256: two row blocks)
+            const int row_end = row0 + seq_rows < B ? row0 + seq_rows : B;
+            hipLaunchKernelGGL((gru_seq_kernel<8, 8>), dim3(cic_cdiv(row_end - row0, 16) * (J / 32)), dim3(512), GRUF_LDS_BYTES, st, w.h_all,
+                               p->w_hh, p->b_hh, w.gi_all, w.len, w.gh_all, w.sync, w.sync + 2 * (size_t)cic_cdiv(B, 16) * (Lp + 1), B, J, Lp,
+                               row0, row_end);
+            CIC_LAUNCH_CHECK();
+        }
     } else {
         CIC_HIP(hipMemsetAsync(w.h_all, 0, sizeof(float) * B * J, st));
     }
@@ -1039,12 +1049,14 @@ static int listener_bwd_impl(const cic_listener_dims* dp, const cic_listener_par
     float* dh = w.dh;
     float* dh2 = w.dh2;
     bool seq_kernel = false;
+    int seq_rows = 0;
     if (g_gru_fused >= 2 && J == 1024 && !io->device_shared) {
         // as in the forward pass: every workgroup resident at once, one per CU
         int dev = 0, cus = 0;
         CIC_HIP(hipGetDevice(&dev));
         CIC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        seq_kernel = cic_cdiv(B, 16) * (J / 32) <= cus;
+        seq_rows = (cus / (J / 32)) * 16;
+        seq_kernel = seq_rows >= 16;
     }
     if (seq_kernel) {
         static DeviceOnce attr_set;
@@ -1052,10 +1064,13 @@ static int listener_bwd_impl(const cic_listener_dims* dp, const cic_listener_par
             CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_bwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)GRUB_LDS_BYTES));
         unsigned* cnt_b = w.sync + (size_t)cic_cdiv(B, 16) * (Lp + 1);
-        hipLaunchKernelGGL((gru_seq_bwd_kernel<8>), dim3(cic_cdiv(B, 16) * (J / 32)), dim3(512), GRUB_LDS_BYTES, st, w.h_all, p->w_hh,
-                           w.gi_all, w.gh_all, w.len, dh, w.dgi_all, w.dgh_all, cnt_b, cnt_b + (size_t)cic_cdiv(B, 16) * (Lp + 1), B, J,
-                           Lp, d.pool, w.d_pool, w.pool_arg, E <= J ? w.dx_emb : nullptr, E);
-        CIC_LAUNCH_CHECK();
+        for (int row0 = 0; row0 < B; row0 += seq_rows) {
+            const int row_end = row0 + seq_rows < B ? row0 + seq_rows : B;
+            hipLaunchKernelGGL((gru_seq_bwd_kernel<8>), dim3(cic_cdiv(row_end - row0, 16) * (J / 32)), dim3(512), GRUB_LDS_BYTES, st, w.h_all,
+                               p->w_hh, w.gi_all, w.gh_all, w.len, dh, w.dgi_all, w.dgh_all, cnt_b, cnt_b + (size_t)cic_cdiv(B, 16) * (Lp + 1),
+                               B, J, Lp, d.pool, w.d_pool, w.pool_arg, E <= J ? w.dx_emb : nullptr, E, row0, row_end);
+            CIC_LAUNCH_CHECK();
+        }
     }
     for (int t = Lp - 1; t >= 0 && !seq_kernel; --t) {
         float* dgi = w.dgi_all + (size_t)t * B * 3 * J;

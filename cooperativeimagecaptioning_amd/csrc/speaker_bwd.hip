@@ -562,6 +562,7 @@ struct BpttArgs {
     const int32_t* L;                                                       // the decode's length on the device, or null
     float scale;
     int B, K, T;
+    int row0, row_end;                                                      // rows [row0, row_end) of the batch: one launch per row block
 };
 constexpr int BPTT_GA = 8, BPTT_GI = 12, BPTT_GC = 4;      // k groups of 16 per wave: (a, b) gate columns / (i, f, o) / d_att_h
 constexpr size_t BPTT_LDS_BYTES = sizeof(float) * ((size_t)8 * (BPTT_GA + BPTT_GC) * 64 * 4 + 8 * 4 * 64 + 8 * 64);
@@ -590,13 +591,14 @@ __global__ __launch_bounds__(KS * 64) void spk_bptt_seq_kernel(BpttArgs a) {
         strip = xcd / xs;
         jt = (xcd % xs) * (TJ / xs) + local;
     }
-    const int m0 = strip * 16;
+    const int RE = a.row_end;
+    const int m0 = a.row0 + strip * 16;
     const int col = jt * 16 + li;
     const bool owner = ks < 4;                            // waves 0-3 finish the 16 x 16 outputs: register ks of the tile
     const int orow = m0 + 4 * lq + (ks & 3);
-    const int orc = orow < B ? orow : B - 1;
-    const int mc = min(m0 + li, B - 1);                   // A rows; rows past B repeat row B-1: their sums are never stored
-    unsigned* cnt = a.cnt + (size_t)strip * T * 3;
+    const int orc = orow < RE ? orow : RE - 1;
+    const int mc = min(m0 + li, RE - 1);                  // A rows; rows past the block repeat its last row: their sums are never stored
+    unsigned* cnt = a.cnt + (size_t)(a.row0 / 16 + strip) * T * 3;
     // ---- the weight tiles, once --------------------------------------------------------------------------------------
     f32x4 wh_ab[GA], wh_ifo[GI];
 #pragma unroll
@@ -672,7 +674,7 @@ __global__ __launch_bounds__(KS * 64) void spk_bptt_seq_kernel(BpttArgs a) {
     const auto r_dpre = uniform_rsrc(a.dpre_all, (size_t)T * B * H5 * sizeof(float));
     const auto r_dres = uniform_rsrc(a.d_att_res_all, (size_t)T * B * H * sizeof(float));
     const auto r_dah = uniform_rsrc(a.d_att_h_all, (size_t)T * B * H * sizeof(float));
-    const int imc = img < B ? img : B - 1;
+    const int imc = img < RE ? img : RE - 1;
     const auto r_att = uniform_rsrc(const_cast<float*>(a.att) + (size_t)imc * K * H, (size_t)K * H * sizeof(float));
     const auto r_patt = uniform_rsrc(const_cast<float*>(a.p_att) + (size_t)imc * K * H, (size_t)K * H * sizeof(float));
     for (int t = T - 1; t >= 0; --t) {
@@ -710,7 +712,7 @@ __global__ __launch_bounds__(KS * 64) void spk_bptt_seq_kernel(BpttArgs a) {
             float gb = pb > pa ? dg : (pa == pb ? 0.5f * dg : 0.f);
             dc = dcc * fg;
             if (poison != 0.f) { gi = poison; gf = poison; go = poison; ga = poison; gb = poison; }
-            if (orow_t < B) {
+            if (orow_t < RE) {
                 const int o = (int)(((size_t)orow_t * H5 + col_t) * 4);
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gi), r_dpre, o, so5, 16);
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gf), r_dpre, o + 4 * H, so5, 16);
@@ -724,7 +726,7 @@ __global__ __launch_bounds__(KS * 64) void spk_bptt_seq_kernel(BpttArgs a) {
         if (!live) {            // grid-uniform: nothing but zeros flows through this step (dpre above came out as zeros)
             if (jt == 0)
                 for (int i = tid; i < 16 * K; i += KS * 64)
-                    if (m0 + i / K < B) a.ddot_all[((size_t)t * B + m0 + i / K) * K + i % K] = 0.f;
+                    if (m0 + i / K < RE) a.ddot_all[((size_t)t * B + m0 + i / K) * K + i % K] = 0.f;
             dh = 0.f;
             continue;
         }
@@ -758,7 +760,7 @@ __global__ __launch_bounds__(KS * 64) void spk_bptt_seq_kernel(BpttArgs a) {
 #pragma unroll
             for (int w = 0; w < KS; ++w) v += red[(w * 4 + ks) * 64 + lane_t];
             if (poison != 0.f) v = poison;
-            if (orow_t < B) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_dres, (int)(((size_t)orow_t * H + col_t) * 4), so1, 16);
+            if (orow_t < RE) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_dres, (int)(((size_t)orow_t * H + col_t) * 4), so1, 16);
         }
         BPTT_STAMP(3);
         publish(cnt + t * 3 + 1, true);
@@ -767,7 +769,7 @@ __global__ __launch_bounds__(KS * 64) void spk_bptt_seq_kernel(BpttArgs a) {
         // waited for: it depends on nothing), then p_att for d att_h (requested as soon as the att rows are consumed).  Buffer
         // loads over the image's [K,H] block: one offset register per lane, the region group in the scalar offset, regions
         // beyond K read as zeros (out of the resource's range).  The odd workgroups go straight on to part 4.
-        const bool do_att = att_wg && img < B;
+        const bool do_att = att_wg && img < RE;
         if (att_wg) {
             constexpr int JMAX = 9;                          // regions 4 j + rg, K <= 36
             const int vo = (rg_t * H + 4 * col4_t) * 4;
@@ -1157,11 +1159,13 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     float* dh_out = g.dh_b;
     // the flagship widths walk the loop in ONE launch (spk_bptt_seq_kernel): every workgroup resident at once, one per CU
     bool seq_kernel = false;
+    int seq_rows = 0;
     if (g_bptt_seq && !ps && !fc && H == 512 && A == 512 && K >= 1 && K <= 36 && !bio->device_shared) {
         int dev = 0, cus = 0;
         CIC_HIP(hipGetDevice(&dev));
         CIC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        seq_kernel = cic_cdiv(B, 16) * (H / 16) <= cus;
+        seq_rows = (cus / (H / 16)) * 16;                     // rows one launch can walk with every workgroup resident
+        seq_kernel = seq_rows >= 16;
     }
     if (seq_kernel && do_loop) {
         static DeviceOnce attr_set;
@@ -1179,8 +1183,12 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         ba.L = g_bptt_early_stop ? io->L : nullptr;
         ba.zero_tbh = (E == H && !ps) ? g.dx_all : nullptr;       // the K-sliced d x product after the loop adds into it
         ba.scale = scale; ba.B = B; ba.K = K; ba.T = T;
-        hipLaunchKernelGGL((spk_bptt_seq_kernel<8>), dim3(cic_cdiv(B, 16) * (H / 16)), dim3(512), BPTT_LDS_BYTES, st, ba);
-        CIC_LAUNCH_CHECK();
+        for (int row0 = 0; row0 < B; row0 += seq_rows) {          // (B = 128: one launch; B = 256: two row blocks)
+            ba.row0 = row0;
+            ba.row_end = row0 + seq_rows < B ? row0 + seq_rows : B;
+            hipLaunchKernelGGL((spk_bptt_seq_kernel<8>), dim3(cic_cdiv(ba.row_end - row0, 16) * (H / 16)), dim3(512), BPTT_LDS_BYTES, st, ba);
+            CIC_LAUNCH_CHECK();
+        }
     }
     for (int t = T - 1; t >= 0 && !seq_kernel && do_loop; --t) {
         const uint8_t* ok = io->out_keep ? io->out_keep + (size_t)(t + (fc ? 1 : 0)) * B * H : nullptr;

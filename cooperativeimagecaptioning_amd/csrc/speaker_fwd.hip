@@ -449,6 +449,7 @@ struct TeacherSeqArgs {
     unsigned *cnt, *err;                                      // [strips][T][3] counters (zeroed by the launcher), 1 word
     float scale;
     int B, K, T;
+    int row0, row_end;                                        // rows [row0, row_end) of the batch: one launch per row block
 };
 constexpr size_t TEACHER_LDS_BYTES = sizeof(float) * ((size_t)8 * 8 * 64 * 4 + 8 * 6 * 4 * 64 + 8 * 64);
 constexpr unsigned long long TEACHER_SPIN_TICKS = 1000ull * 100000ull;    // 1 s of the 100 MHz s_memrealtime counter
@@ -472,13 +473,14 @@ __global__ __launch_bounds__(KS * 64) void spk_teacher_seq_kernel(TeacherSeqArgs
         strip = xcd / xs;
         jt = (xcd % xs) * (TJ / xs) + local;
     }
-    const int m0 = strip * 16;
+    const int RE = a.row_end;
+    const int m0 = a.row0 + strip * 16;
     const int col = jt * 16 + li;
     const bool owner = ks < 4;                            // waves 0-3 finish the 16 x 16 outputs: register ks of every tile
     const int orow = m0 + 4 * lq + (ks & 3);
-    const int orc = orow < B ? orow : B - 1;
-    const int mc = min(m0 + li, B - 1);                   // A rows; rows past B repeat row B-1: their sums are never stored
-    unsigned* cnt = a.cnt + (size_t)strip * T * 3;
+    const int orc = orow < RE ? orow : RE - 1;
+    const int mc = min(m0 + li, RE - 1);                  // A rows; rows past the block repeat its last row: their sums are never stored
+    unsigned* cnt = a.cnt + (size_t)(a.row0 / 16 + strip) * T * 3;
     // ---- the weight tiles, once: B fragments (k = 16 (4 ks + i) + 4 lq + s, n = unit li of the tile) -----------------------------
     f32x4 wh[6][GP];
 #pragma unroll
@@ -502,8 +504,8 @@ __global__ __launch_bounds__(KS * 64) void spk_teacher_seq_kernel(TeacherSeqArgs
     const float b_alpha = a.alpha_b[0];
     const int img = m0 + (jt >> 1);
     const bool att_wg = (jt & 1) == 0;
-    const int imc = img < B ? img : B - 1;
-    const bool do_att = att_wg && img < B;
+    const int imc = img < RE ? img : RE - 1;
+    const bool do_att = att_wg && img < RE;
     auto uniform_rsrc = [](const float* ptr, size_t bytes) {
         const unsigned long long u = reinterpret_cast<unsigned long long>(ptr);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
@@ -586,7 +588,7 @@ __global__ __launch_bounds__(KS * 64) void spk_teacher_seq_kernel(TeacherSeqArgs
                 }
             }
         }
-        if (owner && orow_t < B) {
+        if (owner && orow_t < RE) {
             float q = hs[5] + b_att;
             if (poison != 0.f) q = poison;
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, q), r_ah, (int)(((size_t)orow_t * H + col_t) * 4), so_h, 16);
@@ -696,7 +698,7 @@ __global__ __launch_bounds__(KS * 64) void spk_teacher_seq_kernel(TeacherSeqArgs
             float h2 = og * fast_tanh(c2);                         // :527
             if (poison != 0.f) { c2 = poison; h2 = poison; }
             c_state = c2;
-            if (orow_t < B) {
+            if (orow_t < RE) {
                 pre[0] = pi; pre[H] = pf; pre[2 * H] = po; pre[3 * H] = pa; pre[4 * H] = pb;      // kept for the backward pass
                 const size_t e = (size_t)orow_t * H + col_t;
                 a.c_all[rowH + (size_t)B * H + e] = c2;
@@ -1684,7 +1686,7 @@ bool cic_teacher_seq_ok(int B, int K, int H, int A, int E) {
     if (!(H == 512 && A == 512 && K >= 1 && K <= 36)) return false;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-    return cic_cdiv(B, 16) * (H / 16) <= cus;
+    return cus >= H / 16;          // at least one strip of 16 rows resident: larger batches are walked in row blocks
 }
 int cic_teacher_seq(const TeacherSeqLaunch& L, hipStream_t st) {
     static DeviceOnce attr_set;
@@ -1700,7 +1702,16 @@ int cic_teacher_seq(const TeacherSeqLaunch& L, hipStream_t st) {
     a.alpha_all = L.alpha_all; a.dot_all = L.dot_all; a.out_all = L.out_all;
     a.cnt = L.sync; a.err = L.sync + (size_t)strips * L.T * 3;
     a.scale = L.scale; a.B = L.B; a.K = L.K; a.T = L.T;
-    hipLaunchKernelGGL((spk_teacher_seq_kernel<8>), dim3(strips * 32), dim3(512), TEACHER_LDS_BYTES, st, a);
-    CIC_LAUNCH_CHECK();
+    int dev = 0, cus = 0;
+    CIC_HIP(hipGetDevice(&dev));
+    CIC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int seq_rows = (cus / 32) * 16;                       // rows one launch can walk with every workgroup resident
+    if (seq_rows < 16) { cic_set_error("teacher_seq: fewer than 32 CUs"); return 1; }
+    for (int row0 = 0; row0 < L.B; row0 += seq_rows) {          // (B = 128: one launch; B = 256: two row blocks)
+        a.row0 = row0;
+        a.row_end = row0 + seq_rows < L.B ? row0 + seq_rows : L.B;
+        hipLaunchKernelGGL((spk_teacher_seq_kernel<8>), dim3(cic_cdiv(a.row_end - row0, 16) * 32), dim3(512), TEACHER_LDS_BYTES, st, a);
+        CIC_LAUNCH_CHECK();
+    }
     return 0;
 }

@@ -69,3 +69,17 @@ def test_one_launch_loops_at_a_batch_that_is_not_a_multiple_of_their_16_row_stri
     assert doc['gru_seq_check'] == 'ok' and doc['uneven_load']['mismatches'] == 0 and doc['uneven_load']['backward_mismatches'] == 0
     doc = _run('bptt_seq_check.py', '--iters', '2', '--batch', '100')
     assert doc['bptt_seq_check'] == 'ok' and doc['uneven_load']['mismatches'] == 0
+
+
+@pytest.mark.timeout(1200)
+def test_one_launch_loops_walk_a_batch_of_more_than_128_rows_in_row_blocks():
+    """256 rows = two full row blocks of 8 strips (configs[3]); 144 rows = a full block and a block of one strip."""
+    for B in ('256', '144'):
+        doc = _run('gru_seq_check.py', '--iters', '2', '--batch', B)
+        assert doc['gru_seq_check'] == 'ok' and doc['uneven_load']['mismatches'] == 0 and doc['uneven_load']['backward_mismatches'] == 0
+        doc = _run('bptt_seq_check.py', '--iters', '2', '--batch', B)
+        assert doc['bptt_seq_check'] == 'ok' and doc['uneven_load']['mismatches'] == 0
+    doc = _run('teacher_seq_check.py', '--iters', '2', '--batches', '256,144')
+    assert doc['teacher_seq_check'] == 'ok'
+    for B in (256, 144):
+        assert doc[f'B{B}_uneven_load']['mismatches'] == 0

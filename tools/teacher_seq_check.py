@@ -23,13 +23,14 @@ from cooperativeimagecaptioning_amd.misc import rewards  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=30)
+    ap.add_argument('--batches', default='64,128', help='batch sizes, comma separated (more than 128 rows: several row blocks)')
     args = ap.parse_args()
     lib = _lib.lib
     lib.cic_debug_teacher_seq.argtypes = [C.c_int]
     dev = torch.device('cuda', 0)
     rewards.init_scorer('corpus')
     report, ok = {}, True
-    for B in (64, 128):
+    for B in [int(x) for x in args.batches.split(',')]:
         opt = synthetic.default_opt(batch_size=B, is_alternating=0, phase=2, caption_loss_weight=1.0, retrieval_reward_weight=0.0,
                                     cider_optimization=0, alternating_turn=None)
         torch.manual_seed(0)
