@@ -14,6 +14,11 @@ lib.cic_debug_set_bfx_stamps.argtypes = [C.c_void_p]
 dev = 'cuda'
 SHAPES = [('d_out dlogits W', 2048, 512, 9488, True, False, True), ('dW hh dgh^T h', 3072, 1024, 2176, False, False, True),
           ('d_onehot dx E^T', 2048, 9488, 512, True, True, False), ('att_embed fwd', 4608, 512, 2048, True, True, False)]
+if len(sys.argv) > 1 and sys.argv[1] == '--occupancy':
+    # the same product at 2.3 rounds of 2 workgroups per CU, at ~1.2 workgroups per CU, and on 150 / 75 CUs only: does a wave's K tile
+    # get faster when fewer workgroups ask for operands at the same time?
+    SHAPES = [('d_onehot 1200 tiles', 2048, 9488, 512, True, True, False), ('d_onehot 300 tiles', 512, 9488, 512, True, True, False),
+              ('d_onehot 150 tiles', 256, 9488, 512, True, True, False), ('d_onehot 75 tiles', 128, 9488, 512, True, True, False)]
 for name, M, N, K, akc, bkc, free in SHAPES:
     A = torch.randn((M, K) if akc else (K, M), device=dev)
     B = torch.randn((N, K) if bkc else (K, N), device=dev)
@@ -28,6 +33,9 @@ for name, M, N, K, akc, bkc, free in SHAPES:
     lib.cic_debug_set_bfx_stamps(None)
     s = buf.cpu().numpy().reshape(4096, 8, 8).astype(np.float64)
     used = s[:, :, 7] > 0
+    if not used.any():
+        print(f'{name}: M{M} N{N} K{K}: not dispatched to gemm_bfx_kernel')
+        continue
     w = s[used]                       # [waves, 8]
     nk = w[:, 5]
     per = w[:, :5] * 10.0 / nk[:, None]      # ns per K tile
