@@ -24,3 +24,24 @@ class EngineLoss(torch.autograd.Function):
             raise RuntimeError('the engine workspace of this step was already consumed by a backward pass')
         fn(grad_out)
         return None, None, None
+
+
+_ONES = {}
+
+
+def engine_loss(loss_value, anchor, backward_fn):
+    """EngineLoss.apply whose result answers a bare ``loss.backward()`` (train.py:203-208) with a cached tensor of ones as the
+    upstream gradient: autograd otherwise makes one with a fill launch (5 us on a ~3 ms step) every iteration.  Any other use of the
+    loss (arithmetic on it, ``backward(gradient=...)``, ``torch.autograd.grad``) takes the ordinary path."""
+    out = EngineLoss.apply(loss_value, anchor, backward_fn)
+    tensor_backward = torch.Tensor.backward
+
+    def backward(gradient=None, *args, **kwargs):
+        if gradient is None:
+            key = (out.device, out.dtype, tuple(out.shape))
+            gradient = _ONES.get(key)
+            if gradient is None:
+                gradient = _ONES[key] = torch.ones(out.shape, dtype=out.dtype, device=out.device)
+        return tensor_backward(out, gradient, *args, **kwargs)
+    out.backward = backward
+    return out

@@ -27,27 +27,34 @@ __device__ unsigned long long* g_gru_stamps = nullptr;   // development build: [
 // ---- token preparation -----------------------------------------------------------------
 // generated captions: tokens = [<bos>, seq[:, 0:L]], lens from masks [1,1,(seq>0)[:, :L-1]]
 // (models/AlternatingJointModel.py:353-370)
-__global__ void prep_generated_kernel(const int32_t* __restrict__ seq, const float* __restrict__ stv,
+__global__ __launch_bounds__(256) void prep_generated_kernel(const int32_t* __restrict__ seq, const float* __restrict__ stv,
                                       const int32_t* __restrict__ Lp, int B, int T, int bos, int dense,
                                       int32_t* __restrict__ idx, float* __restrict__ val,
                                       int32_t* __restrict__ len, unsigned* __restrict__ sync, int nsync) {
     // dense != 0 (soft caption rows): positions 1..T are embedded by a dense product added afterwards, so
     // their gather contributes nothing (val = 0)
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    for (int i = b; i < nsync; i += gridDim.x * blockDim.x) sync[i] = 0u;    // hand-off counters of gru_seq_kernel
-    if (b >= B) return;
+    // one wave per caption, lane j = token j (T <= 63; longer captions: lanes stride): one round trip per row instead of T
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = gtid; i < nsync; i += gridDim.x * blockDim.x) sync[i] = 0u;    // hand-off counters of gru_seq_kernel
+    const int b = gtid >> 6, lane = threadIdx.x & 63;
+    if (b >= B) return;                                     // whole waves
     const int L = *Lp;
-    int n = 2;
-    idx[(size_t)b * (T + 1)] = bos;
-    val[(size_t)b * (T + 1)] = 1.0f;
-    for (int j = 0; j < T; ++j) {
+    int cnt = 0;
+    for (int j = lane; j < T; j += 64) {
         const int tok = seq[(size_t)b * T + j];
         idx[(size_t)b * (T + 1) + 1 + j] = (j < L && !dense) ? tok : 0;
         val[(size_t)b * (T + 1) + 1 + j] = dense ? 0.0f : ((j < L && stv) ? stv[(size_t)b * T + j] : 1.0f);
-        if (j < L - 1 && tok > 0) ++n;
+        if (j < L - 1 && tok > 0) ++cnt;
     }
-    if (n > L + 1) n = L + 1;
-    len[b] = n;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) {
+        idx[(size_t)b * (T + 1)] = bos;
+        val[(size_t)b * (T + 1)] = 1.0f;
+        int n = 2 + cnt;
+        if (n > L + 1) n = L + 1;
+        len[b] = n;
+    }
 }
 // ground-truth labels: idx = labels, lens = sum(masks > 0)   (VSEFCModel.py:83-85)
 __global__ void prep_labels_kernel(const int64_t* __restrict__ labels, const float* __restrict__ masks, int B, int Lp,
@@ -928,7 +935,7 @@ static int listener_fwd_impl(const cic_listener_dims* dp, const cic_listener_par
                            w.idx, w.val, w.len, w.sync, w.nsync);
     } else {
         CIC_REQUIRE(io->seq && io->L && Lp == d.T + 1);
-        hipLaunchKernelGGL(prep_generated_kernel, dim3(cic_cdiv(B, 256)), dim3(256), 0, st, io->seq, io->stv, io->L, B,
+        hipLaunchKernelGGL(prep_generated_kernel, dim3(cic_cdiv(B, 4)), dim3(256), 0, st, io->seq, io->stv, io->L, B,
                            d.T, d.V + 1, io->soft ? 1 : 0, w.idx, w.val, w.len, w.sync, w.nsync);
     }
     CIC_LAUNCH_CHECK();

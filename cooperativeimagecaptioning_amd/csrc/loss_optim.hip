@@ -7,15 +7,18 @@ namespace {
 // loss = sum_{b, t<L} slp[b,t] * coef[b] * m[b,t] / sum m,   m[b,0] = 1, m[b,t] = seq[b,t-1] > 0
 //   (gen_masks[:, 1:] of models/AlternatingJointModel.py:353-355; :292-297,:321-325,:421-428)
 // dslp (+)= weight * coef[b] * m[b,t] / sum m
-__global__ __launch_bounds__(256) void seq_loss_kernel(const float* __restrict__ slp, const int32_t* __restrict__ seq,
-                                                       const int32_t* __restrict__ Lp, const float* __restrict__ coef,
-                                                       float coef_sign, float weight, int B, int T,
-                                                       float* __restrict__ loss_out, float* __restrict__ dslp,
-                                                       int accumulate) {
-    __shared__ float sh[2][4];
+__global__ __launch_bounds__(1024) void seq_loss_kernel(const float* __restrict__ slp, const int32_t* __restrict__ seq,
+                                                        const int32_t* __restrict__ Lp, const float* __restrict__ coef,
+                                                        float coef_sign, float weight, int B, int T,
+                                                        float* __restrict__ loss_out, float* __restrict__ dslp,
+                                                        int accumulate) {
+    // one workgroup of 16 waves: at B x T = 2048 every thread owns two elements and the kernel is two round trips (loads,
+    // stores) around one barrier - with 256 threads it was eight dependent trips
+    constexpr int NT = 1024;
+    __shared__ float sh[2][NT / 64];
     const int L = min(*Lp, T);
     float num = 0.f, den = 0.f;
-    for (int i = threadIdx.x; i < B * T; i += 256) {
+    for (int i = threadIdx.x; i < B * T; i += NT) {
         const int b = i / T, t = i % T;
         const bool m = t < L && (t == 0 || seq[(size_t)b * T + t - 1] > 0);
         if (m) {
@@ -27,12 +30,13 @@ __global__ __launch_bounds__(256) void seq_loss_kernel(const float* __restrict__
     den = wave_sum(den);
     if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = num; sh[1][threadIdx.x >> 6] = den; }
     __syncthreads();
-    num = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
-    den = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    num = 0.f; den = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) { num += sh[0][w]; den += sh[1][w]; }
     if (threadIdx.x == 0 && loss_out) *loss_out = num / den;
     if (dslp) {
         const float k = weight / den;
-        for (int i = threadIdx.x; i < B * T; i += 256) {
+        for (int i = threadIdx.x; i < B * T; i += NT) {
             const int b = i / T, t = i % T;
             const bool m = t < L && (t == 0 || seq[(size_t)b * T + t - 1] > 0);
             const float g = m ? k * coef_sign * coef[b] : 0.f;
@@ -139,7 +143,7 @@ extern "C" int cic_loss_combine(const float* const* term, const float* weight, i
 extern "C" int cic_seq_loss(const float* slp, const int32_t* seq, const int32_t* L, const float* coef, float coef_sign,
                             float weight, int B, int T, float* loss_out, float* dslp, int accumulate, cic_stream_t s) {
     CIC_REQUIRE(slp && seq && L && coef && B > 0 && T > 0);
-    hipLaunchKernelGGL(seq_loss_kernel, dim3(1), dim3(256), 0, cic_s(s), slp, seq, L, coef, coef_sign, weight, B, T,
+    hipLaunchKernelGGL(seq_loss_kernel, dim3(1), dim3(1024), 0, cic_s(s), slp, seq, L, coef, coef_sign, weight, B, T,
                        loss_out, dslp, accumulate);
     CIC_LAUNCH_CHECK();
     return 0;

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from .. import engine
-from ..autograd_glue import EngineLoss
+from ..autograd_glue import EngineLoss, engine_loss
 from ..misc import utils
 from ..misc import rewards
 
@@ -282,7 +282,7 @@ class AlternatingJointModel(nn.Module):
                     step(go)
                 if i == last_lst and lst_grad and self.listener_grads_ready is not None:
                     self.listener_grads_ready()
-        return EngineLoss.apply(loss, anchor, backward)
+        return engine_loss(loss, anchor, backward)
 
     def forward(self, fc_feats, seq, masks, data, att_feats, att_masks, is_alternating=False, alternating_turn=None):
         """:433-555."""
@@ -329,7 +329,7 @@ class AlternatingJointModel(nn.Module):
         anchor = next((p for p in vse.parameters() if p.requires_grad), None)
         if anchor is None or not torch.is_grad_enabled():
             return loss.detach()
-        return EngineLoss.apply(loss, anchor, lambda go: vse.run_backward(res, g_scalar=(go * vw).reshape(1).contiguous()))
+        return engine_loss(loss, anchor, lambda go: vse.run_backward(res, g_scalar=(go * vw).reshape(1).contiguous()))
 
     def sample(self, fc_feats, att_feats, att_masks, opt={}):
         return self.caption_generator.sample(fc_feats, att_feats, att_masks, opt)

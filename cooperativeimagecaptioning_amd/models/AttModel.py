@@ -13,7 +13,7 @@ from .. import _lib, engine
 from ..flat import FlatAgent
 from ..noise import NoiseSource
 from ..bufcache import BufCache
-from ..autograd_glue import EngineLoss
+from ..autograd_glue import engine_loss
 
 
 class Attention(nn.Module):
@@ -274,7 +274,7 @@ class AttModel(nn.Module):
         anchor = next((p for p in self.parameters() if p.requires_grad), None)
         if anchor is None or not torch.is_grad_enabled():
             return loss[0].detach().clone()
-        return EngineLoss.apply(loss[0], anchor, bwd)
+        return engine_loss(loss[0], anchor, bwd)
 
     def sample_beam(self, fc_feats, att_feats, att_masks, opt={}):
         """models/AttModel.py:150-289: beam search over all images at once on the device (the reference decodes image

@@ -10,7 +10,7 @@ from .. import _lib, engine, ops
 from ..flat import FlatAgent
 from ..noise import NoiseSource
 from ..bufcache import BufCache
-from ..autograd_glue import EngineLoss
+from ..autograd_glue import engine_loss
 from .AttModel import DecodeResult
 
 
@@ -185,7 +185,7 @@ class FCModel(nn.Module):
         anchor = next((p for p in self.parameters() if p.requires_grad), None)
         if anchor is None or not torch.is_grad_enabled():
             return loss[0].detach().clone()
-        return EngineLoss.apply(loss[0], anchor, bwd)
+        return engine_loss(loss[0], anchor, bwd)
 
     def sample(self, fc_feats, att_feats, att_masks, opt={}):
         """models/FCModel.py:260-327 (beam_size 1; sample_max 1 greedy, 0 multinomial)."""

@@ -6,7 +6,7 @@ import torch.nn as nn
 
 from .. import _lib, engine
 from ..flat import FlatAgent
-from ..autograd_glue import EngineLoss
+from ..autograd_glue import engine_loss
 from ..bufcache import BufCache
 
 
@@ -159,7 +159,7 @@ class VSEFCModel(nn.Module):
         anchor = next((p for p in self.parameters() if p.requires_grad), None)
         if anchor is None or not torch.is_grad_enabled():
             return value.detach().clone()
-        return EngineLoss.apply(value, anchor, bwd)
+        return engine_loss(value, anchor, bwd)
 
     def _next_slot(self):
         self._n = (self._n + 1) % 4
