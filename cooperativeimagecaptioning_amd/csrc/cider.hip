@@ -130,6 +130,33 @@ __device__ __forceinline__ int bsearch_key(const uint64_t* __restrict__ a, int n
     return -1;
 }
 
+// NQ independent binary searches for the same key advanced in lockstep: the loads of one round do not depend on each other,
+// so a round is one memory round trip for all NQ arrays (a loop of bsearch_key calls is NQ x log2(n) dependent trips).
+// pos[q] = index of k in a[q][0..n[q]) or -1; arrays with n[q] <= 0 are skipped.
+template <int NQ>
+__device__ __forceinline__ void bsearch_keys(const uint64_t* const (&a)[NQ], const int (&n)[NQ], uint64_t k, int (&pos)[NQ]) {
+    int lo[NQ], hi[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { lo[q] = 0; hi[q] = n[q] - 1; pos[q] = -1; }
+#pragma unroll 1
+    for (int round = 0; round < 7; ++round) {                  // rows hold at most 64 keys: 7 probes decide
+        uint64_t v[NQ];
+        int mid[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            mid[q] = (lo[q] + hi[q]) >> 1;
+            v[q] = (lo[q] <= hi[q]) ? a[q][mid[q]] : 0ull;
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (lo[q] <= hi[q]) {
+                if (v[q] == k) { pos[q] = mid[q]; lo[q] = 1; hi[q] = 0; }
+                else if (v[q] < k) lo[q] = mid[q] + 1;
+                else hi[q] = mid[q] - 1;
+            }
+    }
+}
+
 // 2. document frequency: one wave per reference sentence
 __global__ __launch_bounds__(256) void df_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ nuniq,
                                                  const int32_t* __restrict__ ref_img, const int32_t* __restrict__ ref_off,
@@ -142,8 +169,18 @@ __global__ __launch_bounds__(256) void df_kernel(const uint64_t* __restrict__ ke
     if (lane >= nuniq[sid]) return;
     const uint64_t key = keys[(size_t)sid * 64 + lane];
     const int img = ref_img[r];
-    for (int q = ref_off[img]; q < r; ++q)                     // already counted by an earlier reference
-        if (bsearch_key(keys + (size_t)(B2 + q) * 64, nuniq[B2 + q], key) >= 0) return;
+    for (int q0 = ref_off[img]; q0 < r; q0 += 4) {             // already counted by an earlier reference (four probed at a time)
+        const uint64_t* rows[4];
+        int nr[4], pos[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = q0 + j < r ? q0 + j : q0;
+            rows[j] = keys + (size_t)(B2 + q) * 64;
+            nr[j] = q0 + j < r ? nuniq[B2 + q] : 0;
+        }
+        bsearch_keys<4>(rows, nr, key, pos);
+        if ((pos[0] & pos[1] & pos[2] & pos[3]) >= 0) return;   // some pos >= 0 (all four are -1 otherwise)
+    }
     uint32_t slot = (uint32_t)hash64(key) & ht_mask;
     for (;;) {
         const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(ht_keys + slot),
@@ -195,14 +232,18 @@ __global__ __launch_bounds__(256) void vec_kernel(const uint64_t* __restrict__ k
     }
 }
 
-// 4. one wave per hypothesis
-__global__ __launch_bounds__(256) void score_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ nuniq,
+// 4. one workgroup of SCORE_W waves per hypothesis: wave w scores references r0 + w, r0 + w + SCORE_W, ... (a reference costs a
+//    binary search, an f64 exp, four f64 wave sums and divisions: ~3 us of one wave's latency), wave 0 adds the per-reference
+//    terms in reference order - the same f64 operations in the same order as a single wave walking the references
+constexpr int SCORE_W = 5;                                     // COCO: five references per image
+__global__ __launch_bounds__(64 * SCORE_W) void score_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ nuniq,
                                                     const int32_t* __restrict__ blen, const double* __restrict__ vec,
                                                     const double* __restrict__ norm, const int32_t* __restrict__ ref_off,
                                                     int B, int spi, double sigma, const int32_t* __restrict__ bad,
                                                     double* __restrict__ scores) {
-    const int lane = threadIdx.x & 63;
-    const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ double part[SCORE_W][NMAX];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int h = blockIdx.x;
     if (h >= 2 * B) return;
     const int img = (h % B) / spi;                               // gts[i % batch_size // seq_per_img] (rewards.py:55)
     const bool on = lane < nuniq[h];
@@ -211,26 +252,37 @@ __global__ __launch_bounds__(256) void score_kernel(const uint64_t* __restrict__
     const int n = on ? (int)(key >> 60) : 0;
     double tot[NMAX] = {0.0, 0.0, 0.0, 0.0};
     const int r0 = ref_off[img], r1 = ref_off[img + 1];
-    for (int r = r0; r < r1; ++r) {
-        const int rs = 2 * B + r;
-        double c = 0.0;
-        if (on) {
-            const int pos = bsearch_key(keys + (size_t)rs * 64, nuniq[rs], key);
-            if (pos >= 0) {
-                const double vr = vec[(size_t)rs * 64 + pos];
-                c = (vh < vr ? vh : vr) * vr;                    // min(hyp, ref) * ref  (:165)
+    for (int rb = r0; rb < r1; rb += SCORE_W) {
+        const int r = rb + w;
+        if (r < r1) {                                            // wave-uniform
+            const int rs = 2 * B + r;
+            double c = 0.0;
+            if (on) {
+                const int pos = bsearch_key(keys + (size_t)rs * 64, nuniq[rs], key);
+                if (pos >= 0) {
+                    const double vr = vec[(size_t)rs * 64 + pos];
+                    c = (vh < vr ? vh : vr) * vr;                // min(hyp, ref) * ref  (:165)
+                }
+            }
+            const double delta = (double)(blen[h] - blen[rs]);
+            const double pen = exp(-(delta * delta) / (2.0 * sigma * sigma));
+#pragma unroll
+            for (int k = 1; k <= NMAX; ++k) {
+                double val = wave_sum_f64(n == k ? c : 0.0);
+                const double nh = norm[(size_t)h * NMAX + k - 1], nr = norm[(size_t)rs * NMAX + k - 1];
+                if (nh != 0.0 && nr != 0.0) val /= (nh * nr);    // (:167-168)
+                if (lane == 0) part[w][k - 1] = val * pen;
             }
         }
-        const double delta = (double)(blen[h] - blen[rs]);
-        const double pen = exp(-(delta * delta) / (2.0 * sigma * sigma));
+        __syncthreads();
+        if (w == 0) {
+            for (int j = 0; j < SCORE_W && rb + j < r1; ++j)
 #pragma unroll
-        for (int k = 1; k <= NMAX; ++k) {
-            double val = wave_sum_f64(n == k ? c : 0.0);
-            const double nh = norm[(size_t)h * NMAX + k - 1], nr = norm[(size_t)rs * NMAX + k - 1];
-            if (nh != 0.0 && nr != 0.0) val /= (nh * nr);        // (:167-168)
-            tot[k - 1] += val * pen;                             // (:172)
+                for (int k = 0; k < NMAX; ++k) tot[k] += part[j][k];   // (:172), in reference order
         }
+        __syncthreads();
     }
+    if (w != 0) return;
     if (lane == 0) {
         double avg = (tot[0] + tot[1] + tot[2] + tot[3]) / (double)NMAX;   // np.mean over n  (:194)
         avg /= (double)(r1 - r0);
@@ -328,7 +380,7 @@ extern "C" int cic_ciderd_reward(const cic_ciderd_args* a, void* ws, size_t ws_b
     const double ref_len = log((double)(2 * B));                  // np.log(float(len(self.crefs)))  (:178-179)
     hipLaunchKernelGGL(vec_kernel, dim3(cic_cdiv(S, 4)), dim3(256), 0, st, w.keys, w.cnt, w.nuniq, S, ref_len, w.ht_keys,
                        w.ht_df, w.ht_size - 1, w.vec, w.norm, w.df);
-    hipLaunchKernelGGL(score_kernel, dim3(cic_cdiv(2 * B, 4)), dim3(256), 0, st, w.keys, w.nuniq, w.blen, w.vec, w.norm,
+    hipLaunchKernelGGL(score_kernel, dim3(2 * B), dim3(64 * SCORE_W), 0, st, w.keys, w.nuniq, w.blen, w.vec, w.norm,
                        a->ref_off, B, a->spi, 6.0, w.bad, a->scores);
     if (a->reward) hipLaunchKernelGGL(reward_kernel, dim3(1), dim3(256), 0, st, a->scores, B, a->reward, a->stats);
     CIC_LAUNCH_CHECK();
