@@ -158,7 +158,7 @@ class AlternatingJointModel(nn.Module):
             terms.append((cw, l_mle))
             if spk_grad:
                 def bwd_mle(go, logit_ready=None):
-                    cg.decode_backward(mle, dslp=d_mle * go, logit_grads_ready=logit_ready)
+                    cg.decode_backward(mle, dslp=d_mle, dslp_scale=go, logit_grads_ready=logit_ready)
                 bwd_mle.is_speaker = True
                 bwd_steps.append(bwd_mle)
         # VSE on ground-truth captions (vse_loss :209-224)

@@ -270,7 +270,7 @@ class AttModel(nn.Module):
         self._loss['xe'] = loss.detach()[0]
 
         def bwd(go):
-            self.decode_backward(res, dslp=dslp * go)
+            self.decode_backward(res, dslp=dslp, dslp_scale=go)
         anchor = next((p for p in self.parameters() if p.requires_grad), None)
         if anchor is None or not torch.is_grad_enabled():
             return loss[0].detach().clone()

@@ -21,6 +21,7 @@ def run(name, steps, turns, **kw):
     rewards.init_scorer('corpus')
     model = models.AlternatingJointModel(opt).cuda().train()
     od = optim.load_optimizer(model, opt)
+    optim.fuse_zero_grad(od)                     # as train.py and bench.py: the clamp+Adam kernels clear the gradients
     batch = synthetic.make_batch(opt, seed=1234, device='cuda')
 
     def step(turn):
@@ -49,9 +50,19 @@ def run(name, steps, turns, **kw):
 
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    only = sys.argv[2] if len(sys.argv) > 2 else None      # 'c2bf16': that configuration alone (for a kernel trace of it)
     if os.environ.get('CIC_GEMM_FLAGS') is not None:       # A/B measurement of the GEMM dispatch switches
         from cooperativeimagecaptioning_amd import engine
         engine.lib.cic_debug_gemm_tail_split(int(os.environ['CIC_GEMM_FLAGS'], 0))
+    if only == 'c2bf16':
+        run('C2 att2in2 MLE (--compute_dtype bf16)', steps, [None], batch_size=64, is_alternating=0, phase=2, caption_loss_weight=1.0,
+            retrieval_reward_weight=0.0, cider_optimization=0, alternating_turn=None, compute_dtype='bf16')
+        return
+    if only == 'c4':
+        for _ in range(2):
+            run('C4 joint reinforce(gt) + CIDEr-D', steps, ['speaker', 'listener'], batch_size=256, retrieval_reward='reinforce',
+                reinforce_baseline_type='gt', vse_loss_weight=1.0)
+        return
     run('C3 joint gumbel + CIDEr-D', steps, ['speaker'], batch_size=128)
     run('C3 joint gumbel (--compute_dtype bf16)', steps, ['speaker'], batch_size=128, compute_dtype='bf16')
     run('C2 att2in2 MLE (f32)', steps, [None], batch_size=64, is_alternating=0, phase=2, caption_loss_weight=1.0,
