@@ -308,3 +308,29 @@ def test_bench_reads_the_logit_walkers_in_step_duration_from_the_committed_trace
     assert us is not None and 15.0 < us < 60.0
     assert bench.trace_kernel_us('no_such_kernel') is None
     assert 0.05 < bench.pmc_mfma_util() < 0.5
+
+
+def test_engine_loss_answers_a_bare_backward_with_a_cached_gradient_of_ones():
+    """train.py:203-208 calls loss.backward() with no argument: the step's loss must hand the backward engines a gradient of
+    ones without autograd's fill launch, and any explicit gradient / arithmetic on the loss must still take the ordinary path."""
+    from cooperativeimagecaptioning_amd.autograd_glue import engine_loss
+    anchor = torch.zeros(3, requires_grad=True)
+    seen = []
+    for shape in ((), (1,)):
+        value = torch.full(shape, 2.5)
+        loss = engine_loss(value, anchor, lambda go: seen.append(go))
+        assert float(loss.detach()) == 2.5 and loss.requires_grad
+        loss.backward()
+        loss2 = engine_loss(value, anchor, lambda go: seen.append(go))
+        loss2.backward()
+        assert seen[-1] is seen[-2] and seen[-1].shape == torch.Size(shape) and float(seen[-1]) == 1.0     # the cached tensor
+        loss3 = engine_loss(value, anchor, lambda go: seen.append(go))
+        loss3.backward(torch.full(shape, 3.0))
+        assert float(seen[-1]) == 3.0
+        loss4 = engine_loss(value, anchor, lambda go: seen.append(go))
+        (loss4 * 0.5).sum().backward()                                   # a scaled loss: autograd's own chain
+        assert float(seen[-1]) == 0.5
+    consumed = engine_loss(torch.tensor(1.0), anchor, lambda go: None)
+    consumed.backward()
+    with pytest.raises(RuntimeError):
+        consumed.backward()                                              # the step's workspace is consumed by one backward pass
