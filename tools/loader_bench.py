@@ -34,7 +34,7 @@ def main():
     od = optim.load_optimizer(model, opt)
     dev = torch.device('cuda', 0)
 
-    def run(loader, n=30):
+    def run(loader, n=30, log=None):
         for i in range(n + 5):
             if i == 5:
                 torch.cuda.synchronize()
@@ -47,7 +47,13 @@ def main():
             optim.update_optimizer(od, od['speaker'], opt)
             if hasattr(loader, 'prefetch'):
                 loader.prefetch()
-            float(loss.detach())                 # the trainer's per-iteration host sync (train.py:533-535)
+            if log is None:
+                float(loss.detach())             # the reference trainer's per-iteration host sync (train.py:533-535)
+            else:                                # this repo's train.py: the log line follows asynchronously (LossLog)
+                log.push(dict(iteration=i, epoch=0, turn='speaker', host_s=0.0, to_history=False), loss, model.loss())
+                log.pop(lambda meta, value, terms: None)
+        if log is not None:
+            log.pop(lambda meta, value, terms: None, block_to=0)
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n
     class Resident:
@@ -58,6 +64,13 @@ def main():
         def get_batch(self, split):
             return self.b
     t_res = run(Resident())
+    optim.fuse_zero_grad(od)                     # from here on as train.py: gradients cleared inside the clamp+Adam kernels
+    t_trainer = run(Resident(), log=T.LossLog(dev))
+    t_trainer_pf = None
+    pf0 = PrefetchLoader(FixedHostLoader(opt, pin=True), dev)
+    t_trainer_pf = run(pf0, log=T.LossLog(dev))
+    pf0.close()
+    optim.fuse_zero_grad(od, on=False)
     t_sync = run(FixedHostLoader(opt))
     pf = PrefetchLoader(FixedHostLoader(opt), dev)
     t_pf = run(pf)
@@ -67,7 +80,9 @@ def main():
     t_pin = run(pf2)
     staged2 = pf2.pageable_bytes
     pf2.close()
-    print(f'batch resident in HBM (bench.py):                      {t_res * 1e3:.2f} ms/iteration = {128 / t_res:.0f} images/s')
+    print(f'batch resident in HBM, host sync per iteration:         {t_res * 1e3:.2f} ms/iteration = {128 / t_res:.0f} images/s')
+    print(f'  ... as train.py runs the loop (asynchronous log line, gradients cleared in clamp+Adam): {t_trainer * 1e3:.2f} ms/iteration'
+          f' resident, {t_trainer_pf * 1e3:.2f} ms/iteration from pinned host batches through PrefetchLoader')
     print(f'pageable host batches, synchronous copy per iteration: {t_sync * 1e3:.2f} ms/iteration = {128 / t_sync:.0f} images/s')
     print(f'pageable host batches through PrefetchLoader:          {t_pf * 1e3:.2f} ms/iteration = {128 / t_pf:.0f} images/s'
           f'   ({staged / 35 / 1e6:.1f} MB from pageable memory per batch)')
