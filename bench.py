@@ -34,6 +34,37 @@ ATTN_BYTES_PER_IMAGE = 151696          # p_att + att rows + att_
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 MFMA_F32_PEAK_TF = 157.3               # MI355X_MICROARCH.md: f32-input MFMA, 157.3 TFLOP/s (spec)
 MFMA_BF16_PEAK_TF = 2500.0             # MI355X_MICROARCH.md: bf16 MFMA, ~2.5 PFLOP/s dense
+# MI355X_MICROARCH.md, "Indexed rows: gather into LDS": a 38 MB table that stays in the Infinity Cache is read at 8.6 TB/s
+# chip-wide.  The attention's working set (att + p_att of 2B images = 37.7 MB) is such a table: re-read every decode step, it
+# is served by the Infinity Cache, not by HBM - `frac_of_cache_level` prices the kernel against THAT level beside the HBM `frac`
+MALL_38MB_GBS = 8600.0
+
+
+def host_cores():
+    """(cores this process may run on, physical cores of the host, logical CPUs of the host)."""
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    logical = os.cpu_count() or usable
+    physical = None
+    try:
+        seen = set()
+        phys_id = core_id = None
+        with open('/proc/cpuinfo') as f:
+            for ln in f:
+                if ln.startswith('physical id'):
+                    phys_id = ln.split(':')[1].strip()
+                elif ln.startswith('core id'):
+                    core_id = ln.split(':')[1].strip()
+                elif not ln.strip():
+                    if phys_id is not None and core_id is not None:
+                        seen.add((phys_id, core_id))
+                    phys_id = core_id = None
+        physical = len(seen) or None
+    except OSError:
+        pass
+    return usable, physical, logical
 
 
 def cpu_baseline(opt, steps_budget_s=20.0):
@@ -41,12 +72,13 @@ def cpu_baseline(opt, steps_budget_s=20.0):
     from oracle import joint as J
     from cooperativeimagecaptioning_amd import synthetic
     import numpy as np
-    # the GPU box gives one GPU's share of the host: 16 cores (fewer if the affinity mask says so)
-    try:
-        ncpu = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncpu = os.cpu_count() or 1
-    torch.set_num_threads(max(1, min(16, ncpu)))
+    # BASELINE.md §3 asks for the host's cores.  A GPU box hands ONE GPU's share of its host to a job (16 cores on this pool);
+    # the affinity mask is the authority where it is narrower, and the threads never exceed the physical cores (SMT siblings
+    # slow the oracle's GEMMs down).  The cap and the host's real core counts are stated in `sample`.
+    usable, physical, logical = host_cores()
+    cap = 16
+    nthreads = max(1, min(cap, usable, physical or usable))
+    torch.set_num_threads(nthreads)
     torch.manual_seed(0)
     B = opt.batch_size
     batch = synthetic.make_batch(opt, seed=1234)
@@ -96,8 +128,11 @@ def cpu_baseline(opt, steps_budget_s=20.0):
             break
     steady = sorted(times[1:])[len(times[1:]) // 2]
     return dict(value=B / steady, unit='images/s', cores=torch.get_num_threads(), kind='port',
+                host_physical_cores=physical, host_logical_cpus=logical, cores_usable_by_this_process=usable,
                 sample=f'{n} joint steps (first discarded, median of the rest) of the same B={B} gumbel+CIDEr-D '
-                       f'workload on the CPU oracle, {steady * 1e3:.0f} ms/step')
+                       f'workload on the CPU oracle, {steady * 1e3:.0f} ms/step; {torch.get_num_threads()} threads = '
+                       f'min(cap {cap}: one GPU\'s share of the host, {usable} CPUs in the affinity mask, '
+                       f'{physical} physical cores of the host; {logical} logical CPUs)')
 
 
 def attention_launch_time(model, batch, stream, iters=200):
@@ -142,7 +177,7 @@ def _profile_doc(names):
 def pmc_traffic(images):
     """HBM-side bytes per attention launch from the committed PMC summary (profiles/, separate FETCH_SIZE and
     WRITE_SIZE passes of this same command, tools/pmc_summary.py), for the launch geometry of the step."""
-    doc = _profile_doc(['r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'])
+    doc = _profile_doc(['r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'])
     for k in (doc or {}).get('kernels', []):
         if k['kernel'].startswith('attn_fwd_cols_kernel') and k['grid_threads'] == images * 1024:
             return k['total_bytes']
@@ -152,7 +187,7 @@ def pmc_traffic(images):
 def pmc_mfma_util():
     """Counter-derived MFMA utilisation of the logit walker from the committed PMC pass (profiles/r03_pmc_mfma.json,
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE ... of this same command), or None before that pass exists."""
-    doc = _profile_doc(['r03_pmc_mfma.json', 'r02_pmc_mfma.json'])
+    doc = _profile_doc(['r04_pmc_mfma.json', 'r03_pmc_mfma.json', 'r02_pmc_mfma.json'])
     for k in (doc or {}).get('kernels', []):
         if k['kernel'].startswith('gemm_ldsb2'):
             return k.get('mfma_util')
@@ -162,7 +197,7 @@ def pmc_mfma_util():
 def trace_kernel_us(prefix):
     """In-step average duration (us) of the kernel whose name starts with `prefix` in the committed rocprofv3 kernel trace of
     this command (profiles/r03_step_breakdown.md, written by tools/trace_summary.py from `rocprofv3 --kernel-trace`), or None."""
-    for name in ('r03_step_breakdown.md', 'r03a_step_breakdown.md'):
+    for name in ('r04_step_breakdown.md', 'r03_step_breakdown.md', 'r03a_step_breakdown.md'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 for ln in f:
@@ -244,7 +279,7 @@ def main():
             _build.build(force=False)
     if world > 1:
         dist.barrier()
-    from cooperativeimagecaptioning_amd import models, optimizer as optim, synthetic, engine
+    from cooperativeimagecaptioning_amd import models, optimizer as optim, synthetic, engine, status
     from cooperativeimagecaptioning_amd.misc import rewards
 
     opt = synthetic.default_opt(batch_size=args.batch)
@@ -297,6 +332,9 @@ def main():
         host_t.append(time.perf_counter() - t0)          # when the host had ENQUEUED step i
     barrier()
     dt = time.perf_counter() - t0
+    # a hand-off of a one-launch recurrence that timed out (status.py) ends the benchmark with a non-zero exit code on the rank
+    # that saw it: the optimiser kernels skipped their updates from that step on, and a line measured over skipped work is void
+    status.check(dev, f'bench.py rank {rank}, during the {args.warmup} warm-up + {args.steps} timed steps')
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     median_ms = step_ms[len(step_ms) // 2]
     # how far the host runs ahead of the device: (device time at which step i ended) - (host time at which it was enqueued).
@@ -313,6 +351,7 @@ def main():
         for _ in range(args.profile_steps):
             loss = step()
         barrier()
+        status.check(dev, f'bench.py rank {rank}, during the profiled steps')
         model.caption_generator.timer = None
         if rank == 0:
             prof = timer.collect()
@@ -371,6 +410,9 @@ def main():
             # average duration of the in-step launches (HIP events of a cic_timer on the step's stream)
             'roofline': {'bound': 'hbm', 'kernel': 'attn_fwd_cols_kernel<5, 1, float> (per-timestep top-down attention, 2B images per launch)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         # the level the kernel actually reads from: its 37.7 MB working set is Infinity-Cache resident
+                         'frac_of_cache_level': achieved / MALL_38MB_GBS, 'cache_level_peak': MALL_38MB_GBS,
+                         'cache_level': 'Infinity Cache, 38 MB gathered table: 8.6 TB/s chip-wide (MI355X_MICROARCH.md)',
                          'traffic': pmc_traffic(n_img), 'avg_launch_us': attn_us, 'launches_timed': micro.get('n', 0),
                          'timing': 'HIP events on the step\'s stream over launches of the step\'s geometry interleaved with a '
                                    'cache-polluting kernel (its time subtracted); in-step event brackets alongside',

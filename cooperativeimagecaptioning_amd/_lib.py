@@ -95,7 +95,7 @@ class DecodeIO(C.Structure):
                 ('ss_pick', c_ptr), ('fc_mode', C.c_int), ('x0', c_ptr), ('first_token', c_ptr),
                 ('seq', c_ptr), ('slp', c_ptr), ('stv', c_ptr), ('L', c_ptr),
                 ('u_philox', C.c_int), ('u_seed', C.c_uint64), ('u_offset', C.c_uint64), ('timer', c_ptr),
-                ('device_shared', C.c_int)]
+                ('device_shared', C.c_int), ('status', c_ptr)]
 
 
 class DecodeBwdIO(C.Structure):
@@ -141,7 +141,7 @@ class ListenerIO(C.Structure):
     _fields_ = [('fc_feats', c_ptr), ('labels', c_ptr), ('masks', c_ptr), ('seq', c_ptr), ('stv', c_ptr),
                 ('L', c_ptr), ('soft', c_ptr), ('only_one_retrieval', C.c_int), ('loss_rows', c_ptr),
                 ('loss_sum', c_ptr),
-                ('img_emb_out', c_ptr), ('cap_emb_out', c_ptr), ('device_shared', C.c_int)]
+                ('img_emb_out', c_ptr), ('cap_emb_out', c_ptr), ('device_shared', C.c_int), ('status', c_ptr)]
 
 
 class ListenerBwdIO(C.Structure):

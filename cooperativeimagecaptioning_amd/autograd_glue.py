@@ -5,6 +5,8 @@ caller runs ``loss.backward()`` (train.py:203-208).  EngineLoss returns the engi
 loss value and, on backward, invokes a closure that launches the backward engines, which
 accumulate straight into the flat gradient buffers the parameters' ``.grad`` views alias.
 """
+import weakref
+
 import torch
 
 
@@ -35,13 +37,19 @@ def engine_loss(loss_value, anchor, backward_fn):
     loss (arithmetic on it, ``backward(gradient=...)``, ``torch.autograd.grad``) takes the ordinary path."""
     out = EngineLoss.apply(loss_value, anchor, backward_fn)
     tensor_backward = torch.Tensor.backward
+    # the closure holds the loss WEAKLY: a strong reference would make loss -> closure -> loss a cycle, and the step's decode /
+    # listener results (kept alive by the autograd node) would wait for the cyclic collector instead of dying with the loss
+    ref = weakref.ref(out)
+    key = (out.device, out.dtype, tuple(out.shape))
 
     def backward(gradient=None, *args, **kwargs):
+        me = ref()
+        if me is None:
+            raise RuntimeError('backward() of a loss tensor that no longer exists')
         if gradient is None:
-            key = (out.device, out.dtype, tuple(out.shape))
             gradient = _ONES.get(key)
             if gradient is None:
-                gradient = _ONES[key] = torch.ones(out.shape, dtype=out.dtype, device=out.device)
-        return tensor_backward(out, gradient, *args, **kwargs)
+                gradient = _ONES[key] = torch.ones(key[2], dtype=key[1], device=key[0])
+        return tensor_backward(me, gradient, *args, **kwargs)
     out.backward = backward
     return out

@@ -66,6 +66,52 @@ void cic_timer_end(void* h, hipStream_t st);
 
 uint64_t cic_hash_bytes(const void* p, size_t n, uint64_t h);
 
+// ---- hand-off time-outs of the one-launch recurrences (cic.h: "status word") -----------------------------------------------
+// Every spin of those kernels is bounded by `ticks` of the 100 MHz s_memrealtime counter (1 s).  A workgroup that gives up
+// raises the loop's error word (cleared with the loop's counters), ORs the loop's bit into the caller's STICKY status word and
+// poisons what it produces with NaN; once it has given up it does not wait again (a launch then ends within ~one bound, not
+// hand-offs x steps of them).  Development build only: the bound can be lowered and ONE workgroup of a chosen loop told never
+// to count itself in (cic_dev.h: cic_debug_spin_ticks, cic_debug_handoff_fault) - how tests force the failure.
+#ifdef CIC_DEVTOOLS
+extern unsigned long long g_spin_ticks;
+extern int g_fault_loop, g_fault_wg;
+#else
+static constexpr unsigned long long g_spin_ticks = 1000ull * 100000ull;
+static constexpr int g_fault_loop = 0, g_fault_wg = -1;
+#endif
+struct HandoffGuard {
+    unsigned* err;                // the loop's error word (in its workspace)
+    unsigned* status;             // the caller's sticky word or null
+    unsigned bit;                 // CIC_STATUS_*
+    unsigned long long ticks;     // spin bound
+    int fault_wg;                 // blockIdx.x of the workgroup that withholds its counter adds, or -1
+};
+static inline HandoffGuard handoff_guard(unsigned* err, uint32_t* status, unsigned bit) {
+    HandoffGuard g;
+    g.err = err; g.status = status; g.bit = bit; g.ticks = g_spin_ticks;
+    g.fault_wg = (g_fault_loop & (int)bit) ? g_fault_wg : -1;
+    return g;
+}
+#ifdef __HIPCC__
+// ONE lane: poll `*c` until it reaches `target` or the bound passes.  Returns 1 when it was reached.
+__device__ __forceinline__ int handoff_poll(unsigned* c, unsigned target, const HandoffGuard& g) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > g.ticks) {
+            __hip_atomic_store(g.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (g.status) __hip_atomic_fetch_or(g.status, g.bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return 0;
+        }
+    }
+    return 1;
+}
+// ONE lane counts its workgroup in (unless it is the development build's faulty workgroup)
+__device__ __forceinline__ void handoff_arrive(unsigned* c, const HandoffGuard& g) {
+    if ((int)blockIdx.x != g.fault_wg) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
+
 static inline hipStream_t cic_s(cic_stream_t s) { return (hipStream_t)s; }
 
 // A pointer per decode of a PAIR of decodes that advance in lock step through the same launches

@@ -4,6 +4,11 @@
 #ifdef CIC_DEVTOOLS
 #include "cic_dev.h"
 
+unsigned long long g_spin_ticks = 1000ull * 100000ull;
+int g_fault_loop = 0, g_fault_wg = -1;
+extern "C" int cic_debug_spin_ticks(unsigned long long ticks) { g_spin_ticks = ticks ? ticks : 1000ull * 100000ull; return 0; }
+extern "C" int cic_debug_handoff_fault(int loop_bits, int wg) { g_fault_loop = loop_bits; g_fault_wg = loop_bits ? wg : -1; return 0; }
+
 namespace {
 __global__ void clock_probe_kernel(float* out, int spin) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -37,6 +42,19 @@ __global__ __launch_bounds__(512) void stream_probe_kernel(const f32x4* __restri
     }
     if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) sink[blockIdx.x] = acc[0];
 }
+// Stand-in for a collective's kernel: `wgs` workgroups that each HOLD a CU's worth of LDS (so that no 100 KB workgroup of a
+// one-launch recurrence fits beside them) for `ticks` of the 100 MHz clock, doing nothing else.
+__global__ __launch_bounds__(256) void hold_cus_kernel(unsigned long long ticks, unsigned* sink) {
+    extern __shared__ __attribute__((aligned(16))) float hold_lds[];
+    hold_lds[threadIdx.x] = (float)threadIdx.x;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    }
+    __syncthreads();
+    if (hold_lds[threadIdx.x] < 0.f && sink) sink[0] = 1u;
+}
 __global__ void empty_kernel(int* p) {
     if (p && threadIdx.x == 0 && blockIdx.x == 0x7fffffff) *p = 1;
 }
@@ -69,6 +87,15 @@ extern "C" int cic_debug_stream_probe(const float* src, int64_t region_floats, i
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *avg_us = (double)ms * 1e3 / iters;
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int cic_debug_hold_cus(int wgs, unsigned long long ticks, int lds_bytes, cic_stream_t s) {
+    CIC_REQUIRE(wgs > 0 && wgs <= 256 && lds_bytes >= 1024 && lds_bytes <= 160 * 1024 && ticks <= 100000000ull);
+    static DeviceOnce attr_set;
+    if (attr_set.first())
+        CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hold_cus_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(hold_cus_kernel, dim3(wgs), dim3(256), (size_t)lds_bytes, cic_s(s), ticks, (unsigned*)nullptr);
     CIC_LAUNCH_CHECK();
     return 0;
 }

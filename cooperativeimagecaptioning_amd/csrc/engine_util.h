@@ -74,10 +74,12 @@ struct TeacherSeqLaunch {
     const uint8_t* out_keep;
     float *pre_all, *h_all, *c_all, *att_h_all, *att_res_all, *alpha_all, *dot_all, *out_all;
     unsigned* sync;           // cic_cdiv(B, 16) * T * 3 + 1 words
+    uint32_t* status;         // the caller's sticky status word (cic.h) or null
     float scale;
     int B, K, T;
 };
 bool cic_teacher_seq_ok(int B, int K, int H, int A, int E);
+int cic_resident_cus(const void* kernel, int threads, size_t lds_bytes);   // CUs that each admit one such workgroup, or 0
 int cic_teacher_seq(const TeacherSeqLaunch& L, hipStream_t st);
 int cic_apply_keep2(const float* x, Dual<const uint8_t> keep, float p_drop, Dual<float> y, int64_t n, hipStream_t st);
 int cic_att_keep_rows(const float* x, const uint8_t* keep, float p_drop, const float* masks, float* y, int B, int K, int H,

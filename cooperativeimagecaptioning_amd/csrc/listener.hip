@@ -240,7 +240,7 @@ __global__ __launch_bounds__(KS * 64) void gru_step_fused_kernel(const float* __
 // stream.  Nothing here depends on dispatch order or placement; it needs every workgroup RESIDENT (grid <= CUs, checked
 // by the launcher, which otherwise uses the per-step kernel).  Every spin is bounded by a wall-clock budget (1 s): a workgroup
 // that gives up raises *err and poisons its outputs with NaN (the loss then says so) instead of hanging the device.
-constexpr unsigned long long GRU_SPIN_TICKS = 1000ull * 100000ull;   // 1 s of the 100 MHz s_memrealtime counter
+// (bound, error word, sticky status word and the development build's fault injection: HandoffGuard, cic_common.h)
 // Tiling (r3): a workgroup owns a 16-row strip x a 32-unit tile (its backward twin's shape): 8 strips x 32 tiles at B = 128, so
 // that the 32 workgroups of a strip share ONE XCD (blockIdx % 8: the hand-off stays inside an L2's reach; speed only) and a
 // step moves 64 KB of h rows per workgroup instead of 128.  The weight tile (3 gates x 32 units x J floats = 393 KB) is split:
@@ -252,7 +252,7 @@ template <int GPS, int KS>
 __global__ __launch_bounds__(KS * 64) void gru_seq_kernel(float* __restrict__ h_all, const float* __restrict__ W,
                                                           const float* __restrict__ b_hh, const float* __restrict__ gi_all,
                                                           const int32_t* __restrict__ len, float* __restrict__ gh_all,
-                                                          unsigned* __restrict__ cnt_base, unsigned* __restrict__ err, int B, int J, int Lp,
+                                                          unsigned* __restrict__ cnt_base, HandoffGuard hg, int B, int J, int Lp,
                                                           int row0, int row_end) {
     // rows [row0, row_end) of the batch: a batch of more than CUs / 32 strips is walked in row blocks, one launch each (rows are
     // independent of each other); B stays the row count of the slabs
@@ -293,6 +293,7 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_kernel(float* __restrict__ h_
     const float bh0 = b_hh[col], bh1 = b_hh[J + col], bh2 = b_hh[2 * J + col];
     float poison = 0.f;
     if (orow < row_end) h_all[(size_t)orow * J + col] = 0.f;    // h_0 (read by the backward pass; this kernel never reads it)
+    if (tid == 0) ok_s = 1;                               // sticky: a workgroup that has given up once does not wait again
     __syncthreads();
     for (int t = 0; t < Lp; ++t) {
         const float* gi = gi_all + (size_t)t * B * 3 * J;
@@ -304,16 +305,7 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_kernel(float* __restrict__ h_
         float ghv[3] = {bh0, bh1, bh2};
         float hp = 0.f;
         if (t > 0) {
-            if (tid == 0) {
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                int ok = 1;
-                while (__hip_atomic_load(cnt + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)tiles_j) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > GRU_SPIN_TICKS) { ok = 0; break; }
-                }
-                ok_s = ok;
-                if (!ok) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (tid == 0 && ok_s) ok_s = handoff_poll(cnt + t, (unsigned)tiles_j, hg);
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // compiler only: no load of h_t above the poll
             if (!ok_s) poison = __builtin_nanf("");
@@ -376,7 +368,7 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_kernel(float* __restrict__ h_
         if (t + 1 < Lp) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // EVERY storing wave drains before the signal
             __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(cnt + t + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) handoff_arrive(cnt + t + 1, hg);
         }
     }
 }
@@ -408,7 +400,7 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_bwd_kernel(const float* __res
                                                               const float* __restrict__ gi_all, const float* __restrict__ gh_all,
                                                               const int32_t* __restrict__ len, const float* __restrict__ dh_init,
                                                               float* __restrict__ dgi_all, float* __restrict__ dgh_all,
-                                                              unsigned* __restrict__ cnt_base, unsigned* __restrict__ err,
+                                                              unsigned* __restrict__ cnt_base, HandoffGuard hg,
                                                               int B, int J, int Lp, int pool, const float* __restrict__ d_pool,
                                                               const int32_t* __restrict__ pool_arg,
                                                               // [Lp,B,zero_n] cleared on the way (zero_n <= J: the K-sliced product
@@ -441,7 +433,7 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_bwd_kernel(const float* __res
     const int ln = len[orc];
     const int J3 = 3 * J;
     unsigned* cnt = cnt_base + (size_t)(row0 / 16 + strip) * (Lp + 1);    // cnt[t]: workgroups of this strip that have published dgh_t
-    if (tid == 0) smax_s = 0;
+    if (tid == 0) { smax_s = 0; ok_s = 1; }               // ok_s is sticky: a workgroup that has given up once does not wait again
     __syncthreads();
     if (tid < 16) atomicMax(&smax_s, len[min(m0 + tid, row_end - 1)]);
     // the weight tile, once: B fragments (k = 16*group + 4*lq + s, n = column li of tile ct) of this wave's K slice
@@ -524,15 +516,8 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_bwd_kernel(const float* __res
         __syncthreads();
         GRU_STAMP(2);
         if (tid == 0) {
-            __hip_atomic_fetch_add(cnt + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            int ok = 1;
-            while (__hip_atomic_load(cnt + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)tiles_j) {
-                __builtin_amdgcn_s_sleep(1);
-                if (__builtin_amdgcn_s_memrealtime() - t0 > GRU_SPIN_TICKS) { ok = 0; break; }
-            }
-            ok_s = ok;
-            if (!ok) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            handoff_arrive(cnt + t, hg);
+            if (ok_s) ok_s = handoff_poll(cnt + t, (unsigned)tiles_j, hg);
         }
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // compiler only: no load of dgh_t above the poll
@@ -962,21 +947,20 @@ static int listener_fwd_impl(const cic_listener_dims* dp, const cic_listener_par
     if (g_gru_fused >= 2 && J == 1024 && !io->device_shared) {
         // the one-launch form needs every workgroup resident at once: one per CU (512 threads holding the weight tile in
         // ~200 VGPRs each fill a CU's register file)
-        int dev = 0, cus = 0;
-        CIC_HIP(hipGetDevice(&dev));
-        CIC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        seq_rows = (cus / (J / 32)) * 16;            // rows one launch can walk with every workgroup resident
-        seq_kernel = seq_rows >= 16;
-    }
-    if (seq_kernel) {
         static DeviceOnce attr_set;
         if (attr_set.first())
             CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_kernel<8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)GRUF_LDS_BYTES));
+        const int cus = cic_resident_cus(reinterpret_cast<const void*>(&gru_seq_kernel<8, 8>), 512, GRUF_LDS_BYTES);
+        seq_rows = (cus / (J / 32)) * 16;            // rows one launch can walk with every workgroup resident
+        seq_kernel = seq_rows >= 16;
+    }
+    if (seq_kernel) {
         for (int row0 = 0; row0 < B; row0 += seq_rows) {      // (B = 128: one launch; B = 256: two row blocks)
             const int row_end = row0 + seq_rows < B ? row0 + seq_rows : B;
             hipLaunchKernelGGL((gru_seq_kernel<8, 8>), dim3(cic_cdiv(row_end - row0, 16) * (J / 32)), dim3(512), GRUF_LDS_BYTES, st, w.h_all,
-                               p->w_hh, p->b_hh, w.gi_all, w.len, w.gh_all, w.sync, w.sync + 2 * (size_t)cic_cdiv(B, 16) * (Lp + 1), B, J, Lp,
+                               p->w_hh, p->b_hh, w.gi_all, w.len, w.gh_all, w.sync,
+                               handoff_guard(w.sync + 2 * (size_t)cic_cdiv(B, 16) * (Lp + 1), io->status, CIC_STATUS_GRU_FWD), B, J, Lp,
                                row0, row_end);
             CIC_LAUNCH_CHECK();
         }
@@ -1059,23 +1043,21 @@ static int listener_bwd_impl(const cic_listener_dims* dp, const cic_listener_par
     int seq_rows = 0;
     if (g_gru_fused >= 2 && J == 1024 && !io->device_shared) {
         // as in the forward pass: every workgroup resident at once, one per CU
-        int dev = 0, cus = 0;
-        CIC_HIP(hipGetDevice(&dev));
-        CIC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        seq_rows = (cus / (J / 32)) * 16;
-        seq_kernel = seq_rows >= 16;
-    }
-    if (seq_kernel) {
         static DeviceOnce attr_set;
         if (attr_set.first())
             CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_bwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)GRUB_LDS_BYTES));
+        const int cus = cic_resident_cus(reinterpret_cast<const void*>(&gru_seq_bwd_kernel<8>), 512, GRUB_LDS_BYTES);
+        seq_rows = (cus / (J / 32)) * 16;
+        seq_kernel = seq_rows >= 16;
+    }
+    if (seq_kernel) {
         unsigned* cnt_b = w.sync + (size_t)cic_cdiv(B, 16) * (Lp + 1);
         for (int row0 = 0; row0 < B; row0 += seq_rows) {
             const int row_end = row0 + seq_rows < B ? row0 + seq_rows : B;
             hipLaunchKernelGGL((gru_seq_bwd_kernel<8>), dim3(cic_cdiv(row_end - row0, 16) * (J / 32)), dim3(512), GRUB_LDS_BYTES, st, w.h_all,
-                               p->w_hh, w.gi_all, w.gh_all, w.len, dh, w.dgi_all, w.dgh_all, cnt_b, cnt_b + (size_t)cic_cdiv(B, 16) * (Lp + 1),
-                               B, J, Lp, d.pool, w.d_pool, w.pool_arg, E <= J ? w.dx_emb : nullptr, E, row0, row_end);
+                               p->w_hh, w.gi_all, w.gh_all, w.len, dh, w.dgi_all, w.dgh_all, cnt_b,
+                               handoff_guard(cnt_b + (size_t)cic_cdiv(B, 16) * (Lp + 1), io->status, CIC_STATUS_GRU_BWD), B, J, Lp, d.pool, w.d_pool, w.pool_arg, E <= J ? w.dx_emb : nullptr, E, row0, row_end);
             CIC_LAUNCH_CHECK();
         }
     }

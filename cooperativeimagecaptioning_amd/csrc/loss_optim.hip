@@ -71,15 +71,28 @@ __global__ __launch_bounds__(256) void masked_nll_kernel(const float* __restrict
         }
 }
 
+// torch's clamp_ (misc/utils.py:65-69) keeps a NaN a NaN; fminf(fmaxf(NaN, -c), c) would hand Adam a finite -c instead
+__device__ __forceinline__ float clamp_nan(float x, float clip) { return x != x ? x : fminf(fmaxf(x, -clip), clip); }
+
 // clip_gradient (elementwise clamp, misc/utils.py:65-69) + torch.optim.Adam.step (optimizer.py:25-27)
 // ZERO: the gradient is cleared on the way out (the next step's zero_grad(), optimizer.py:224-230, without a pass of its own)
+// status: the caller's sticky status word (cic.h) or null.  Non-zero = a one-launch recurrence of this or an earlier step gave up
+// on a hand-off and poisoned its gradients: nothing is touched (the word is read by every thread: one cached line).
 template <bool ZERO>
 __global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, float* __restrict__ g,
                                                          float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                          float clip, float wd, float b1, float b2, float eps,
-                                                         float step_size, float bc2_sqrt, float gscale) {
+                                                         float step_size, float bc2_sqrt, float gscale,
+                                                         unsigned* __restrict__ status) {
     const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t i = i4 * 4;
+    if (status) {
+        const unsigned st = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (st & ~(unsigned)CIC_STATUS_UPDATE_SKIPPED) {
+            if (i4 == 0) __hip_atomic_fetch_or(status, (unsigned)CIC_STATUS_UPDATE_SKIPPED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
     if (i >= n) return;
     if (i + 3 < n) {
         f32x4 pp = *reinterpret_cast<f32x4*>(p + i);
@@ -87,7 +100,7 @@ __global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, 
         f32x4 mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float x = fminf(fmaxf(gg[e] * gscale, -clip), clip);
+            float x = clamp_nan(gg[e] * gscale, clip);
             if (wd != 0.f) x += wd * pp[e];
             mm[e] = mm[e] * b1 + (1.0f - b1) * x;
             vv[e] = vv[e] * b2 + (1.0f - b2) * x * x;
@@ -100,7 +113,7 @@ __global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, 
         if (ZERO) *reinterpret_cast<f32x4*>(g + i) = f32x4{0.f, 0.f, 0.f, 0.f};
     } else {
         for (int64_t j = i; j < n; ++j) {
-            float x = fminf(fmaxf(g[j] * gscale, -clip), clip);
+            float x = clamp_nan(g[j] * gscale, clip);
             if (wd != 0.f) x += wd * p[j];
             m[j] = m[j] * b1 + (1.0f - b1) * x;
             v[j] = v[j] * b2 + (1.0f - b2) * x * x;
@@ -168,6 +181,13 @@ extern "C" int cic_clamp_adam(float* p, const float* g, float* m, float* v, int6
 extern "C" int cic_clamp_adam_zero(float* p, float* g, float* m, float* v, int64_t n, double lr, double beta1,
                                    double beta2, double eps, double weight_decay, double grad_clip, int step,
                                    double grad_scale, int zero_grad, cic_stream_t s) {
+    return cic_clamp_adam_guarded(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, grad_clip, step, grad_scale, zero_grad,
+                                  nullptr, s);
+}
+
+extern "C" int cic_clamp_adam_guarded(float* p, float* g, float* m, float* v, int64_t n, double lr, double beta1,
+                                      double beta2, double eps, double weight_decay, double grad_clip, int step,
+                                      double grad_scale, int zero_grad, uint32_t* status, cic_stream_t s) {
     CIC_REQUIRE(p && g && m && v && n > 0 && step >= 1 && grad_clip > 0.0);
     CIC_REQUIRE(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                   reinterpret_cast<uintptr_t>(v)) & 15) == 0);
@@ -177,11 +197,11 @@ extern "C" int cic_clamp_adam_zero(float* p, float* g, float* m, float* v, int64
     if (zero_grad)
         hipLaunchKernelGGL(clamp_adam_kernel<true>, dim3(cic_cdiv((n + 3) / 4, 256)), dim3(256), 0, cic_s(s), p, g, m, v, n,
                            (float)grad_clip, (float)weight_decay, (float)beta1, (float)beta2, (float)eps, step_size, bc2_sqrt,
-                           (float)grad_scale);
+                           (float)grad_scale, status);
     else
         hipLaunchKernelGGL(clamp_adam_kernel<false>, dim3(cic_cdiv((n + 3) / 4, 256)), dim3(256), 0, cic_s(s), p, g, m, v, n,
                            (float)grad_clip, (float)weight_decay, (float)beta1, (float)beta2, (float)eps, step_size, bc2_sqrt,
-                           (float)grad_scale);
+                           (float)grad_scale, status);
     CIC_LAUNCH_CHECK();
     return 0;
 }

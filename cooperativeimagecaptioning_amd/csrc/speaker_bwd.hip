@@ -558,7 +558,8 @@ struct BpttArgs {
     const float* d_out_all;                                                 // [T,B,H]
     float *dpre_all, *d_att_res_all, *d_att_h_all, *ddot_all;               // [T,B,5H] [T,B,H] [T,B,H] [T,B,K]
     float* zero_tbh;                                                        // [T,B,H] cleared on the way (d x of the batched product after the loop) or null
-    unsigned *cnt, *err;                                                    // [strips][T][3] counters (zeroed by the launcher), 1 word
+    unsigned* cnt;                                                          // [strips][T][3] counters (zeroed by the launcher)
+    HandoffGuard hg;                                                        // error word behind them, status word, spin bound (cic_common.h)
     const int32_t* L;                                                       // the decode's length on the device, or null
     float scale;
     int B, K, T;
@@ -566,7 +567,6 @@ struct BpttArgs {
 };
 constexpr int BPTT_GA = 8, BPTT_GI = 12, BPTT_GC = 4;      // k groups of 16 per wave: (a, b) gate columns / (i, f, o) / d_att_h
 constexpr size_t BPTT_LDS_BYTES = sizeof(float) * ((size_t)8 * (BPTT_GA + BPTT_GC) * 64 * 4 + 8 * 4 * 64 + 8 * 64);
-constexpr unsigned long long BPTT_SPIN_TICKS = 1000ull * 100000ull;        // 1 s of the 100 MHz s_memrealtime counter
 #ifdef CIC_DEVTOOLS
 __device__ unsigned long long* g_bptt_stamps = nullptr;    // development build: [workgroup][step][8] s_memrealtime stamps
 #endif
@@ -635,6 +635,7 @@ __global__ __launch_bounds__(KS * 64) void spk_bptt_seq_kernel(BpttArgs a) {
     const f32x4 wa = reinterpret_cast<const f32x4*>(a.alpha_w)[col4];
     const int img = m0 + (jt >> 1);
     const bool att_wg = (jt & 1) == 0;
+    if (tid == 0) ok_s = 1;                               // sticky: a workgroup that has given up once does not wait again
     __syncthreads();
     const int Lv = __builtin_amdgcn_readfirstlane(a.L ? *a.L : T);      // wave-uniform: the step loop stays scalar control flow
     float dh = 0.f, dc = 0.f;                             // carried gradients of this lane's (row, unit) (owners)
@@ -645,21 +646,12 @@ __global__ __launch_bounds__(KS * 64) void spk_bptt_seq_kernel(BpttArgs a) {
     auto publish = [&](unsigned* c, bool add) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // EVERY storing wave drains before the signal
         __syncthreads();
-        if (tid == 0 && add) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && add) handoff_arrive(c, a.hg);
     };
     // ... consumer side: ONE lane polls until `target` workgroups of the strip have published; loads of handed-off bytes
     // (all sc1) come after it
     auto wait_for = [&](unsigned* c, unsigned target) {
-        if (tid == 0) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            int ok = 1;
-            while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                __builtin_amdgcn_s_sleep(1);
-                if (__builtin_amdgcn_s_memrealtime() - t0 > BPTT_SPIN_TICKS) { ok = 0; break; }
-            }
-            ok_s = ok;
-            if (!ok) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (tid == 0 && ok_s) ok_s = handoff_poll(c, target, a.hg);
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // compiler only: no load of handed-off bytes above the poll
         if (!ok_s) poison = __builtin_nanf("");
@@ -1160,26 +1152,29 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     // the flagship widths walk the loop in ONE launch (spk_bptt_seq_kernel): every workgroup resident at once, one per CU
     bool seq_kernel = false;
     int seq_rows = 0;
-    if (g_bptt_seq && !ps && !fc && H == 512 && A == 512 && K >= 1 && K <= 36 && !bio->device_shared) {
-        int dev = 0, cus = 0;
-        CIC_HIP(hipGetDevice(&dev));
-        CIC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        seq_rows = (cus / (H / 16)) * 16;                     // rows one launch can walk with every workgroup resident
-        seq_kernel = seq_rows >= 16;
-    }
-    if (seq_kernel && do_loop) {
+    if (g_bptt_seq && !ps && !fc && H == 512 && A == 512 && K >= 1 && K <= 36 && !bio->device_shared && !io->device_shared) {
         static DeviceOnce attr_set;
         if (attr_set.first())
             CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spk_bptt_seq_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)BPTT_LDS_BYTES));
-        // (the hand-off counters were cleared by sampler_bwd_kernel: the logit phase always precedes this one)
+        // every workgroup of a launch resident at once: one per CU, where the occupancy query admits one
+        const int cus = cic_resident_cus(reinterpret_cast<const void*>(&spk_bptt_seq_kernel<8>), 512, BPTT_LDS_BYTES);
+        seq_rows = (cus / (H / 16)) * 16;                     // rows one launch can walk with every workgroup resident
+        seq_kernel = seq_rows >= 16;
+    }
+    if (seq_kernel && do_loop) {
+        // The hand-off counters and the error word: cleared by sampler_bwd_kernel when the logit phase ran in this call; a call
+        // that enters at the loop (CIC_BWD_LOOP / CIC_BWD_REST, or a repeated one on the same ws_bwd) clears them itself - with
+        // counters left at their targets every wait would pass at once and the workgroups would race
+        if (!do_logit) CIC_HIP(hipMemsetAsync(g.sync, 0, sizeof(unsigned) * g.nsync, st));
         BpttArgs ba = {};
         ba.pre_all = w.pre_all; ba.c_all = w.c_all; ba.alpha_all = w.alpha_all; ba.att_h_all = w.att_h_all;
         ba.p_att = w.p_att; ba.att = w.att; ba.out_keep = io->out_keep;
         ba.a2c_w = p->a2c_w; ba.h2h_w = p->h2h_w; ba.h2att_w = p->h2att_w; ba.alpha_w = p->alpha_w;
         ba.d_out_all = g.d_out_all; ba.dpre_all = g.dpre_all; ba.d_att_res_all = g.d_att_res_all;
         ba.d_att_h_all = g.d_att_h_all; ba.ddot_all = g.ddot_all;
-        ba.cnt = g.sync; ba.err = g.sync + (size_t)cic_cdiv(B, 16) * T * 3;
+        ba.cnt = g.sync;
+        ba.hg = handoff_guard(g.sync + (size_t)cic_cdiv(B, 16) * T * 3, io->status, CIC_STATUS_BPTT);
         ba.L = g_bptt_early_stop ? io->L : nullptr;
         ba.zero_tbh = (E == H && !ps) ? g.dx_all : nullptr;       // the K-sliced d x product after the loop adds into it
         ba.scale = scale; ba.B = B; ba.K = K; ba.T = T;

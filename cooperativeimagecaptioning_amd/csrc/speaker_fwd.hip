@@ -6,6 +6,7 @@
 // for the per-region reductions, LDS only for the cross-wave hand-off.  The GEMMs around them
 // (h2att, i2h/h2h, a2c, logit) are cic_gemm_f32.
 #include "cic_common.h"
+#include <mutex>
 #include "engine_util.h"
 
 namespace {
@@ -446,13 +447,13 @@ struct TeacherSeqArgs {
     const float *p_att, *att, *masks;                         // [B,K,H] x2, [B,K] or null
     const uint8_t* out_keep;                                  // [T,B,H] or null
     float *pre_all, *h_all, *c_all, *att_h_all, *att_res_all, *alpha_all, *dot_all, *out_all;   // the decode's activation slabs
-    unsigned *cnt, *err;                                      // [strips][T][3] counters (zeroed by the launcher), 1 word
+    unsigned* cnt;                                            // [strips][T][3] counters (zeroed by the launcher)
+    HandoffGuard hg;                                          // error word behind them, status word, spin bound (cic_common.h)
     float scale;
     int B, K, T;
     int row0, row_end;                                        // rows [row0, row_end) of the batch: one launch per row block
 };
 constexpr size_t TEACHER_LDS_BYTES = sizeof(float) * ((size_t)8 * 8 * 64 * 4 + 8 * 6 * 4 * 64 + 8 * 64);
-constexpr unsigned long long TEACHER_SPIN_TICKS = 1000ull * 100000ull;    // 1 s of the 100 MHz s_memrealtime counter
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 template <int KS>
 __global__ __launch_bounds__(KS * 64) void spk_teacher_seq_kernel(TeacherSeqArgs a) {
@@ -516,25 +517,17 @@ __global__ __launch_bounds__(KS * 64) void spk_teacher_seq_kernel(TeacherSeqArgs
     const auto r_res = uniform_rsrc(a.att_res_all, (size_t)T * B * H * sizeof(float));
     const auto r_patt = uniform_rsrc(a.p_att + (size_t)imc * K * H, (size_t)K * H * sizeof(float));
     const auto r_att = uniform_rsrc(a.att + (size_t)imc * K * H, (size_t)K * H * sizeof(float));
+    if (tid == 0) ok_s = 1;                               // sticky: a workgroup that has given up once does not wait again
     __syncthreads();
     float c_state = 0.f;                                  // c_{t-1} of this lane's (row, unit) (owners); init_hidden: zeros
     float poison = 0.f;
     auto publish = [&](unsigned* c, bool add) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // EVERY storing wave drains before the signal
         __syncthreads();
-        if (tid == 0 && add) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && add) handoff_arrive(c, a.hg);
     };
     auto wait_for = [&](unsigned* c, unsigned target) {
-        if (tid == 0) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            int ok = 1;
-            while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                __builtin_amdgcn_s_sleep(1);
-                if (__builtin_amdgcn_s_memrealtime() - t0 > TEACHER_SPIN_TICKS) { ok = 0; break; }
-            }
-            ok_s = ok;
-            if (!ok) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (tid == 0 && ok_s) ok_s = handoff_poll(c, target, a.hg);
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // compiler only: no load of handed-off bytes above the poll
         if (!ok_s) poison = __builtin_nanf("");
@@ -1688,6 +1681,29 @@ bool cic_teacher_seq_ok(int B, int K, int H, int A, int E) {
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
     return cus >= H / 16;          // at least one strip of 16 rows resident: larger batches are walked in row blocks
 }
+// CUs of the current device if each of them admits one workgroup of `kernel` (threads, dynamic LDS bytes) by the occupancy
+// query, else 0: the grid bound of the one-launch recurrences (residency was taken from the CU count alone).  The
+// query knows this process's kernel only; a second process on the GPU has to be declared (device_shared).
+int cic_resident_cus(const void* kernel, int threads, size_t lds_bytes) {
+    // the answer is a constant of (kernel, device): asked once, then served from a small table (a step asks four times)
+    struct Entry { const void* k; int dev; int cus; };
+    static Entry table[32];
+    static std::atomic<int> filled{0};
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    const int n = filled.load(std::memory_order_acquire);
+    for (int i = 0; i < n; ++i)
+        if (table[i].k == kernel && table[i].dev == dev) return table[i].cus;
+    int cus = 0, blocks = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, threads, lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    const int ans = blocks >= 1 ? cus : 0;
+    std::lock_guard<std::mutex> lock(mu);
+    const int m = filled.load(std::memory_order_relaxed);
+    if (m < 32) { table[m] = Entry{kernel, dev, ans}; filled.store(m + 1, std::memory_order_release); }
+    return ans;
+}
 int cic_teacher_seq(const TeacherSeqLaunch& L, hipStream_t st) {
     static DeviceOnce attr_set;
     if (attr_set.first())
@@ -1700,13 +1716,13 @@ int cic_teacher_seq(const TeacherSeqLaunch& L, hipStream_t st) {
     a.alpha_w = L.alpha_w; a.alpha_b = L.alpha_b; a.p_att = L.p_att; a.att = L.att; a.masks = L.masks; a.out_keep = L.out_keep;
     a.pre_all = L.pre_all; a.h_all = L.h_all; a.c_all = L.c_all; a.att_h_all = L.att_h_all; a.att_res_all = L.att_res_all;
     a.alpha_all = L.alpha_all; a.dot_all = L.dot_all; a.out_all = L.out_all;
-    a.cnt = L.sync; a.err = L.sync + (size_t)strips * L.T * 3;
+    a.cnt = L.sync;
+    a.hg = handoff_guard(L.sync + (size_t)strips * L.T * 3, L.status, CIC_STATUS_TEACHER);
     a.scale = L.scale; a.B = L.B; a.K = L.K; a.T = L.T;
-    int dev = 0, cus = 0;
-    CIC_HIP(hipGetDevice(&dev));
-    CIC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    // every workgroup of a launch must be resident at once: one per CU, and only where the occupancy query admits one
+    const int cus = cic_resident_cus(reinterpret_cast<const void*>(&spk_teacher_seq_kernel<8>), 512, TEACHER_LDS_BYTES);
     const int seq_rows = (cus / 32) * 16;                       // rows one launch can walk with every workgroup resident
-    if (seq_rows < 16) { cic_set_error("teacher_seq: fewer than 32 CUs"); return 1; }
+    if (seq_rows < 16) { cic_set_error("teacher_seq: fewer than 32 CUs admit the kernel"); return 1; }
     for (int row0 = 0; row0 < L.B; row0 += seq_rows) {          // (B = 128: one launch; B = 256: two row blocks)
         a.row0 = row0;
         a.row_end = row0 + seq_rows < L.B ? row0 + seq_rows : L.B;

@@ -5,7 +5,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+from . import _lib, status
 from ._lib import (lib, check, stream, SpeakerDims, SpeakerParams, DecodeIO, DecodeBwdIO, SPEAKER_PARAM_FIELDS,
                    ListenerDims, ListenerParams, ListenerIO, ListenerBwdIO, LISTENER_PARAM_FIELDS, CiderdArgs)
 
@@ -48,6 +48,8 @@ lib.cic_clamp_adam.argtypes = [P, P, P, P, C.c_int64] + [C.c_double] * 6 + [C.c_
 lib.cic_clamp_adam.restype = C.c_int
 lib.cic_clamp_adam_zero.argtypes = [P, P, P, P, C.c_int64] + [C.c_double] * 6 + [C.c_int, C.c_double, C.c_int, P]
 lib.cic_clamp_adam_zero.restype = C.c_int
+lib.cic_clamp_adam_guarded.argtypes = [P, P, P, P, C.c_int64] + [C.c_double] * 6 + [C.c_int, C.c_double, C.c_int, P, P]
+lib.cic_clamp_adam_guarded.restype = C.c_int
 
 ONLY_ONE = {'off': 0, 'image': 1, 'caption': 2}
 # several processes computing on ONE GPU (the multi-rank rehearsals on a one-GPU box: bench.py / train.py / tools with
@@ -158,6 +160,7 @@ def speaker_decode_io(dims, params, att_pre, mode, temp=1.0, att_masks=None, att
         io.timer = timer.handle
     io.ss_u, io.ss_prob, io.ss_pick = _p(ss_u), float(ss_prob), _p(ss_pick)
     io.device_shared = 1 if DEVICE_SHARED[0] else 0
+    io.status = status.ptr(dev)           # hand-off time-outs of the one-launch loops land in the sticky status word
     io.seq, io.slp, io.stv, io.L = _p(out['seq']), _p(out['slp']), _p(out['stv']), _p(out['L'])
     out['io'] = io
     out['_keep'] = (att_pre, att_masks, att_keep, x_keep, out_keep, U, pick, first_token, ss_u, ss_pick, ps_u, fc_x0)   # alive until the backward call
@@ -245,6 +248,7 @@ def listener_fwd(dims, params, fc_feats, labels=None, masks=None, seq=None, stv=
     io.loss_rows, io.loss_sum = _p(out['loss_rows']), _p(out['loss_sum'])
     io.img_emb_out, io.cap_emb_out = _p(out['img_emb']), _p(out['cap_emb'])
     io.device_shared = 1 if DEVICE_SHARED[0] else 0
+    io.status = status.ptr(dev)
     check(lib.cic_listener_fwd(C.byref(dims), C.byref(params), C.byref(io), ws.data_ptr(), ws.numel(), stream()),
           'cic_listener_fwd')
     out['io'] = io
@@ -345,9 +349,12 @@ def masked_nll(slp, mask, weight, dslp=None, loss_out=None):
 
 
 def clamp_adam(p, g, m, v, lr, step, grad_clip=0.1, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0,
-               zero_grad=False):
-    check(lib.cic_clamp_adam_zero(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay,
-                                  grad_clip, int(step), grad_scale, 1 if zero_grad else 0, stream()), 'cic_clamp_adam_zero')
+               zero_grad=False, guarded=True):
+    """guarded: the update reads the device's sticky status word (status.py) and leaves p, m, v and g untouched while it is
+    set - a gradient poisoned by a timed-out hand-off never reaches the weights."""
+    check(lib.cic_clamp_adam_guarded(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay,
+                                     grad_clip, int(step), grad_scale, 1 if zero_grad else 0,
+                                     status.ptr(p.device) if guarded else None, stream()), 'cic_clamp_adam_guarded')
 
 
 TIMED_IDS = {'attn_fwd': 0, 'logit_gemm': 1, 'attn_bwd': 2, 'sampler': 3}

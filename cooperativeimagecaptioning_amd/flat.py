@@ -37,6 +37,9 @@ class FlatAgent:
         self.exp_avg = None
         self.exp_avg_sq = None
         self.step = 0
+        # True from the moment the gradient buffer is handed out for writing (grad_tensors(), a fresh attach()) until a fused
+        # clamp+Adam+zero step has cleared it: FlatAdam.zero_grad() may skip its fill only while this is False
+        self.grad_dirty = True
 
     def attached(self):
         if self.flat is None:
@@ -56,6 +59,7 @@ class FlatAgent:
             if g_old is not None:
                 p.grad.copy_(g_old)
         self.flat, self.grad = flat, grad
+        self.grad_dirty = True
         if self.exp_avg is None or self.exp_avg.device != dev:
             self.exp_avg = torch.zeros(self.numel, device=dev)
             self.exp_avg_sq = torch.zeros(self.numel, device=dev)
@@ -73,6 +77,7 @@ class FlatAgent:
         return {prefix + n: p.data for n, p in zip(self.names, self.params)}
 
     def grad_tensors(self, prefix=''):
+        self.grad_dirty = True            # whoever asks for these writes into them (the backward engines)
         return {prefix + n: self.grad[o:o + p.numel()].view(p.shape)
                 for n, p, o in zip(self.names, self.params, self.offsets)}
 

@@ -67,8 +67,10 @@ class FlatAdam:
         # extra backward): it must land before the buffer is cleared, and must not be mistaken for the next step's
         self._drain()
         self._done.clear()
-        if self._grad_is_zero and self.flat.attached():
-            self._grad_is_zero = False      # cleared by the last step(); whatever runs next writes into it again
+        # the last step() cleared the buffer inside its kernel and NOTHING has asked for it since (FlatAgent.grad_dirty: a
+        # backward into this agent during another agent's turn sets it): only then is the fill skipped
+        if self._grad_is_zero and self.flat.attached() and not self.flat.grad_dirty:
+            self._grad_is_zero = False      # whatever runs next writes into it again
             self.flat.ensure()
             return
         self._grad_is_zero = False
@@ -139,6 +141,8 @@ class FlatAdam:
         engine.clamp_adam(fl.flat, fl.grad, fl.exp_avg, fl.exp_avg_sq, g['lr'], fl.step, clip, g['betas'], g['eps'],
                           g['weight_decay'], scale, zero_grad=self.zero_grad_in_step)
         self._grad_is_zero = bool(self.zero_grad_in_step)
+        if self.zero_grad_in_step:
+            fl.grad_dirty = False           # (a skipped update - status word set - leaves the run to raise; see status.py)
 
     # torch-compatible checkpoints: per-parameter state in parameter order
     def state_dict(self):

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import models, opts, synthetic
+from . import models, opts, status, synthetic
 from .misc import utils
 from .misc.rewards import init_scorer
 from .optimizer import load_optimizer, save_optimizer, zeroing_optimizer, update_optimizer
@@ -249,7 +249,12 @@ class LossLog:
     (train.py:533-535): a host sync per iteration, after which the device idles while Python prepares the next step's first
     launches.  Here the step's loss and the logged terms (model.loss(): 0-dim device values) are gathered by ONE small launch,
     copied to page-locked memory asynchronously and read when their event has fired - normally while the NEXT step is being
-    enqueued; the host never runs more than `depth` iterations ahead of the device."""
+    enqueued; the host never runs more than `depth` iterations ahead of the device.
+
+    The device's sticky status word (status.py: a hand-off of a one-launch recurrence timed out) rides in the same copy, its
+    32 bits carried unchanged in a float slot: pop() raises CicError naming the loop and the iteration whose line it was
+    reading - the first line after the failure - before that line is emitted.  The optimiser kernels read the same word on
+    the device and skip their updates from the failing step on, so the weights stay those of the last good step."""
 
     def __init__(self, device, depth=2, width=32):
         self.depth, self.width = depth, width
@@ -259,9 +264,10 @@ class LossLog:
         self._n = 0
 
     def push(self, meta, loss, terms):
-        keys = list(terms.keys())[:self.width - 1]
+        keys = list(terms.keys())[:self.width - 2]
         vals = [loss.detach().reshape(())] + [torch.as_tensor(terms[k], device=loss.device).detach().reshape(()).float()
                                               for k in keys]
+        vals.append(status.word(loss.device).view(torch.float32)[0])      # bit pattern of the int32 word (copied, never computed on)
         slot = self.slots[self._n % len(self.slots)]
         self._n += 1
         slot[:len(vals)].copy_(torch.stack(vals), non_blocking=True)
@@ -275,7 +281,8 @@ class LossLog:
         while self.pending and (len(self.pending) > block_to or self.pending[0][3].query()):
             meta, keys, slot, ev, n = self.pending.pop(0)
             ev.synchronize()
-            vals = slot[:n].tolist()
+            status.raise_if_set(int(slot[n - 1:n].view(torch.int32)[0]), f"seen with the log line of iteration {meta['iteration']}")
+            vals = slot[:n - 1].tolist()
             self.last[meta['iteration']] = vals[0]
             emit(meta, vals[0], dict(zip(keys, vals[1:])))
 
@@ -409,6 +416,7 @@ def train(opt, loader=None):
         done = (epoch >= opt.max_epochs != -1) or (0 < opt.max_iterations <= iteration)
         if iteration % opt.save_checkpoint_every == 0 or start_ckpt:               # train.py:546-552
             log.pop(emit, block_to=0)                            # the histories record holds every line up to here
+            status.check(device, f'before the checkpoint of iteration {iteration}')   # never save weights behind a failed hand-off
             operations_in_checkpoint(opt, model, loader, iteration, epoch, best, optimizer_dict, infos, histories)
             model.train()
         if start_ckpt:
@@ -416,6 +424,7 @@ def train(opt, loader=None):
         if done:
             break
     log.pop(emit, block_to=0)
+    status.check(device, 'at the end of training')
     if hasattr(loader, 'close'):
         loader.close()
     return model

@@ -34,6 +34,27 @@ typedef void* cic_stream_t; /* hipStream_t */
 int cic_version(void);
 const char* cic_last_error(void);
 
+/* ---- status word: failures of the one-launch recurrences, reported without a host synchronisation -------------------
+ * Four loops of a step run as ONE launch whose workgroups hand state to each other inside the launch (the listener's GRU pass
+ * and its BPTT loop, the speaker's teacher-forced recurrence and its BPTT loop).  They need every workgroup RESIDENT at once:
+ * one per CU.  When something else holds CUs (a second process on the GPU that did not say so through device_shared, a
+ * CU-masked queue) a workgroup waits for partners that never start; every such wait is bounded (1 s), the workgroup that gives
+ * up poisons what it produces with NaN, and - new in round 4 - sets its loop's bit in the caller-owned device word
+ * `status` of the io struct (cic_decode_io.status, cic_listener_io.status; NULL = not reported):
+ *     CIC_STATUS_GRU_FWD | CIC_STATUS_GRU_BWD | CIC_STATUS_TEACHER | CIC_STATUS_BPTT.
+ * The word is STICKY: the library only ever ORs into it; the caller zeroes it once and reads it when it likes (the trainer
+ * copies it to pinned memory beside the step's loss and raises; no extra synchronisation).  cic_clamp_adam_guarded reads the
+ * same word on the device: while it is non-zero the update is SKIPPED - parameters, moments and the gradient stay as they
+ * were - and CIC_STATUS_UPDATE_SKIPPED is set, so a poisoned gradient never reaches the weights.  A process that shares its
+ * GPU must set device_shared (CIC_SHARED_DEVICE=1 on the Python host): the loops then run as per-step launches. */
+enum {
+    CIC_STATUS_GRU_FWD = 1,          /* gru_seq_kernel         (VSEFCModel.py:95-140) */
+    CIC_STATUS_GRU_BWD = 2,          /* gru_seq_bwd_kernel */
+    CIC_STATUS_TEACHER = 4,          /* spk_teacher_seq_kernel (AttModel.py:103-148) */
+    CIC_STATUS_BPTT = 8,             /* spk_bptt_seq_kernel    (AttModel.py:465-531 reversed) */
+    CIC_STATUS_UPDATE_SKIPPED = 256  /* cic_clamp_adam_guarded found the word set and left the weights alone */
+};
+
 /* ---- in-situ kernel timing: a caller-owned object, no library state -------------------------------------
  * A decode whose cic_decode_io.timer is set brackets every launch of the kernels listed below with a pair of HIP
  * events on its own stream (forward and backward); the events live in the cic_timer.  cic_timer_collect
@@ -338,6 +359,8 @@ typedef struct {
     int device_shared;        /* != 0: other processes run kernels on this device at the same time.  The teacher-forced
                                  recurrence is then launched step by step (its one-launch form needs all its workgroups
                                  resident together) */
+    uint32_t* status;         /* the caller's sticky status word on the device ("status word" above) or NULL: the one-launch
+                                 loops of this decode - forward AND backward - OR their bit into it when a hand-off times out */
 } cic_decode_io;
 
 /* Bytes of workspace a decode needs; the same workspace must be handed, untouched, to
@@ -453,6 +476,8 @@ typedef struct {
                                  to each other inside the launch, which needs all of them resident together (a second
                                  process's kernels could hold the CUs some of them wait for: the pass would then give up
                                  after its time budget and mark its outputs NaN rather than hang) */
+    uint32_t* status;         /* the caller's sticky status word on the device ("status word" above) or NULL: the GRU pass and
+                                 its BPTT loop (cic_listener_bwd reads this struct too) OR their bit into it on a time-out */
 } cic_listener_io;
 
 typedef struct {
@@ -505,11 +530,19 @@ int cic_loss_combine(const float* const* term, const float* weight, int count, f
 int cic_clamp_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
                    double beta2, double eps, double weight_decay, double grad_clip, int step,
                    double grad_scale, cic_stream_t s);
-/* The same update that also CLEARS the gradient buffer while each element is in registers (zero_grad != 0): the next
+/* The clamp propagates NaN as torch's clamp_ does (misc/utils.py:65-69: a NaN gradient stays NaN, and Adam then writes NaN
+ * into the parameter - the reference's behaviour; fminf / fmaxf alone would turn it into -grad_clip).
+ * The same update that also CLEARS the gradient buffer while each element is in registers (zero_grad != 0): the next
  * step's zeroing_optimizer (optimizer.py:224-230) then has nothing left to do.  zero_grad == 0: cic_clamp_adam. */
 int cic_clamp_adam_zero(float* p, float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                         double eps, double weight_decay, double grad_clip, int step, double grad_scale, int zero_grad,
                         cic_stream_t s);
+/* cic_clamp_adam_zero behind the status word ("status word" above): when *status != 0 at launch time the kernel touches
+ * nothing - p, m, v AND g stay as they are (the poisoned gradient remains as evidence) - and sets CIC_STATUS_UPDATE_SKIPPED.
+ * status == NULL: cic_clamp_adam_zero. */
+int cic_clamp_adam_guarded(float* p, float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                           double eps, double weight_decay, double grad_clip, int step, double grad_scale, int zero_grad,
+                           uint32_t* status, cic_stream_t s);
 
 /* ---- self-critical CIDEr-D reward: misc/rewards.py:26-72, ciderD_scorer.py:13-215 ---------- */
 typedef struct {

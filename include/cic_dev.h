@@ -55,7 +55,14 @@ int cic_debug_gru_fused(int on);
 int cic_debug_set_gru_stamps(unsigned long long* buf);
 /* diagnostics: 0 runs the speaker's a2c product and cell as two launches instead of the fused kernel */
 int cic_debug_a2c_cell_fused(int on);
-
+/* fault injection for the hand-offs of the one-launch recurrences (cic.h: "status word"): the spin bound in ticks of the
+ * 100 MHz s_memrealtime counter (0 = back to 1 s), and ONE workgroup (blockIdx.x = wg) of the loops named by loop_bits
+ * (CIC_STATUS_GRU_FWD | ...) that never counts itself in, so that its partners time out (loop_bits 0 = off) */
+int cic_debug_spin_ticks(unsigned long long ticks);
+int cic_debug_handoff_fault(int loop_bits, int wg);
+/* the stand-in for a collective's kernel: `wgs` workgroups (256 threads) that each hold lds_bytes of LDS - 64 KB and more keep a
+ * one-launch recurrence's workgroup (100+ KB) off their CU - for `ticks` of the 100 MHz clock, on stream s */
+int cic_debug_hold_cus(int wgs, unsigned long long ticks, int lds_bytes, cic_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""What happens when a hand-off inside a one-launch recurrence FAILS, and what a kernel that holds CUs beside one costs
+(development build: include/cic_dev.h).
+
+Part 1 - forced time-out, once per loop (listener GRU pass, its BPTT loop, speaker BPTT loop on a full-width joint step;
+the teacher-forced recurrence on a full-width MLE step): the spin bound is lowered to 2 ms and ONE workgroup of the loop is
+told never to count itself in (cic_debug_handoff_fault), so its partners give up.  Required: the loop's bit appears in the
+sticky status word; the clamp+Adam kernels SKIP their updates (weights, moments and step counters' buffers bit-equal to
+before the step, CIC_STATUS_UPDATE_SKIPPED set); train.LossLog raises CicError naming the loop; the whole step still ends
+within a few bounds (a workgroup that has given up does not wait again).  After clearing the word and the fault the same
+step runs clean and updates the weights.
+
+Part 2 - CU occupancy: a second stream launches a kernel that HOLDS n CUs (64 KB of LDS each: no loop workgroup fits beside
+it) for 2 ms right before the forward pass and again right before the backward pass - the stand-in for an RCCL kernel that
+occupies CUs while a 256-workgroup loop starts.  Required: no status bit, loss bit-equal to the undisturbed step, gradients
+to float-atomic tolerance.  The slowdown per step is printed: it is the price estimate of a collective that overlaps a loop.
+
+  python tools/handoff_fault_check.py        -> one JSON line; exit code 0 when everything holds"""
+import contextlib
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _devlib  # noqa: F401,E402
+import torch  # noqa: E402
+from cooperativeimagecaptioning_amd import models, optimizer as optim, synthetic, status, train as T, _lib  # noqa: E402
+from cooperativeimagecaptioning_amd.misc import rewards  # noqa: E402
+
+
+def main():
+    lib = _lib.lib
+    lib.cic_debug_spin_ticks.argtypes = [C.c_ulonglong]
+    lib.cic_debug_handoff_fault.argtypes = [C.c_int, C.c_int]
+    lib.cic_debug_hold_cus.argtypes = [C.c_int, C.c_ulonglong, C.c_int, C.c_void_p]
+    dev = torch.device('cuda', 0)
+    rewards.init_scorer('corpus')
+    report, ok = {}, True
+
+    def build(mle):
+        opt = synthetic.default_opt(batch_size=64 if mle else 128)
+        if mle:       # BASELINE configs[1]: AttModel MLE
+            opt.caption_loss_weight, opt.retrieval_reward_weight, opt.cider_optimization = 1.0, 0.0, 0.0
+        torch.manual_seed(0)
+        model = models.AlternatingJointModel(opt).to(dev).train()
+        with contextlib.redirect_stdout(sys.stderr):
+            od = optim.load_optimizer(model, opt)
+        optim.fuse_zero_grad(od)
+        batch = synthetic.make_batch(opt, seed=12, device=dev)
+        return opt, model, od, batch
+
+    def step(opt, model, od, batch, seed=7):
+        model.caption_generator.noise.manual_seed(seed)
+        optim.zeroing_optimizer(opt, od, od['speaker'])
+        loss = model(batch['fc_feats'], batch['labels'], batch['masks'], batch, batch['att_feats'], batch['att_masks'],
+                     is_alternating=True, alternating_turn='speaker')
+        loss.backward()
+        optim.update_optimizer(od, od['speaker'], opt)
+        return loss
+
+    def snapshot(od):
+        return {a: (o.flat.flat.clone(), o.flat.exp_avg.clone(), o.flat.exp_avg_sq.clone()) for a, o in od['speaker'].items()}
+
+    # ---- part 1: forced time-outs ---------------------------------------------------------------------------------
+    cases = (('gru_fwd', status.GRU_FWD, False), ('gru_bwd', status.GRU_BWD, False), ('bptt', status.BPTT, False),
+             ('teacher', status.TEACHER, True))
+    sets = {}
+    for name, bit, mle in cases:
+        if mle not in sets:
+            sets[mle] = build(mle)
+        opt, model, od, batch = sets[mle]
+        step(opt, model, od, batch)                       # a clean step first (also: workspaces exist)
+        torch.cuda.synchronize()
+        status.check(dev, 'clean step')
+        before = snapshot(od)
+        lib.cic_debug_spin_ticks(200000)                  # 2 ms
+        lib.cic_debug_handoff_fault(bit, 3)
+        t0 = time.time()
+        loss = step(opt, model, od, batch)
+        log = T.LossLog(dev)
+        log.push(dict(iteration=41, epoch=0, turn='speaker', host_s=0.0, to_history=False), loss, model.loss())
+        raised = ''
+        try:
+            log.pop(lambda *a: None, block_to=0)
+        except _lib.CicError as e:
+            raised = str(e)
+        torch.cuda.synchronize()
+        wall = time.time() - t0
+        word = int(status.word(dev)[0].item())
+        after = snapshot(od)
+        untouched = all(torch.equal(x, y) for a in before for x, y in zip(before[a], after[a]))
+        # the poisoned gradient is still there as evidence (the guarded kernel leaves g alone); the failing loop's agent has NaN in it
+        lib.cic_debug_handoff_fault(0, -1)
+        lib.cic_debug_spin_ticks(0)
+        status.clear(dev)
+        for o in od['speaker'].values():                  # the failed step's gradient is discarded like any other: zero_grad
+            o._grad_is_zero = False
+        loss2 = step(opt, model, od, batch)
+        torch.cuda.synchronize()
+        clean_word = int(status.word(dev)[0].item())
+        moved = any(not torch.equal(before[a][0], o.flat.flat) for a, o in od['speaker'].items())
+        finite = bool(torch.isfinite(loss2)) and all(bool(torch.isfinite(o.flat.flat).all()) for o in od['speaker'].values())
+        good = (word & bit) != 0 and (word & status.UPDATE_SKIPPED) != 0 and untouched and status.LOOPS[bit] in raised and \
+            'iteration 41' in raised and wall < 2.0 and clean_word == 0 and moved and finite
+        report[name] = dict(status_word=hex(word), weights_and_moments_untouched=untouched, losslog_raised=bool(raised),
+                            names_loop=status.LOOPS[bit] in raised, step_wall_s=round(wall, 3), clean_after_clear=clean_word == 0,
+                            next_step_updates=moved, next_step_finite=finite)
+        ok = ok and good
+
+    # ---- part 2: a kernel that holds CUs beside the loops ------------------------------------------------------------
+    opt, model, od, batch = sets[False]
+    agents = od['speaker']
+    side = torch.cuda.Stream()
+
+    def fwd_bwd(hold):
+        model.caption_generator.noise.manual_seed(7)
+        optim.zeroing_optimizer(opt, od, od['speaker'])
+        for o in agents.values():
+            o.flat.grad.zero_()
+        if hold:
+            lib.cic_debug_hold_cus(hold, 200000, 64 * 1024, side.cuda_stream)
+        loss = model(batch['fc_feats'], batch['labels'], batch['masks'], batch, batch['att_feats'], batch['att_masks'],
+                     is_alternating=True, alternating_turn='speaker')
+        if hold:
+            lib.cic_debug_hold_cus(hold, 200000, 64 * 1024, side.cuda_stream)
+        loss.backward()
+        return loss.detach().clone(), {a: o.flat.grad.clone() for a, o in agents.items()}
+
+    ref_loss, ref_g = fwd_bwd(0)
+    torch.cuda.synchronize()
+    occ = {}
+    for hold in (0, 8, 32):
+        for _ in range(2):
+            fwd_bwd(hold)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        bad = 0
+        n = 10
+        e0.record()
+        outs = [fwd_bwd(hold) for _ in range(n)]
+        e1.record()
+        torch.cuda.synchronize()
+        for loss, g in outs:
+            if float(loss) != float(ref_loss):
+                bad += 1
+            for a in g:
+                if not float((g[a] - ref_g[a]).abs().max()) <= 1e-5 * float(ref_g[a].abs().max()):
+                    bad += 1
+        word = int(status.word(dev)[0].item())
+        occ[f'hold_{hold}_cus'] = dict(ms_per_fwd_bwd=round(e0.elapsed_time(e1) / n, 3), mismatches=bad, status_word=hex(word))
+        ok = ok and bad == 0 and word == 0
+    base = occ['hold_0_cus']['ms_per_fwd_bwd']
+    for k, v in occ.items():
+        v['slowdown_ms'] = round(v['ms_per_fwd_bwd'] - base, 3)
+    occ['note'] = ('two 2 ms holds per step (before the forward pass, before the backward pass) on a second stream; a held CU '
+                   'delays the workgroup of a one-launch loop that needs it until the hold ends - the partners spin, nothing fails')
+    report['occupancy'] = occ
+    report['handoff_fault_check'] = 'ok' if ok else 'FAILED'
+    print(json.dumps(report), flush=True)
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == '__main__':
+    main()

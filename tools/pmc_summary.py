@@ -37,13 +37,17 @@ def main():
         wb = 1024.0 * sum(w) / max(len(w), 1)
         out['kernels'].append({'kernel': short(key[0]), 'grid_threads': key[1], 'launches': max(len(f), len(w)),
                                'read_bytes': round(rb), 'write_bytes': round(wb), 'total_bytes': round(rb + wb)})
-    # calibration: clamp+Adam over the two flat parameter buffers (14,453,201 + 11,680,576 floats... read from the run)
+    # calibration on a kernel whose bytes are known exactly: clamp+Adam over the two flat parameter buffers.  It reads p, g, m, v
+    # (16 B per parameter); the <true> form (the step's: it clears g on the way out) writes p, m, v, g = 16 B, the <false> form
+    # p, m, v = 12 B.  Expected read / write ratio: 1.0 for <true>, 4/3 for <false>.
     adam = [k for k in out['kernels'] if k['kernel'].startswith('clamp_adam_kernel')]
     if adam:
         rd = sum(k['read_bytes'] * k['launches'] for k in adam) / sum(k['launches'] for k in adam)
         wr = sum(k['write_bytes'] * k['launches'] for k in adam) / sum(k['launches'] for k in adam)
-        out['calibration'] = {'clamp_adam_read_over_write': rd / wr, 'expected': 16.0 / 12.0,
-                              'note': 'clamp_adam reads p,g,m,v and writes p,m,v: 16 B vs 12 B per parameter'}
+        zeroing = all('<true>' in k['kernel'] or '<1>' in k['kernel'] for k in adam)
+        out['calibration'] = {'clamp_adam_read_over_write': rd / wr, 'expected': 1.0 if zeroing else 16.0 / 12.0,
+                              'note': ('clamp_adam_kernel<true> reads p,g,m,v and writes p,m,v and the cleared g: 16 B vs 16 B per parameter'
+                                       if zeroing else 'clamp_adam_kernel<false> reads p,g,m,v and writes p,m,v: 16 B vs 12 B per parameter')}
     json.dump(out, open(sys.argv[3], 'w'), indent=1)
     for k in out['kernels'][:12]:
         print(k)
