@@ -116,7 +116,7 @@ class CiderdArgs(C.Structure):
                 ('Tr', C.c_int), ('gen', c_ptr), ('L_gen', c_ptr), ('greedy', c_ptr), ('L_greedy', c_ptr),
                 ('refs', c_ptr), ('ref_off', c_ptr), ('scores', c_ptr), ('reward', c_ptr), ('stats', c_ptr),
                 ('dbg_keys', c_ptr), ('dbg_cnt', c_ptr), ('dbg_df', c_ptr), ('dbg_nuniq', c_ptr),
-                ('vocab_size', C.c_int)]
+                ('vocab_size', C.c_int), ('max_refs_per_image', C.c_int)]
 
 
 class ListenerDims(C.Structure):

@@ -29,13 +29,24 @@ class EngineLoss(torch.autograd.Function):
 
 
 _ONES = {}
+# True: a bare ``loss.backward()`` calls the step's backward closure directly, on the caller's thread and stream, instead of
+# going through torch's autograd engine (whose device thread hand-over showed as a ~25 us hole between the forward and the
+# backward launches of every step: profiles/r03_step_sequence.txt).  The autograd node stays in place for every other use.
+DIRECT_BACKWARD = [True]
 
 
 def engine_loss(loss_value, anchor, backward_fn):
     """EngineLoss.apply whose result answers a bare ``loss.backward()`` (train.py:203-208) with a cached tensor of ones as the
     upstream gradient: autograd otherwise makes one with a fill launch (5 us on a ~3 ms step) every iteration.  Any other use of the
     loss (arithmetic on it, ``backward(gradient=...)``, ``torch.autograd.grad``) takes the ordinary path."""
-    out = EngineLoss.apply(loss_value, anchor, backward_fn)
+    cell = [backward_fn]
+
+    def run(go):
+        fn, cell[0] = cell[0], None
+        if fn is None:
+            raise RuntimeError('the engine workspace of this step was already consumed by a backward pass')
+        fn(go)
+    out = EngineLoss.apply(loss_value, anchor, run)
     tensor_backward = torch.Tensor.backward
     # the closure holds the loss WEAKLY: a strong reference would make loss -> closure -> loss a cycle, and the step's decode /
     # listener results (kept alive by the autograd node) would wait for the cyclic collector instead of dying with the loss
@@ -50,6 +61,10 @@ def engine_loss(loss_value, anchor, backward_fn):
             gradient = _ONES.get(key)
             if gradient is None:
                 gradient = _ONES[key] = torch.ones(key[2], dtype=key[1], device=key[0])
+            if DIRECT_BACKWARD[0] and not args and not kwargs:
+                with torch.no_grad():             # as inside an autograd node: the closure's own torch ops record nothing
+                    run(gradient)
+                return None
         return tensor_backward(me, gradient, *args, **kwargs)
     out.backward = backward
     return out

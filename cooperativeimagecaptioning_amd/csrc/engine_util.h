@@ -66,7 +66,8 @@ int cic_teacher_finish_all(const float* part, int np, int part_rows, const float
                            float* lse_all, float* slp, int T, int B, hipStream_t st);
 int cic_finalize_len2(Dual<const int> any_unfinished, int T, Dual<int> L, int nb, hipStream_t st);
 int cic_sample_finish2(const cic_sampler_args* a, const float* part_a, int part_rows_a, float* lse_a,
-                       const cic_sampler_args* b, const float* part_b, int part_rows_b, float* lse_b, int np, hipStream_t st);
+                       const cic_sampler_args* b, const float* part_b, int part_rows_b, float* lse_b, int np, hipStream_t st,
+                       int32_t* L_a = nullptr, int32_t* L_b = nullptr, int T = 0);
 // dropout of the embedded regions with ragged region counts: rows beyond an image's own regions become 0
 // the teacher-forced recurrence of a decode as ONE launch (speaker_fwd.hip: spk_teacher_seq_kernel)
 struct TeacherSeqLaunch {

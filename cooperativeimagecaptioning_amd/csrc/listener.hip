@@ -27,10 +27,13 @@ __device__ unsigned long long* g_gru_stamps = nullptr;   // development build: [
 // ---- token preparation -----------------------------------------------------------------
 // generated captions: tokens = [<bos>, seq[:, 0:L]], lens from masks [1,1,(seq>0)[:, :L-1]]
 // (models/AlternatingJointModel.py:353-370)
+// (r4) ... and the caption's embedded input rows x_emb[t,b,:] = val[b,t] * E[idx[b,t],:] in the same launch (embed_st_fwd_kernel's
+// arithmetic; the tokens are in the wave's lanes already: one launch and one dependent round trip less per step)
 __global__ __launch_bounds__(256) void prep_generated_kernel(const int32_t* __restrict__ seq, const float* __restrict__ stv,
                                       const int32_t* __restrict__ Lp, int B, int T, int bos, int dense,
                                       int32_t* __restrict__ idx, float* __restrict__ val,
-                                      int32_t* __restrict__ len, unsigned* __restrict__ sync, int nsync) {
+                                      int32_t* __restrict__ len, unsigned* __restrict__ sync, int nsync,
+                                      const float* __restrict__ E, float* __restrict__ x_emb, int Ed) {
     // dense != 0 (soft caption rows): positions 1..T are embedded by a dense product added afterwards, so
     // their gather contributes nothing (val = 0)
     // one wave per caption, lane j = token j (T <= 63; longer captions: lanes stride): one round trip per row instead of T
@@ -40,11 +43,27 @@ __global__ __launch_bounds__(256) void prep_generated_kernel(const int32_t* __re
     if (b >= B) return;                                     // whole waves
     const int L = *Lp;
     int cnt = 0;
+    int tok_l = 0;                 // this lane's position j = lane (captions of up to 63 tokens: the fused embedding's case)
+    float val_l = 1.0f;
     for (int j = lane; j < T; j += 64) {
         const int tok = seq[(size_t)b * T + j];
-        idx[(size_t)b * (T + 1) + 1 + j] = (j < L && !dense) ? tok : 0;
-        val[(size_t)b * (T + 1) + 1 + j] = dense ? 0.0f : ((j < L && stv) ? stv[(size_t)b * T + j] : 1.0f);
+        const int ti = (j < L && !dense) ? tok : 0;
+        const float tv = dense ? 0.0f : ((j < L && stv) ? stv[(size_t)b * T + j] : 1.0f);
+        idx[(size_t)b * (T + 1) + 1 + j] = ti;
+        val[(size_t)b * (T + 1) + 1 + j] = tv;
+        if (j == lane) { tok_l = ti; val_l = tv; }
         if (j < L - 1 && tok > 0) ++cnt;
+    }
+    if (x_emb && T < 64) {
+        // position p of the caption: p = 0 is <bos> (value 1), p >= 1 the token lane p-1 holds; time-major rows [p, b, :]
+        const int E4 = Ed >> 2;
+        for (int p = 0; p <= T; ++p) {
+            const int tok = p == 0 ? bos : __shfl(tok_l, p - 1, 64);
+            const float v = p == 0 ? 1.0f : __shfl(val_l, p - 1, 64);
+            const f32x4* er = reinterpret_cast<const f32x4*>(E + (size_t)tok * Ed);
+            f32x4* xr = reinterpret_cast<f32x4*>(x_emb + ((size_t)p * B + b) * Ed);
+            for (int c = lane; c < E4; c += 64) xr[c] = er[c] * v;
+        }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
@@ -658,10 +677,18 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
 }
 
 // ---- l2norm (VSEFCModel.py:12-17): y = x / (||x|| + 1e-7) ---------------------------------
-__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                         float* __restrict__ nrm, int J, int use_abs, int do_norm) {
+// two row sets in ONE launch (the image embeddings and the caption embeddings of a listener pass): workgroup b < B is row b of
+// the first set, workgroup B + b row b of the second; per row y = x / (||x|| + 1e-7) (|y| with use_abs), nrm = ||x||
+__global__ __launch_bounds__(256) void l2norm_fwd2_kernel(const float* __restrict__ x0, float* __restrict__ y0, float* __restrict__ n0,
+                                                          int norm0, const float* __restrict__ x1, float* __restrict__ y1,
+                                                          float* __restrict__ n1, int norm1, int B, int J, int use_abs) {
     __shared__ float sh[4];
-    const int b = blockIdx.x;
+    const bool second = (int)blockIdx.x >= B;
+    const int b = second ? blockIdx.x - B : blockIdx.x;
+    const float* x = second ? x1 : x0;
+    float* y = second ? y1 : y0;
+    float* nrm = second ? n1 : n0;
+    const int do_norm = second ? norm1 : norm0;
     float s = 0.f;
     for (int j = threadIdx.x; j < J; j += 256) {
         const float v = x[(size_t)b * J + j];
@@ -680,11 +707,21 @@ __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict
     if (threadIdx.x == 0) nrm[b] = n;
 }
 // dx = (dy' - yn * (yn . dy') * (n + eps) / n) / (n + eps),  yn = x/(n+eps), dy' = dy*sign(yn) if abs
-__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ nrm,
-                                                         const float* __restrict__ dy, float* __restrict__ dx, int J,
-                                                         int use_abs, int do_norm) {
+// the backward twin of l2norm_fwd2_kernel: two row sets in one launch (gridDim.x = B: the second set only, rows b of
+// (x1, n1, dy1, dx1); gridDim.x = 2B: workgroups [0, B) the first set, [B, 2B) the second)
+__global__ __launch_bounds__(256) void l2norm_bwd2_kernel(const float* __restrict__ x0, const float* __restrict__ n0,
+                                                          const float* __restrict__ dy0, float* __restrict__ dx0, int norm0,
+                                                          const float* __restrict__ x1, const float* __restrict__ n1,
+                                                          const float* __restrict__ dy1, float* __restrict__ dx1, int norm1,
+                                                          int B, int J, int use_abs) {
     __shared__ float sh[4];
-    const int b = blockIdx.x;
+    const bool first = (int)gridDim.x == 2 * B && (int)blockIdx.x < B;
+    const int b = ((int)gridDim.x == 2 * B && !first) ? blockIdx.x - B : blockIdx.x;
+    const float* x = first ? x0 : x1;
+    const float* nrm = first ? n0 : n1;
+    const float* dy = first ? dy0 : dy1;
+    float* dx = first ? dx0 : dx1;
+    const int do_norm = first ? norm0 : norm1;
     const float n = nrm[b];
     const float inv = do_norm ? 1.0f / (n + 1e-7f) : 1.0f;
     float s = 0.f;
@@ -716,7 +753,12 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
 __global__ __launch_bounds__(64) void contrastive_fwd_kernel(const float* __restrict__ S, int B, float margin,
                                                              int max_violation, int sel_s, int sel_im,
                                                              float* __restrict__ out_rows, int32_t* __restrict__ arg_s,
-                                                             int32_t* __restrict__ arg_im) {
+                                                             int32_t* __restrict__ arg_im, unsigned* __restrict__ arrived,
+                                                             float* __restrict__ out_sum) {
+    // arrived / out_sum: (r4) the scalar loss in the same launch.  Every workgroup (one wave) stores its row's loss write-through,
+    // drains, and counts itself in; the one whose add comes last sums the B rows in row order with sc1 loads - exactly
+    // contrastive_sum_kernel's chunks of 64 added in order, so the sum is bit-identical to the two-launch form.  `arrived` is
+    // zeroed with the listener's hand-off counters by the token-preparation kernel.
     const int i = blockIdx.x, lane = threadIdx.x;
     const float d = S[(size_t)i * B + i];
     float cs = 0.f, ci = 0.f;
@@ -751,20 +793,25 @@ __global__ __launch_bounds__(64) void contrastive_fwd_kernel(const float* __rest
         ci = wave_sum(ci) / (float)B;
         as = ai = -1;
     }
+    unsigned ticket = 0;
     if (lane == 0) {
-        out_rows[i] = (sel_s ? cs : 0.f) + (sel_im ? ci : 0.f);
+        __hip_atomic_store(out_rows + i, (sel_s ? cs : 0.f) + (sel_im ? ci : 0.f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (arg_s) arg_s[i] = as;
         if (arg_im) arg_im[i] = ai;
+        if (arrived) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ticket = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-}
-// scalar loss = sum of the per-row losses in row order (fixed summation order)
-__global__ __launch_bounds__(64) void contrastive_sum_kernel(const float* __restrict__ rows, int B, float* __restrict__ out_sum) {
+    if (!arrived) return;
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket != (unsigned)B - 1u) return;              // (wave-uniform)
     float s = 0.f;
     for (int j0 = 0; j0 < B; j0 += 64) {
-        const int j = j0 + (int)threadIdx.x;
-        s += wave_sum(j < B ? rows[j] : 0.f);
+        const int j = j0 + lane;
+        s += wave_sum(j < B ? __hip_atomic_load(out_rows + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f);
     }
-    if (threadIdx.x == 0) *out_sum = s;
+    if (lane == 0) *out_sum = s;
 }
 // dS from per-row upstream gradients g_rows[i] (scalar loss: all equal), one thread per entry of dS: what the reference's
 // autograd scatters (row i: +g at its hardest negative(s), -g on the diagonal) is gathered per (i, j) - no zero-fill of dS
@@ -826,7 +873,8 @@ LstWs lst_carve(const cic_listener_dims& d, void* base) {
     LstWs w;
     Carver c(base);
     const size_t B = d.B, J = d.J, E = d.E, Lp = d.Lp;
-    w.nsync = (int)(2 * ((B + 15) / 16) * (Lp + 1) + 1);   // forward counters, backward counters (16-row strips each), error word
+    // forward counters, backward counters (16-row strips each), error word, arrival counter of the contrastive loss's row sum
+    w.nsync = (int)(2 * ((B + 15) / 16) * (Lp + 1) + 2);
     w.sync = reinterpret_cast<unsigned*>(c.i32((size_t)(w.nsync + 3) / 4 * 4));
     w.idx = c.i32(B * Lp);
     w.len = c.i32(B);
@@ -914,23 +962,24 @@ static int listener_fwd_impl(const cic_listener_dims* dp, const cic_listener_par
     int rc;
 #define RUN(x) if ((rc = (x)) != 0) return rc
     // tokens
+    bool embedded = false;         // generated captions: the preparation kernel embeds the rows itself
     if (io->labels) {
         CIC_REQUIRE(io->masks);
         hipLaunchKernelGGL(prep_labels_kernel, dim3(cic_cdiv(B, 256)), dim3(256), 0, st, io->labels, io->masks, B, Lp,
                            w.idx, w.val, w.len, w.sync, w.nsync);
     } else {
         CIC_REQUIRE(io->seq && io->L && Lp == d.T + 1);
+        embedded = d.T < 64 && (E & 3) == 0;
         hipLaunchKernelGGL(prep_generated_kernel, dim3(cic_cdiv(B, 4)), dim3(256), 0, st, io->seq, io->stv, io->L, B,
-                           d.T, d.V + 1, io->soft ? 1 : 0, w.idx, w.val, w.len, w.sync, w.nsync);
+                           d.T, d.V + 1, io->soft ? 1 : 0, w.idx, w.val, w.len, w.sync, w.nsync,
+                           embedded ? p->embed_w : nullptr, embedded ? w.x_emb : nullptr, E);
     }
     CIC_LAUNCH_CHECK();
-    // image encoder: l2norm(fc W^T + b)                                  (VSEFCModel.py:40-54)
+    // image encoder: l2norm(fc W^T + b)                                  (VSEFCModel.py:40-54); its l2norm shares a launch with
+    // the caption's, after the GRU pass
     RUN(gemm_nt(io->fc_feats, d.F, p->img_fc_w, d.F, w.img_lin, J, B, J, d.F, p->img_fc_b, false, false, st));
-    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(B), dim3(256), 0, st, w.img_lin, w.img_emb, w.nrm_img, J, d.use_abs,
-                       !d.no_imgnorm);
-    CIC_LAUNCH_CHECK();
     // text encoder                                                       (VSEFCModel.py:95-140)
-    {
+    if (!embedded) {
         const int64_t n = (int64_t)Lp * B * (E / 4);
         hipLaunchKernelGGL(embed_st_fwd_kernel, dim3(cic_cdiv(n, 256)), dim3(256), 0, st, p->embed_w, w.idx, w.val,
                            w.x_emb, B, Lp, E);
@@ -988,15 +1037,14 @@ static int listener_fwd_impl(const cic_listener_dims* dp, const cic_listener_par
         CIC_LAUNCH_CHECK();
         cap_raw = w.pooled;
     }
-    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(B), dim3(256), 0, st, cap_raw, w.cap_emb, w.nrm_cap, J, d.use_abs, 1);
+    hipLaunchKernelGGL(l2norm_fwd2_kernel, dim3(2 * B), dim3(256), 0, st, w.img_lin, w.img_emb, w.nrm_img, !d.no_imgnorm,
+                       cap_raw, w.cap_emb, w.nrm_cap, 1, B, J, d.use_abs);
     CIC_LAUNCH_CHECK();
     // contrastive loss                                                   (VSEFCModel.py:167-207)
     RUN(gemm_nt(w.img_emb, J, w.cap_emb, J, w.S, B, B, B, J, nullptr, false, false, st));
     const int sel_s = io->only_one_retrieval != 1, sel_im = io->only_one_retrieval != 2;
     hipLaunchKernelGGL(contrastive_fwd_kernel, dim3(B), dim3(64), 0, st, w.S, B, d.margin, d.max_violation, sel_s, sel_im,
-                       io->loss_rows, w.arg_s, w.arg_im);
-    CIC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(contrastive_sum_kernel, dim3(1), dim3(64), 0, st, io->loss_rows, B, io->loss_sum);
+                       io->loss_rows, w.arg_s, w.arg_im, w.sync + 2 * (size_t)cic_cdiv(B, 16) * (Lp + 1) + 1, io->loss_sum);
     CIC_LAUNCH_CHECK();
     if (io->img_emb_out) CIC_HIP(hipMemcpyAsync(io->img_emb_out, w.img_emb, sizeof(float) * B * J, hipMemcpyDeviceToDevice, st));
     if (io->cap_emb_out) CIC_HIP(hipMemcpyAsync(io->cap_emb_out, w.cap_emb, sizeof(float) * B * J, hipMemcpyDeviceToDevice, st));
@@ -1025,17 +1073,13 @@ static int listener_bwd_impl(const cic_listener_dims* dp, const cic_listener_par
     // S = im cap^T  ->  d_im = dS cap,  d_cap = dS^T im
     RUN(gemm_nn(w.dS, B, w.cap_emb, J, w.d_img, J, B, J, B, false, st));
     RUN(gemm_tn(w.dS, B, w.img_emb, J, w.d_cap, J, B, J, B, false, st));
-    // image branch
-    if (g) {
-        hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(B), dim3(256), 0, st, w.img_lin, w.nrm_img, w.d_img, w.d_lin, J,
-                           d.use_abs, !d.no_imgnorm);
-        CIC_LAUNCH_CHECK();
-        RUN(gemm_tn(w.d_lin, J, io->fc_feats, d.F, g->img_fc_w, d.F, J, d.F, B, true, st, g->img_fc_b));
-    }
-    // text branch: l2norm then GRU BPTT
-    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(B), dim3(256), 0, st, d.pool ? w.pooled : w.h_all + (size_t)Lp * B * J,
-                       w.nrm_cap, w.d_cap, d.pool ? w.d_pool : w.dh, J, d.use_abs, 1);
+    // back through both l2norms in ONE launch (image rows only when parameter gradients are wanted), then the image branch's
+    // weight gradient; text branch: GRU BPTT
+    hipLaunchKernelGGL(l2norm_bwd2_kernel, dim3(g ? 2 * B : B), dim3(256), 0, st, w.img_lin, w.nrm_img, w.d_img, w.d_lin,
+                       !d.no_imgnorm, d.pool ? w.pooled : w.h_all + (size_t)Lp * B * J, w.nrm_cap, w.d_cap,
+                       d.pool ? w.d_pool : w.dh, 1, B, J, d.use_abs);
     CIC_LAUNCH_CHECK();
+    if (g) RUN(gemm_tn(w.d_lin, J, io->fc_feats, d.F, g->img_fc_w, d.F, J, d.F, B, true, st, g->img_fc_b));
     if (d.pool) CIC_HIP(hipMemsetAsync(w.dh, 0, sizeof(float) * B * J, st));   // nothing reaches the final state directly
     float* dh = w.dh;
     float* dh2 = w.dh2;

@@ -4,6 +4,12 @@
 
 namespace {
 
+struct LossTerms {
+    const float* term[CIC_LOSS_MAX_TERMS];
+    float weight[CIC_LOSS_MAX_TERMS];
+    int count;
+};
+
 // loss = sum_{b, t<L} slp[b,t] * coef[b] * m[b,t] / sum m,   m[b,0] = 1, m[b,t] = seq[b,t-1] > 0
 //   (gen_masks[:, 1:] of models/AlternatingJointModel.py:353-355; :292-297,:321-325,:421-428)
 // dslp (+)= weight * coef[b] * m[b,t] / sum m
@@ -11,7 +17,10 @@ __global__ __launch_bounds__(1024) void seq_loss_kernel(const float* __restrict_
                                                         const int32_t* __restrict__ Lp, const float* __restrict__ coef,
                                                         float coef_sign, float weight, int B, int T,
                                                         float* __restrict__ loss_out, float* __restrict__ dslp,
-                                                        int accumulate) {
+                                                        int accumulate, LossTerms lt, float w_self,
+                                                        float* __restrict__ total) {
+    // total (optional): the step's loss sum_i lt.weight[i] * lt.term[i][0] + w_self * (this term), added in that order - what
+    // loss_combine_kernel computes when this term is the last one (AlternatingJointModel.py:470-503), without its launch
     // one workgroup of 16 waves: at B x T = 2048 every thread owns two elements and the kernel is two round trips (loads,
     // stores) around one barrier - with 256 threads it was eight dependent trips
     constexpr int NT = 1024;
@@ -34,6 +43,11 @@ __global__ __launch_bounds__(1024) void seq_loss_kernel(const float* __restrict_
 #pragma unroll
     for (int w = 0; w < NT / 64; ++w) { num += sh[0][w]; den += sh[1][w]; }
     if (threadIdx.x == 0 && loss_out) *loss_out = num / den;
+    if (threadIdx.x == 0 && total) {
+        float t = 0.f;
+        for (int i = 0; i < lt.count; ++i) t += lt.weight[i] * lt.term[i][0];
+        *total = t + w_self * (num / den);
+    }
     if (dslp) {
         const float k = weight / den;
         for (int i = threadIdx.x; i < B * T; i += NT) {
@@ -124,11 +138,6 @@ __global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, 
     }
 }
 
-struct LossTerms {
-    const float* term[CIC_LOSS_MAX_TERMS];
-    float weight[CIC_LOSS_MAX_TERMS];
-    int count;
-};
 __global__ void loss_combine_kernel(LossTerms lt, float* __restrict__ total) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         float t = 0.f;
@@ -155,9 +164,25 @@ extern "C" int cic_loss_combine(const float* const* term, const float* weight, i
 
 extern "C" int cic_seq_loss(const float* slp, const int32_t* seq, const int32_t* L, const float* coef, float coef_sign,
                             float weight, int B, int T, float* loss_out, float* dslp, int accumulate, cic_stream_t s) {
+    return cic_seq_loss_total(slp, seq, L, coef, coef_sign, weight, B, T, loss_out, dslp, accumulate, nullptr, nullptr, 0, 0.f,
+                              nullptr, s);
+}
+
+extern "C" int cic_seq_loss_total(const float* slp, const int32_t* seq, const int32_t* L, const float* coef, float coef_sign,
+                                  float weight, int B, int T, float* loss_out, float* dslp, int accumulate,
+                                  const float* const* term, const float* term_weight, int count, float self_weight,
+                                  float* total, cic_stream_t s) {
     CIC_REQUIRE(slp && seq && L && coef && B > 0 && T > 0);
+    CIC_REQUIRE(count >= 0 && count < CIC_LOSS_MAX_TERMS && (count == 0 || (term && term_weight)));
+    LossTerms lt = {};
+    lt.count = total ? count : 0;
+    for (int i = 0; i < lt.count; ++i) {
+        CIC_REQUIRE(term[i]);
+        lt.term[i] = term[i];
+        lt.weight[i] = term_weight[i];
+    }
     hipLaunchKernelGGL(seq_loss_kernel, dim3(1), dim3(1024), 0, cic_s(s), slp, seq, L, coef, coef_sign, weight, B, T,
-                       loss_out, dslp, accumulate);
+                       loss_out, dslp, accumulate, lt, self_weight, total);
     CIC_LAUNCH_CHECK();
     return 0;
 }

@@ -37,10 +37,12 @@ struct DecodeInit {
     int32_t* it;               // [B]
     const int64_t* first_token;   // [B] or null
     float* bias_ih;            // [5H]
+    float* x0;                 // [B,E] or null: (r4) the input of core step 0, x = dropout(relu(E[first token])) (AttModel.py:74-76,
+    const uint8_t* keep0;      //       399; embed_fwd_kernel's arithmetic) - one launch less at the head of every decode
 };
 __global__ __launch_bounds__(256) void decode_init_kernel(DecodeInit a, DecodeInit b, const float* __restrict__ i2h_b,
                                                           const float* __restrict__ h2h_b, int BH4, int B, int T1, int H5,
-                                                          int bos) {
+                                                          int bos, const float* __restrict__ Emb, int Ed, float scale, int plain) {
     const DecodeInit d = blockIdx.y ? b : a;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -54,6 +56,21 @@ __global__ __launch_bounds__(256) void decode_init_kernel(DecodeInit a, DecodeIn
         d.it[i] = d.first_token ? (int32_t)d.first_token[i] : bos;
     }
     if (i < H5) d.bias_ih[i] = i2h_b[i] + h2h_b[i];
+    const int E4 = Ed >> 2;
+    if (d.x0 && i < B * E4) {
+        const int r = i / E4, j = i % E4;
+        const int tok = d.first_token ? (int32_t)d.first_token[r] : bos;
+        f32x4 v = reinterpret_cast<const f32x4*>(Emb + (size_t)tok * Ed)[j];
+        uint32_t kp = 0x01010101u;
+        if (d.keep0) kp = *reinterpret_cast<const uint32_t*>(d.keep0 + (size_t)i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float kf = (float)((kp >> (8 * e)) & 0xffu);
+            const float q = plain ? v[e] : fmaxf(v[e], 0.f);
+            v[e] = d.keep0 ? q * (kf * scale) : q;
+        }
+        reinterpret_cast<f32x4*>(d.x0)[i] = v;
+    }
 }
 
 }  // namespace
@@ -197,6 +214,9 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         CIC_REQUIRE(ws_bytes[q] >= w[q].bytes);
         CIC_REQUIRE((fc || io[q]->att_pre) && io[q]->seq && io[q]->slp && io[q]->L && !(fc && psq));
     }
+    // teacher forcing without scheduled sampling embeds all its steps in one launch of its own (below)
+    const bool init_embeds = !(nb == 1 && !fc && ios[0]->mode == CIC_SAMPLE_TEACHER && ios[0]->pick &&
+                               !(ios[0]->ss_u && ios[0]->ss_prob > 0.f));
     {
         DecodeInit di[2] = {};
         for (int q = 0; q < nb; ++q) {
@@ -205,13 +225,18 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
             di[q].c = fc ? nullptr : w[q].c_all;
             di[q].any_unf = w[q].any_unf; di[q].unfinished = w[q].unfinished; di[q].it = w[q].it_all;
             di[q].first_token = io[q]->first_token; di[q].bias_ih = w[q].bias_ih;
+            if (init_embeds) {
+                di[q].x0 = w[q].x_all;
+                di[q].keep0 = fc ? nullptr : io[q]->x_keep;     // (row 0 of the [T+1,B,E] masks; the fc speaker embeds plain rows)
+            }
         }
         const int BH4 = B * H / 4;
         int span = BH4 > 5 * H ? BH4 : 5 * H;
         if (span < T + 1) span = T + 1;
         if (span < B) span = B;
+        if (init_embeds && span < B * E / 4) span = B * E / 4;
         hipLaunchKernelGGL(decode_init_kernel, dim3(cic_cdiv(span, 256), nb), dim3(256), 0, st, di[0], di[1], p->i2h_b, p->h2h_b,
-                           BH4, B, T + 1, 5 * H, d.V + 1);
+                           BH4, B, T + 1, 5 * H, d.V + 1, p->embed_w, E, 1.0f / (1.0f - p_drop), fc ? 1 : 0);
         CIC_LAUNCH_CHECK();
     }
     // a pair over the same embedded regions, no ragged masks: both dropouts in one launch
@@ -297,6 +322,8 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     if (presplit_logit) RUN(cic_split_bf16x3(p->logit_w, (int64_t)V1 * H, w[0].logit_parts, s));
     bool early_stop = g_early_stop && !fc && !ps && !teacher_batched;
     for (int q = 0; q < nb; ++q) early_stop = early_stop && !io[q]->first_token;
+    bool len_in_sampler = !ps && !teacher_batched && !teacher_seq;
+    for (int q = 0; q < nb; ++q) len_in_sampler = len_in_sampler && !io[q]->first_token;
     for (int t = 0; t < T && !teacher_seq; ++t) {
         const Dual<float> x = SLAB(x_all, B * E), att_h = SLAB(att_h_all, B * A), att_res = SLAB(att_res_all, B * H),
                           pre = SLAB(pre_all, B * 5 * H), out = SLAB(out_all, B * H), logp = SLAB(logp_all, B * V1);
@@ -323,7 +350,7 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
             float* xp = io[0]->xpre + (size_t)t * B * E;
             RUN(gemm_nn_fwd(io[0]->soft_raw + (size_t)(t - 1) * B * V1, V1, p->embed_w, E, xp, E, B, E, V1, false, st));
             RUN(cic_relu_keep_fwd(xp, xk.a, xk.a ? p_drop : 0.f, x.a, (int64_t)B * E, st));
-        } else if (t == 0 || ps) {
+        } else if ((t == 0 && !init_embeds) || (ps && t > 0)) {
             // xt = embed(it)                                               (:399); for t >= 1 the sampler launch of the
             // previous step wrote x[t] (fused embedding)
             RUN(cic_embed_fwd2(p->embed_w,
@@ -462,9 +489,12 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         if (ps) {
             CIC_TIMED(io[0]->timer, CIC_TIMED_SAMPLER, st, rc = cic_logsoftmax_sample2(&sa[0], nb == 2 ? &sa[1] : nullptr, st));
         } else {
+            // the last sampler launch of decodes that choose their own tokens also writes their lengths L
+            const bool last = t == T - 1 && len_in_sampler;
             CIC_TIMED(io[0]->timer, CIC_TIMED_SAMPLER, st,
                      rc = cic_sample_finish2(&sa[0], w[0].part, B, w[0].lse_all + (size_t)t * B, nb == 2 ? &sa[1] : nullptr,
-                                             w[1].part, B, nb == 2 ? w[1].lse_all + (size_t)t * B : nullptr, np, st));
+                                             w[1].part, B, nb == 2 ? w[1].lse_all + (size_t)t * B : nullptr, np, st,
+                                             last ? io[0]->L : nullptr, last && nb == 2 ? io[1]->L : nullptr, T));
         }
         if (rc) return rc;
     }
@@ -479,7 +509,9 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         RUN(cic_logit_partials(w[0].logp_all, R, V1, V1, &e, np, s));
         RUN(cic_teacher_finish_all(w[0].part, np, R, w[0].logp_all, V1, io[0]->pick, w[0].lse_all, io[0]->slp, T, B, st));
     }
-    if (nb == 2 && !io[0]->first_token && !io[1]->first_token) {
+    if (len_in_sampler) {
+        // (written by the last sampler launch)
+    } else if (nb == 2 && !io[0]->first_token && !io[1]->first_token) {
         RUN(cic_finalize_len2(Dual<const int>{w[0].any_unf, w[1].any_unf}, T, Dual<int>{io[0]->L, io[1]->L}, 2, st));
     } else {
         for (int q = 0; q < nb; ++q) {

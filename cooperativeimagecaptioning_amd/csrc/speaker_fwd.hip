@@ -1239,7 +1239,33 @@ struct FinishArgs {
     int part_rows;
     float* lse;            // [B]
 };
-__global__ __launch_bounds__(256) void sample_finish_kernel(FinishArgs a0, FinishArgs a1, int np) {
+// The decode's length with the LAST sampler launch (r4; was a launch of its own): every workgroup counts itself in after its
+// rows' bookkeeping (any_unfinished[step] is OR-ed with device-scope atomics); the one whose add comes last reads the flags of
+// all steps (atomic = sc1 loads) and writes L as finalize_len_kernel does.  The counter is any_unfinished[0] of the first
+// decode: cleared by decode_init_kernel, read by nobody else.
+struct FinishLen {
+    int32_t* counter;              // null: not the last step
+    Dual<const int32_t> any_unf;   // [T+1] per decode (b null for a single decode)
+    Dual<int32_t> L;
+    int T;
+};
+__device__ __forceinline__ void finish_len_tail(const FinishLen& fl) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's bookkeeping atomics have left
+    __syncthreads();
+    __shared__ unsigned ticket_s;
+    if (threadIdx.x == 0)
+        ticket_s = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(fl.counter), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (ticket_s != gridDim.x - 1u || threadIdx.x >= 2) return;
+    const bool second = threadIdx.x == 1;
+    const int32_t* any_unf = fl.any_unf.sel(second);
+    if (!any_unf) return;
+    int l = fl.T;
+    for (int t = 1; t <= fl.T; ++t)
+        if (__hip_atomic_load(any_unf + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) { l = t - 1; break; }
+    *fl.L.sel(second) = l;
+}
+__device__ __forceinline__ void sample_finish_rows(const FinishArgs& a0, const FinishArgs& a1, int np) {
     const int lane = threadIdx.x & 63;
     const int rg = blockIdx.x * 4 + (threadIdx.x >> 6);
     const bool second = rg >= a0.s.B;
@@ -1276,6 +1302,10 @@ __global__ __launch_bounds__(256) void sample_finish_kernel(FinishArgs a0, Finis
         }
     }
     if (lane == 0) row_bookkeeping(a, c, b);      // EOS bookkeeping (AttModel.py:401-434)
+}
+__global__ __launch_bounds__(256) void sample_finish_kernel(FinishArgs a0, FinishArgs a1, int np, FinishLen fl) {
+    sample_finish_rows(a0, a1, np);
+    if (fl.counter) finish_len_tail(fl);      // (grid-uniform)
 }
 
 // ---- teacher forcing without scheduled sampling: the fed tokens are the targets, known before the loop ------------------
@@ -1629,7 +1659,9 @@ int cic_teacher_finish_all(const float* part, int np, int part_rows, const float
 
 // the sampler of one decode (b == NULL) or of a pair on the row partials of this step's logits
 int cic_sample_finish2(const cic_sampler_args* a, const float* part_a, int part_rows_a, float* lse_a,
-                       const cic_sampler_args* b, const float* part_b, int part_rows_b, float* lse_b, int np, hipStream_t st) {
+                       const cic_sampler_args* b, const float* part_b, int part_rows_b, float* lse_b, int np, hipStream_t st,
+                       int32_t* L_a, int32_t* L_b, int T) {
+    // L_a (and L_b for a pair): this is the decode's LAST sampler launch; it also writes the decodes' lengths
     if (int rc = check_sampler_args(a, true)) return rc;
     if (b) { if (int rc = check_sampler_args(b, true)) return rc; }
     CIC_REQUIRE(part_a && np > 0 && (!b || part_b));
@@ -1640,7 +1672,15 @@ int cic_sample_finish2(const cic_sampler_args* a, const float* part_a, int part_
     FinishArgs fa{*a, part_a, part_rows_a, lse_a};
     FinishArgs fb = b ? FinishArgs{*b, part_b, part_rows_b, lse_b} : fa;
     const int rows = a->B + (b ? b->B : 0);
-    hipLaunchKernelGGL(sample_finish_kernel, dim3(cic_cdiv(rows, 4)), dim3(256), 0, st, fa, fb, np);
+    FinishLen fl = {};
+    if (L_a) {
+        CIC_REQUIRE(T > 0 && a->step == T && (!b || L_b));
+        fl.counter = a->any_unfinished;                      // entry 0: no step's flag
+        fl.any_unf = Dual<const int32_t>{a->any_unfinished, b ? b->any_unfinished : nullptr};
+        fl.L = Dual<int32_t>{L_a, b ? L_b : nullptr};
+        fl.T = T;
+    }
+    hipLaunchKernelGGL(sample_finish_kernel, dim3(cic_cdiv(rows, 4)), dim3(256), 0, st, fa, fb, np, fl);
     CIC_LAUNCH_CHECK();
     return 0;
 }

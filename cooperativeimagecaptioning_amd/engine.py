@@ -40,6 +40,9 @@ lib.cic_ciderd_reward.argtypes = [C.POINTER(CiderdArgs), P, C.c_size_t, P]
 lib.cic_ciderd_reward.restype = C.c_int
 lib.cic_seq_loss.argtypes = [P, P, P, P, C.c_float, C.c_float, C.c_int, C.c_int, P, P, C.c_int, P]
 lib.cic_seq_loss.restype = C.c_int
+lib.cic_seq_loss_total.argtypes = [P, P, P, P, C.c_float, C.c_float, C.c_int, C.c_int, P, P, C.c_int,
+                                   C.POINTER(C.c_void_p), C.POINTER(C.c_float), C.c_int, C.c_float, P, P]
+lib.cic_seq_loss_total.restype = C.c_int
 lib.cic_loss_combine.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_float), C.c_int, P, P]
 lib.cic_loss_combine.restype = C.c_int
 lib.cic_masked_nll.argtypes = [P, P, C.c_int, C.c_float, C.c_int, C.c_int, P, P, P]
@@ -274,8 +277,9 @@ def pack_refs(gts, device):
     off = np.zeros(len(gts) + 1, np.int32)
     off[1:] = np.cumsum([len(g) for g in gts])
     refs = np.concatenate([np.asarray(g) for g in gts], 0).astype(np.int32)
-    return (torch.from_numpy(np.ascontiguousarray(refs)).to(device),
-            torch.from_numpy(off).to(device))
+    ref_off = torch.from_numpy(off).to(device)
+    ref_off.max_refs = int(max(len(g) for g in gts))      # known here, on the host: saves the reward a fallback launch
+    return torch.from_numpy(np.ascontiguousarray(refs)).to(device), ref_off
 
 
 CIDERD_MAX_VOCAB = 32766      # n-gram keys pack 15 bits per token (ids 0 .. V+1)
@@ -303,6 +307,7 @@ def ciderd_reward(gen, L_gen, greedy, L_greedy, refs, ref_off, spi=None, debug=F
     a.refs, a.ref_off = _p(refs), _p(ref_off)
     a.scores, a.reward, a.stats = _p(out['scores']), _p(out['reward']), _p(out['stats'])
     a.vocab_size = int(vocab_size)
+    a.max_refs_per_image = int(getattr(ref_off, 'max_refs', 0))
     if debug:
         S = 2 * B + R
         out['dbg_keys'] = torch.zeros(S, 64, dtype=torch.int64, device=dev)
@@ -315,13 +320,29 @@ def ciderd_reward(gen, L_gen, greedy, L_greedy, refs, ref_off, spi=None, debug=F
     return out
 
 
-def seq_loss(slp, seq, L, coef, coef_sign, weight, dslp=None, accumulate=False, loss_out=None):
+def seq_loss(slp, seq, L, coef, coef_sign, weight, dslp=None, accumulate=False, loss_out=None, combine=None):
+    """combine = (weighted_terms, self_weight): this term is the LAST of the step's loss sum; the kernel then also writes
+    sum_i w_i * term_i + self_weight * (this term) - what loss_combine would, without its launch - and the call returns
+    (loss_out, total) with total a 0-dim tensor."""
     B, T = slp.shape
     if loss_out is None:
         loss_out = torch.empty(1, device=slp.device)
-    check(lib.cic_seq_loss(_p(slp), _p(seq), _p(L), _p(coef), float(coef_sign), float(weight), B, T, _p(loss_out),
-                           _p(dslp), int(accumulate), stream()), 'cic_seq_loss')
-    return loss_out
+    if combine is None:
+        check(lib.cic_seq_loss(_p(slp), _p(seq), _p(L), _p(coef), float(coef_sign), float(weight), B, T, _p(loss_out),
+                               _p(dslp), int(accumulate), stream()), 'cic_seq_loss')
+        return loss_out
+    prior, w_self = combine
+    k = len(prior)
+    assert all(t.dtype == torch.float32 and t.is_cuda for _, t in prior)
+    ptrs = (C.c_void_p * max(k, 1))(*[_p(t) for _, t in prior])
+    ws = (C.c_float * max(k, 1))(*[float(w) for w, _ in prior])
+    total = torch.empty(1, device=slp.device)
+    check(lib.cic_seq_loss_total(_p(slp), _p(seq), _p(L), _p(coef), float(coef_sign), float(weight), B, T, _p(loss_out),
+                                 _p(dslp), int(accumulate), ptrs, ws, k, float(w_self), _p(total), stream()),
+          'cic_seq_loss_total')
+    out = total[0]
+    out._cic_fresh = True
+    return loss_out, out
 
 
 def loss_combine(weighted_terms):

@@ -176,6 +176,7 @@ class AlternatingJointModel(nn.Module):
         sample = None
         greedy = None
         dslp = None
+        fused_total = None
         need_greedy = bool(ciw) or (dw > 0 and rr == 'reinforce' and self.reinforce_baseline_type == 'greedy')
 
         def sampled_with_greedy(**spec):
@@ -244,7 +245,9 @@ class AlternatingJointModel(nn.Module):
             fresh = dslp is None
             if fresh:
                 dslp = cg._buf.get('dslp', (B, T), torch.float32, dev)
-            lc = engine.seq_loss(sample.slp, sample.seq, sample.L, coef, -1.0, ciw, dslp=dslp, accumulate=not fresh)
+            # the CIDEr term is the last of the step's sum: its kernel writes the step's loss as well (no loss_combine launch)
+            lc, fused_total = engine.seq_loss(sample.slp, sample.seq, sample.L, coef, -1.0, ciw, dslp=dslp,
+                                              accumulate=not fresh, combine=(list(terms), ciw))
             terms.append((ciw, lc))
             # mean of coef from the reward kernel's own sums (stats = mean sampled score, mean greedy score): no launch here
             st = rw['stats']
@@ -264,7 +267,8 @@ class AlternatingJointModel(nn.Module):
 
         if not terms:
             return self._zero_loss(dev)
-        loss = engine.loss_combine(terms)          # sum_i weight_i * term_i, one launch
+        # sum_i weight_i * term_i: by the last term's own kernel when that is the CIDEr term, else one launch
+        loss = fused_total if fused_total is not None else engine.loss_combine(terms)
         anchor = next((p for p in self.parameters() if p.requires_grad), None)
         if anchor is None or not torch.is_grad_enabled() or not bwd_steps:
             return loss.detach()

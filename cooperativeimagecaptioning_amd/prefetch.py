@@ -87,8 +87,10 @@ class PrefetchLoader:
                 off = np.zeros(len(gts) + 1, np.int32)
                 off[1:] = np.cumsum([len(g) for g in gts])
                 refs = np.ascontiguousarray(np.concatenate([np.asarray(g) for g in gts], 0).astype(np.int32))
+                ref_off = self._pinned('ref_off', torch.from_numpy(off)).to(self.device, non_blocking=True)
+                ref_off.max_refs = int(max(len(g) for g in gts))     # as engine.pack_refs: lets the reward skip a fallback launch
                 out['_cic_refs'] = (gts, self._pinned('refs', torch.from_numpy(refs)).to(self.device, non_blocking=True),
-                                    self._pinned('ref_off', torch.from_numpy(off)).to(self.device, non_blocking=True))   # see AlternatingJointModel._refs
+                                    ref_off)   # see AlternatingJointModel._refs
             ev = torch.cuda.Event()
             ev.record(self._stream)
         self._uploads = (self._uploads + [ev])[-2:]

@@ -515,6 +515,14 @@ int cic_retrieval_ranks(const float* ims, const float* caps, int n_images, int c
  * :292-297,:321-325).  dslp (+)= weight * d loss / d slp.  loss_out / dslp may be NULL. */
 int cic_seq_loss(const float* slp, const int32_t* seq, const int32_t* L, const float* coef, float coef_sign,
                  float weight, int B, int T, float* loss_out, float* dslp, int accumulate, cic_stream_t s);
+/* cic_seq_loss that also writes the STEP's loss when its term is the last one of the sum (AlternatingJointModel.py:470-503):
+ * total[0] = sum_{i < count} term_weight[i] * term[i][0] + self_weight * (this term), added in that order - cic_loss_combine
+ * over (term..., this term) without a launch of its own.  term / term_weight are host arrays of `count` < CIC_LOSS_MAX_TERMS
+ * entries (device scalars / floats); total == NULL: cic_seq_loss. */
+int cic_seq_loss_total(const float* slp, const int32_t* seq, const int32_t* L, const float* coef, float coef_sign,
+                       float weight, int B, int T, float* loss_out, float* dslp, int accumulate,
+                       const float* const* term, const float* term_weight, int count, float self_weight, float* total,
+                       cic_stream_t s);
 /* LanguageModelCriterion, misc/utils.py:49-58: loss = -sum slp*mask / sum mask (slp = log p(target));
  * dslp = weight * d loss / d slp. */
 int cic_masked_nll(const float* slp, const float* mask, int mask_ld, float weight, int B, int T,
@@ -564,6 +572,8 @@ typedef struct {
      * the call is refused unless 1 <= V <= 32766; a token outside [0, V+1] met on the device turns every score into
      * NaN (the reference's string n-grams have no such limit: refusing beats aliasing two words silently). */
     int vocab_size;
+    int max_refs_per_image;   /* the largest reference count of an image if the caller knows it (it packed ref_off), else 0.  Up to 16
+                                 the document frequencies are counted inside the n-gram launch; 0 or more: one more launch */
 } cic_ciderd_args;
 size_t cic_ciderd_ws_bytes(int B, int R);
 int cic_ciderd_reward(const cic_ciderd_args* a, void* ws, size_t ws_bytes, cic_stream_t s);
