@@ -1257,6 +1257,8 @@ __device__ __forceinline__ void finish_len_tail(const FinishLen& fl) {
         ticket_s = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(fl.counter), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (ticket_s != gridDim.x - 1u || threadIdx.x >= 2) return;
+    // everyone has arrived: the counter goes back to 0 (the workspace then reads the same whether a decode ran alone or paired)
+    if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned*>(fl.counter), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool second = threadIdx.x == 1;
     const int32_t* any_unf = fl.any_unf.sel(second);
     if (!any_unf) return;
