@@ -1294,8 +1294,9 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         RUN(cic_colsum_f32(g.dpre_img, B, 5 * H, 5 * H, gr->h2h_b, 1, s));
     }
     // token embedding: dx = dpre i2h.W, scattered into the embedding rows
-    if (!ps) RUN(gemm_nn(g.dpre_all, 5 * H, p->i2h_w, E, g.dx_all, E, T * B, E, 5 * H, false, st, true, seq_kernel && E == H));
-    {
+    // (grads->embed_w == NULL: the table is frozen - share_embed = 1 in phase 2, AlternatingJointModel.py:86-88 - and takes no gradient)
+    if (!ps && gr->embed_w) RUN(gemm_nn(g.dpre_all, 5 * H, p->i2h_w, E, g.dx_all, E, T * B, E, 5 * H, false, st, true, seq_kernel && E == H));
+    if (gr->embed_w) {
         // partial sampling: only step 0 reads an embedding row (<bos>); steps >= 1 used soft_raw[t-1] @ embed
         const int rows = ps ? B : T * B;
         const int64_t n = (int64_t)rows * E;

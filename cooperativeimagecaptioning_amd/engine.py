@@ -79,7 +79,7 @@ def speaker_params(tensors):
     sp = SpeakerParams()
     for field, key in SPEAKER_PARAM_FIELDS:
         t = tensors[key]
-        assert t.dtype == torch.float32
+        assert t is None or t.dtype == torch.float32
         setattr(sp, field, _p(t))
     return sp
 

@@ -29,7 +29,7 @@ class AlternatingJointModel(nn.Module):
             self.vse = setup(opt, opt.vse_model, 'vse_model')
             self.share_embed = opt.share_embed
             if self.share_embed:
-                raise NotImplementedError('share_embed=1 is not supported on the MI355X path (scripts use 0)')
+                self.tie_embeddings()                                   # :83-88
         else:
             self.vse = None
             self.share_embed = 0
@@ -86,6 +86,27 @@ class AlternatingJointModel(nn.Module):
                 print("Make sure the vse opt are the same !!!!!")
                 sd = torch.load(opt.initialize_retrieval, map_location='cpu', weights_only=True)
                 utils.load_state_dict(self, {k: v for k, v in sd.items() if 'vse.' in k})
+
+    def tie_embeddings(self):
+        """share_embed = 1 (:83-88; train.py:390-391 repeats it after the move to the GPU): the listener's embedding module
+        becomes the speaker's token embedding - ONE Parameter, reachable under both state-dict names, owned by both Adam
+        instances.  MI355X layout: the table lives in the LISTENER's flat buffers; the speaker's FlatAgent lists it as external
+        (flat.FlatAgent), its engines read it and add their gradient into the listener's gradient segment, and the speaker's
+        FlatAdam steps it with moments of its own (optimizer.FlatAdam)."""
+        cg = self.caption_generator
+        if not isinstance(getattr(cg, 'embed', None), nn.Sequential):
+            raise NotImplementedError("share_embed = 1 needs the att2in2 speaker: the reference assigns caption_generator.embed[0] "
+                                      "(AlternatingJointModel.py:85), which FCModel's bare nn.Embedding does not support")
+        if cg.embed[0] is not self.vse.txt_enc.embed:
+            if tuple(cg.embed[0].weight.shape) != tuple(self.vse.txt_enc.embed.weight.shape):
+                raise ValueError('share_embed = 1 needs input_encoding_size to be the same for both agents')
+            cg.embed[0] = self.vse.txt_enc.embed
+            cg._flat = None                                             # (a layout made before the tie is stale)
+        cg._external = ('embed.0.weight',)
+        cg._external_owner = self.vse
+        if getattr(self.opt, 'phase', None) == 2:                        # second phase (MLE) only: the table is frozen
+            for p in cg.embed.parameters():
+                p.requires_grad = False
 
     # ---- flags (:180-194) ---------------------------------------------------------------------
     def getLossFlags(self):

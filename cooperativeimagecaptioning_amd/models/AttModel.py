@@ -106,9 +106,12 @@ class AttModel(nn.Module):
 
     # ---- engine plumbing -----------------------------------------------------------------
     def flat(self):
+        owner = getattr(self, '_external_owner', None)
+        owner_flat = owner.flat() if owner is not None else None   # share_embed: the shared table's storage and gradient view are the listener's
         if self._flat is None:
             # the logit layer last: a contiguous early bucket of the data-parallel gradient exchange (flat.py)
-            self._flat = FlatAgent(self, tail=('logit.weight', 'logit.bias'))
+            self._flat = FlatAgent(self, tail=('logit.weight', 'logit.bias'), external=getattr(self, '_external', ()))
+        self._flat.ext_owner_flat = owner_flat
         self._flat.ensure()
         return self._flat
 

@@ -139,8 +139,15 @@ class VSEFCModel(nn.Module):
             g_scalar = self._buf.stage('g_scalar', g_scalar.reshape(1), torch.float32)
         if g_rows is not None:
             g_rows = self._buf.stage('g_rows', g_rows.contiguous(), torch.float32)
+        grads = None
+        if param_grads:
+            # a frozen parameter takes no gradient (share_embed = 1: the shared table in a reinforce listener turn,
+            # AlternatingJointModel.py:592-645 - the engine skips a missing pointer)
+            grads = fl.grad_tensors()
+            if not self.txt_enc.embed.weight.requires_grad:
+                grads = {k: v for k, v in grads.items() if k != 'txt_enc.embed.weight'}
         engine.listener_bwd(res.dims, res.params, res.fwd, g_rows=g_rows, g_scalar=g_scalar,
-                            grads=fl.grad_tensors() if param_grads else None, d_onehot=d_onehot, g_scale=g_scale)
+                            grads=grads, d_onehot=d_onehot, g_scale=g_scale)
 
     def forward(self, fc_feats, att_feats, seq, masks, whole_batch=False, only_one_retrieval='off'):
         """models/VSEFCModel.py:230-241."""

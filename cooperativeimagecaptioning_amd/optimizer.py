@@ -45,6 +45,12 @@ class FlatAdam:
         # trainer and the benchmark never do; off by default, as torch.optim keeps .grad until zero_grad().
         self.zero_grad_in_step = False
         self._grad_is_zero = False
+        # share_embed = 1: parameters of this agent that live in another agent's flat buffers (flat.FlatAgent.external) - the one
+        # embedding table both Adam instances own (AlternatingJointModel.py:83-88, optimizer.py:25-27).  This optimizer keeps
+        # moments of its own for them and steps them with a launch of their own; the OWNER's optimizer steps them again with
+        # its moments, from the same gradient (optimizer.py:233-242: the clamp is idempotent).  name -> (exp_avg, exp_avg_sq)
+        self._ext_state = {}
+        self.ext_owner = None         # the owner's FlatAdam (set by load_optimizer): its exchange must have landed before our step
 
     @property
     def flat(self):
@@ -62,11 +68,18 @@ class FlatAdam:
             h.wait()
         self._pending.clear()
 
+    def _externals(self):
+        fl = self.flat
+        return [(n, p) for n, p, o in zip(fl.names, fl.params, fl.offsets) if o is None]
+
     def zero_grad(self, set_to_none=False):
         # an exchange still in flight belongs to a step that never reached step() (a skipped or failed update, an
         # extra backward): it must land before the buffer is cleared, and must not be mistaken for the next step's
         self._drain()
         self._done.clear()
+        for _, p in self._externals():          # torch's zero_grad() clears every parameter the optimizer holds
+            if p.grad is not None:
+                p.grad.zero_()
         # the last step() cleared the buffer inside its kernel and NOTHING has asked for it since (FlatAgent.grad_dirty: a
         # backward into this agent during another agent's turn sets it): only then is the fill skipped
         if self._grad_is_zero and self.flat.attached() and not self.flat.grad_dirty:
@@ -140,6 +153,18 @@ class FlatAdam:
         clip = self._grad_clip if self._grad_clip is not None else 3.0e38
         engine.clamp_adam(fl.flat, fl.grad, fl.exp_avg, fl.exp_avg_sq, g['lr'], fl.step, clip, g['betas'], g['eps'],
                           g['weight_decay'], scale, zero_grad=self.zero_grad_in_step)
+        for name, p in self._externals():
+            # torch's Adam skips a parameter without gradient (a frozen table: phase 2); the gradient is the owner's segment and
+            # stays as it is (the owner's own step still needs it, and clears it if it clears)
+            if not p.requires_grad or p.grad is None:
+                continue
+            if self.ext_owner is not None:
+                self.ext_owner.all_reduce_grads()          # data parallel: the owner's bucket carries this gradient
+            st = self._ext_state.get(name)
+            if st is None:
+                st = self._ext_state[name] = (torch.zeros(p.numel(), device=p.device), torch.zeros(p.numel(), device=p.device))
+            engine.clamp_adam(p.data.view(-1), p.grad.view(-1), st[0], st[1], g['lr'], fl.step, clip, g['betas'], g['eps'],
+                              g['weight_decay'], scale, zero_grad=False)
         self._grad_is_zero = bool(self.zero_grad_in_step)
         if self.zero_grad_in_step:
             fl.grad_dirty = False           # (a skipped update - status word set - leaves the run to raise; see status.py)
@@ -148,8 +173,14 @@ class FlatAdam:
     def state_dict(self):
         fl = self.flat
         state = {}
-        for i, (p, o) in enumerate(zip(fl.params, fl.offsets)):
+        for i, (name, p, o) in enumerate(zip(fl.names, fl.params, fl.offsets)):
             n = p.numel()
+            if o is None:                     # a shared table: this optimizer's own moments for it
+                st = self._ext_state.get(name)
+                if st is not None:
+                    state[i] = dict(step=torch.tensor(float(fl.step)), exp_avg=st[0].view(p.shape).clone(),
+                                    exp_avg_sq=st[1].view(p.shape).clone())
+                continue
             state[i] = dict(step=torch.tensor(float(fl.step)),
                             exp_avg=fl.exp_avg[o:o + n].view(p.shape).clone(),
                             exp_avg_sq=fl.exp_avg_sq[o:o + n].view(p.shape).clone())
@@ -160,11 +191,16 @@ class FlatAdam:
 
     def load_state_dict(self, sd):
         fl = self.flat
-        for i, (p, o) in enumerate(zip(fl.params, fl.offsets)):
+        for i, (name, p, o) in enumerate(zip(fl.names, fl.params, fl.offsets)):
             st = sd['state'].get(i)
             if st is None:
                 continue
             n = p.numel()
+            if o is None:
+                self._ext_state[name] = (st['exp_avg'].reshape(-1).to(p.device).float().clone(),
+                                         st['exp_avg_sq'].reshape(-1).to(p.device).float().clone())
+                fl.step = int(st['step'])
+                continue
             fl.exp_avg[o:o + n].copy_(st['exp_avg'].reshape(-1))
             fl.exp_avg_sq[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
             fl.step = int(st['step'])
@@ -225,6 +261,9 @@ def load_optimizer(model, opt):
                             o = load_state_dict(o, p2, curr_turn)
                     else:
                         print('\n Using new "listener" optimizer \n')
+                spk = optimizer_dict.get('speaker')
+                if getattr(opt, 'share_embed', 0) and isinstance(spk, FlatAdam):
+                    spk.ext_owner = o          # the shared table's gradient travels in the listener's bucket
                 if opt.retrieval_reward == 'reinforce':
                     optimizer_dict[curr_turn] = o
                 else:
@@ -291,9 +330,14 @@ def overlap_gradient_exchange(model, optimizer_dict):
                 lst = o
             if isinstance(o, FlatAdam) and o.module is getattr(model, 'caption_generator', None):
                 spk = o
+    shared = bool(getattr(model, 'share_embed', 0))
     if lst is not None:
-        lst._started_early = True
-    model.listener_grads_ready = (lambda: None if lst.defer_exchange else lst.begin_all_reduce()) if lst is not None else None
+        # share_embed = 1: the speaker's backward still adds into the listener's gradient segment (the shared table), so the
+        # listener's bucket leaves after the whole backward pass, and the speaker - whose step reads that segment before the
+        # listener's step may clear it - is updated first (the reference's order, optimizer.py:233-239)
+        lst._started_early = not shared
+    model.listener_grads_ready = (lambda: None if lst.defer_exchange else lst.begin_all_reduce()) \
+        if lst is not None and not shared else None
     # the speaker's logit bucket (final before the BPTT loop of its backward engine) leaves from inside backward() too
     if spk is not None and 'logit' in spk.buckets():
         model.speaker_logit_grads_ready = lambda: None if spk.defer_exchange else spk.begin_all_reduce('logit')
@@ -326,7 +370,8 @@ def update_optimizer(optimizer_dict, optimizer, opt):
                 for name in o.buckets():
                     if name not in o._pending and name not in o._done:
                         o.begin_all_reduce(name)
-        # the agent whose exchange started first (the listener's, from inside backward) is updated first
+        # the agent whose exchange started first (the listener's, from inside backward) is updated first - a stable sort: without
+        # an early start (single GPU, share_embed) the reference's order, speaker then listener, stands
         for o in sorted(agents, key=lambda o: 0 if getattr(o, '_started_early', False) else 1):
             utils.clip_gradient(o, opt.grad_clip)
             o.step()

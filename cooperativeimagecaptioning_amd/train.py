@@ -333,6 +333,8 @@ def train(opt, loader=None):
     opt.gumbel_temp = infos.get('gumbel_temp', opt.gumbel_temp)                # train.py:366, before the model reads it
     torch.manual_seed(opt.seed)                               # same initial weights on every rank
     model = models.AlternatingJointModel(opt).to(device).train()   # loads <start_from>/*.pth when asked to continue
+    if getattr(opt, 'share_embed', 0):                            # train.py:390-391: re-tie after the move to the device
+        model.tie_embeddings()
     cg = model.caption_generator
     cg.noise.manual_seed(opt.seed * 1000 + rank)
     if infos:                                                 # the schedule values and stream positions in force at the checkpoint

@@ -389,7 +389,7 @@ typedef struct {
     const float* d_onehot;   /* [T,B,V+1] gradient w.r.t. the ST one-hot rows / the soft rows io->soft_out (from
                                 cic_listener_bwd) or NULL */
     const float* dslp;       /* [B,T] gradient w.r.t. the sampled log-probs (io->slp) or NULL */
-    const cic_speaker_params* grads; /* accumulated into (+=) */
+    const cic_speaker_params* grads; /* accumulated into (+=); grads->embed_w may be NULL (a frozen embedding table) */
     const float* att_raw;    /* [B,K,D] the raw region features (for the att_embed weight gradient); NULL in fc_mode */
     float* d_x0;             /* fc_mode: out [B,E] gradient w.r.t. io->x0 (the caller back-propagates img_embed) */
     /* 0: the whole backward pass.  Data-parallel callers split it in two calls on the same arguments so that the

@@ -182,3 +182,34 @@ def clamp_adam_step(params, grads, state, lr, grad_clip=0.1, betas=(0.9, 0.999),
         step_size = lr / bc1
         denom = (st['exp_avg_sq'].sqrt() / np.sqrt(bc2)).add_(eps)
         p.addcdiv_(st['exp_avg'], denom, value=-step_size)
+
+
+def train_step(Ps, Pl, cfg, batch, noise, turn, state_s, state_l, lr, grad_clip=0.1):
+    """One iteration of the reference's trainer around joint_forward (train.py:487-531): zeroing_optimizer
+    (optimizer.py:224-230), the requires_grad effect of changeModelUpdateStatus in the reinforce turns
+    (AlternatingJointModel.py:508-555,571-685: the vse loop runs first, the caption model's last), forward, backward,
+    update_optimizer (optimizer.py:233-242: clamp, then Adam, for one or both agents).  With share_embed = 1
+    (AlternatingJointModel.py:83-88) the SAME tensor object sits in Ps['embed.0.weight'] and Pl['txt_enc.embed.weight']:
+    both paths accumulate into its one .grad, each optimizer that steps moves it with its own moments, and in a listener turn
+    it is frozen because the caption model's loop sets its flag last.  torch 0.4.1's zero_grad() zero-fills (a frozen
+    parameter then has a ZERO gradient, not None, and Adam still visits it).  Returns (loss, aux)."""
+    rr = cfg['retrieval_reward']
+    both = rr != 'reinforce'                                  # gumbel / multinomial*: the listener turn is removed, both step
+    agents = (('s', Ps, state_s), ('l', Pl, state_l))
+    stepping = [a for a in agents if both or (a[0] == 's') == (turn == 'speaker')]
+    for _, P, _ in stepping:                                  # zeroing_optimizer
+        for v in P.values():
+            v.grad = torch.zeros_like(v)
+    if rr == 'reinforce':                                     # forward :508-555
+        flags = {'speaker': (False, True), 'listener': (True, False)}[turn]
+        for v in Pl.values():
+            v.requires_grad_(flags[0])
+        for v in Ps.values():                                 # (a shared table takes the caption model's flag)
+            v.requires_grad_(flags[1])
+    loss, aux = joint_forward(Ps, Pl, cfg, batch, noise, turn, True)
+    if loss.requires_grad:
+        loss.backward()
+    with torch.no_grad():
+        for _, P, st in stepping:                             # update_optimizer: speaker first, then listener
+            clamp_adam_step(P, {k: v.grad for k, v in P.items()}, st, lr, grad_clip)
+    return loss, aux

@@ -296,3 +296,46 @@ def test_retrieval_ranks_match_reference(name):
     np.testing.assert_array_equal(ranks_i, z['t2i_ranks'])
     np.testing.assert_array_equal(top1_i, z['t2i_top1'])
     np.testing.assert_allclose(np.array(ri), z['t2i_r'])
+
+
+# ---- share_embed = 1: ONE embedding table owned by both agents and both Adam instances (AlternatingJointModel.py:83-88) --------
+import share_util as SU  # noqa: E402
+
+
+@pytest.mark.parametrize('name', SU.SHARE_CASES)
+def test_share_embed_trajectory_matches_reference(name):
+    """Several iterations of the reference's trainer (zeroing, forward, backward, clamp + Adam for the agents of the turn)
+    with the shared table: per iteration the loss, the decoded tokens, every gradient digest and the digest of EVERY weight
+    after the update - the table's included, which pins who moves it, with which moments, from which gradient."""
+    z, cfg, w0 = SU.load(name)
+    Ps = {k[len('caption_generator.'):]: T(v).clone().requires_grad_(True) for k, v in w0.items() if k.startswith('caption_generator.')}
+    Pl = {k[len('vse.'):]: T(v).clone().requires_grad_(True) for k, v in w0.items() if k.startswith('vse.')}
+    Pl['txt_enc.embed.weight'] = Ps['embed.0.weight']                 # the same tensor object: the shared table
+    st_s, st_l = {}, {}
+    for s in range(int(z['n_steps'])):
+        d = SU.step_view(z, s)
+        turn = d['turn']
+        noise = {k: {kk: T(vv) for kk, vv in v.items()} for k, v in SU.step_noise(d, cfg, turn).items()}
+        b = SU.step_batch(d)
+        batch = dict(fc_feats=T(b['fc_feats']), att_feats=T(b['att_feats']), att_masks=None, labels=T(b['labels']),
+                     masks=T(b['masks']), gts=b['gts'])
+        loss, aux = J.train_step(Ps, Pl, cfg, batch, noise, turn, st_s, st_l, cfg['learning_rate'], cfg['grad_clip'])
+        close(loss, d['loss'], rtol=1e-4)
+        np.testing.assert_array_equal(aux['gen_result'].numpy(), d['tokens0'])
+        assert bool(Ps['embed.0.weight'].requires_grad) == bool(int(d['embed_requires_grad']))
+        n = 0
+        for pre, P in (('caption_generator.', Ps), ('vse.', Pl)):
+            for k, p in P.items():
+                key = 'gdig.' + pre + k
+                # (the agent that does not step in a reinforce turn keeps the previous turn's gradients, clamped in place by
+                # clip_gradient: stale values nobody reads)
+                frozen = cfg['retrieval_reward'] == 'reinforce' and (pre == 'vse.') == (turn == 'speaker')
+                if key in d and float(np.abs(d[key][1])) > 0 and not frozen:
+                    check_digest(p.grad, d[key], f'step {s} {key}', rtol=5e-4)
+                    n += 1
+                if k.endswith('alpha_net.bias'):     # a softmax shift: its gradient is rounding noise, and Adam turns noise into +-lr
+                    continue
+                wk = 'wdig.' + pre + k
+                got = GU.digest(p.detach().numpy())
+                np.testing.assert_allclose(got, d[wk], rtol=2e-5, atol=2e-6, err_msg=f'step {s} {wk}')
+        assert n > 0

@@ -429,6 +429,108 @@ def gen_fc_joint(torch, models, rec):
              gts_count=np.array([len(x) for x in batch['gts']]))
 
 
+# ----------------------------------------------------------------------------
+# share_embed = 1 (AlternatingJointModel.py:83-88, train.py:390-391, optimizer.py:224-242): ONE embedding table is a parameter
+# of both agents and of both Adam instances.  Multi-step cases through the reference's own zeroing_optimizer / update_optimizer:
+# what pins the semantics is the weight trajectory (the table is updated by each optimizer that steps, with that optimizer's
+# moments, from the one clamped gradient both agents accumulated into).
+SHARE_CASES = [
+    # gumbel: every iteration is a "speaker" turn that steps BOTH optimizers (optimizer.py:90-95,233-239): the table moves twice
+    ('share_joint_gumbel', dict(retrieval_reward='gumbel', drop_prob_lm=0.5), ['speaker', 'speaker']),
+    # reinforce: real alternation.  listener turn: the table is frozen (the caption model's requires_grad loop runs last,
+    # :592-645) but the listener's Adam still steps it by its momentum; speaker turn: only the speaker's Adam steps it
+    ('share_reinforce', dict(retrieval_reward='reinforce', reinforce_baseline_type='gt', vse_loss_weight=1.0, drop_prob_lm=0.5),
+     ['listener', 'speaker', 'listener', 'speaker']),
+]
+
+
+def gen_share_embed(torch, models, rec):
+    import contextlib
+    import io
+    import optimizer as ref_optim
+    # torch 0.4.1's Optimizer.zero_grad() zero-FILLS the gradients (p.grad.detach_(); p.grad.zero_()); torch 2.x sets them to
+    # None by default, and Adam then SKIPS such a parameter.  The difference is visible exactly here: in a reinforce listener
+    # turn the shared table is frozen, its gradient stays the zero tensor, and 0.4.1's Adam still moves it by its momentum.
+    # Same kind of shim as the zero-dim indexing one: the reference's own call, with the semantics of the torch it was written for.
+    _zg = torch.optim.Optimizer.zero_grad
+    torch.optim.Optimizer.zero_grad = lambda self, set_to_none=False: _zg(self, set_to_none=False)
+    for name, kw, turns in SHARE_CASES:
+        opt = make_opt(share_embed=1, learning_rate=2e-3, weight_decay=0.0, grad_clip=0.1, **kw)
+        torch.manual_seed(31)
+        m = models.AlternatingJointModel(opt)
+        assert m.caption_generator.embed[0].weight is m.vse.txt_enc.embed.weight
+        m.train()
+        cg = m.caption_generator
+        batch0 = make_batch(torch, opt, K=7, seed=31)
+        widen(cg, batch0)                    # (scales the SHARED table too)
+        cg.logit.bias.data[0] = 1.0
+        init = {k: v for k, v in sd_np(m).items()}
+        opt.is_alternating = 1               # what zeroing_optimizer / update_optimizer branch on
+        o_s = ref_optim.define_optimizer(m.caption_generator, opt)
+        o_l = ref_optim.define_optimizer(m.vse, opt)
+        if opt.retrieval_reward == 'reinforce':
+            od = {'speaker': o_s, 'listener': o_l}
+        else:
+            od = {'speaker': {'speaker': o_s, 'listener': o_l}}      # optimizer.py:90-93
+        out = {}
+        T = opt.seq_length + 1
+        for s_i, turn in enumerate(turns):
+            batch = make_batch(torch, opt, K=7, seed=31 + s_i)
+            B = opt.batch_size
+            sc = (0.3 + 0.5 * (np.arange(B) % 6)).astype(np.float32)
+            batch['att_feats'] = batch['att_feats'] * torch.from_numpy(sc).view(B, 1, 1)
+            batch['fc_feats'] = batch['att_feats'].mean(1)
+            optimizer = od[turn] if turn in od else od['speaker']
+            ref_optim.zeroing_optimizer(opt, od, optimizer)
+            torch.manual_seed(100 + s_i)
+            tokens = []
+            orig_sample = cg.sample
+
+            def spy(*a, **k):
+                r = orig_sample(*a, **k)
+                tokens.append(r[0].detach().numpy().astype(np.int64).copy())
+                return r
+            cg.sample = spy
+            rec.start()
+            with contextlib.redirect_stdout(io.StringIO()):
+                loss = m(batch['fc_feats'], batch['labels'], batch['masks'], {'gts': batch['gts']}, batch['att_feats'], None,
+                         is_alternating=True, alternating_turn=turn)
+            ev = rec.stop()
+            cg.sample = orig_sample
+            loss.backward()
+            decs = split_decodes(ev, T, B, opt.input_encoding_size, opt.rnn_size, opt.vocab_size + 1, None)
+            pre = f's{s_i}.'
+            for i, d in enumerate(decs):
+                out.update({pre + k: v for k, v in flat_noise(f'noise{i}', d).items()})
+            for i, t in enumerate(tokens):
+                out[pre + f'tokens{i}'] = t
+            out[pre + 'n_decodes'] = np.int64(len(decs))
+            out[pre + 'loss'] = np.float64(float(loss))
+            out[pre + 'turn'] = np.array(turn)
+            for k, p_ in m.named_parameters():          # (shared table: listed once, under the caption generator's name)
+                if k.startswith('prev_') or p_.grad is None:
+                    continue
+                out[pre + 'gdig.' + k] = GU.digest(p_.grad.detach().numpy())
+            out[pre + 'embed_requires_grad'] = np.int64(int(m.vse.txt_enc.embed.weight.requires_grad))
+            for k in ('fc_feats', 'att_feats', 'labels', 'masks'):
+                out[pre + k] = batch[k].numpy()
+            out[pre + 'gts_flat'] = np.concatenate(batch['gts'], 0)
+            out[pre + 'gts_count'] = np.array([len(x) for x in batch['gts']])
+            with contextlib.redirect_stdout(io.StringIO()):
+                ref_optim.update_optimizer(od, optimizer, opt)
+            assert cg.embed[0].weight is m.vse.txt_enc.embed.weight
+            for k, v in sd_np(m).items():
+                if not k.startswith('prev_'):
+                    out[pre + 'wdig.' + k] = GU.digest(v)
+            print(name, 'step', s_i, turn, 'loss', float(loss), 'decodes', [(t.shape[1], sorted(set((t > 0).sum(1).tolist()))) for t in tokens])
+        cfg = opt_np(opt)
+        cfg['cfg.share_embed'] = np.float64(1)
+        cfg['cfg.learning_rate'] = np.float64(opt.learning_rate)
+        cfg['cfg.grad_clip'] = np.float64(opt.grad_clip)
+        save(name, **{'w.' + k: v for k, v in init.items()}, **cfg, **out, n_steps=np.int64(len(turns)))
+    torch.optim.Optimizer.zero_grad = _zg
+
+
 def gen_fc(torch, models, rec):
     """FCModel (the fc-feature speaker of BASELINE configs[0]): MLE forward/backward and greedy / multinomial decodes."""
 
@@ -563,6 +665,10 @@ def main():
     if '--only-fc-joint' in sys.argv:
         rewards.init_scorer('corpus')
         gen_fc_joint(torch, models, rec)
+        return
+    if '--only-share-embed' in sys.argv:
+        rewards.init_scorer('corpus')
+        gen_share_embed(torch, models, rec)
         return
     if '--only-beam' in sys.argv:
         gen_beam(torch, models, rec)
@@ -942,6 +1048,7 @@ def main():
         clamp_adam_case()
         gen_fc(torch, models, rec)
         gen_fc_joint(torch, models, rec)
+        gen_share_embed(torch, models, rec)
         gen_beam(torch, models, rec)
         gen_retrieval(torch)
         gen_state_dict_layout(torch, models)
