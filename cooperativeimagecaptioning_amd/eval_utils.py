@@ -231,10 +231,60 @@ def encode_data(model, loader, eval_kwargs={}, useGenSent=False):
     return img_embs, cap_embs, images_data
 
 
+def _evalrank_fold5(img_embs, cap_embs, images_data, useGenSent):
+    """fold5 = 1 (eval_utils.py:450-487,503-540): the MSCOCO 5k test set as five folds of 1000 images, metrics averaged.
+    The reference's own fold5 branch cannot execute - it calls t2i() without its required `images_data` argument (TypeError)
+    and returns an `images_ranking` it never assigned - so there is nothing to record from it: this follows its evident intent
+    (per fold i2t + t2i on rows [i*5000, (i+1)*5000) - 1000 images x 5 caption rows; with generated captions 1000 rows of
+    each -, the thirteen numbers [r1 r5 r10 medr meanr] x 2 + ar + ari + rsum averaged over the folds) through the same
+    device rank kernels as the full evaluation.  Parity: by construction on i2t / t2i, which are pinned (tests/golden/retrieval_*)."""
+    per = 1000 * (1 if useGenSent else 5)
+    nfold = img_embs.shape[0] // per
+    if nfold < 1:
+        raise ValueError(f'fold5 needs at least {per} embedded rows (1000 images), got {img_embs.shape[0]}')
+    results, first_ranking = [], None
+    for i in range(min(5, nfold)):
+        sl = slice(i * per, (i + 1) * per)
+        infos = images_data[i * 1000:(i + 1) * 1000]
+        ri, rti, ranking = t2i(img_embs[sl], cap_embs[sl], infos, measure='cosine', return_ranks=True, useGenSent=useGenSent)
+        if useGenSent:
+            r = (0.0,) * 5                      # one caption per image: the reference ranks text -> image only there
+        else:
+            r, rt = i2t(img_embs[sl], cap_embs[sl], measure='cosine', return_ranks=True)
+            print('Image to text: %.1f, %.1f, %.1f, %.1f, %.1f' % r)
+        print('Text to image: %.1f, %.1f, %.1f, %.1f, %.1f' % ri)
+        ar, ari = (r[0] + r[1] + r[2]) / 3, (ri[0] + ri[1] + ri[2]) / 3
+        rsum = r[0] + r[1] + r[2] + ri[0] + ri[1] + ri[2]
+        print('rsum: %.1f ar: %.1f ari: %.1f' % (rsum, ar, ari))
+        results.append(list(r) + list(ri) + [ar, ari, rsum])
+        if i == 0:
+            first_ranking = ranking
+    m = tuple(np.array(results).mean(axis=0).flatten())
+    print('-----------------------------------')
+    print('Mean metrics: ')
+    print('rsum: %.1f' % m[12])
+    if not useGenSent:
+        print('Average i2t Recall: %.1f' % m[10])
+        print('Image to text: %.1f %.1f %.1f %.1f %.1f' % m[:5])
+    print('Average t2i Recall: %.1f' % m[11])
+    print('Text to image: %.1f %.1f %.1f %.1f %.1f' % m[5:10])
+    out = {'rsum': m[12], 't2i_ar': m[11], 't2i_r1': m[5], 't2i_r5': m[6], 't2i_r10': m[7], 't2i_medr': m[8], 't2i_meanr': m[9],
+           'folds': len(results)}
+    if useGenSent:
+        out['images_ranking'] = first_ranking
+    else:
+        out.update({'i2t_ar': m[10], 'i2t_r1': m[0], 'i2t_r5': m[1], 'i2t_r10': m[2], 'i2t_medr': m[3], 'i2t_meanr': m[4],
+                    'gt_images_ranking': first_ranking})
+    return out
+
+
 def evalrank(model, loader, eval_kwargs={}, useGenSent=False):
-    """eval_utils.py:415-542 (full evaluation; fold5 = 5 x 1000-image folds of MSCOCO test is not mirrored)."""
+    """eval_utils.py:415-542: the full evaluation, or with eval_kwargs['fold5'] the five 1000-image folds (_evalrank_fold5)."""
     if eval_kwargs.get('fold5', 0):
-        raise NotImplementedError('fold5 cross-validation (eval_utils.py:450-487) is not mirrored')
+        img_embs, cap_embs, images_data = encode_data(model, loader, eval_kwargs, useGenSent) if useGenSent \
+            else encode_data(model, loader, eval_kwargs)
+        print('Images: %d, Captions: %d' % (img_embs.shape[0] / (1 if useGenSent else 5), cap_embs.shape[0]))
+        return _evalrank_fold5(img_embs, cap_embs, images_data, useGenSent)
     if not useGenSent:
         print('Computing results useGenSent = False...')
         img_embs, cap_embs, images_data = encode_data(model, loader, eval_kwargs)

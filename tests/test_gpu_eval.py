@@ -86,3 +86,33 @@ def test_eval_split_generates_the_oracle_captions(tmp_path):
     assert 't2i_r1' in losses and 'gt_ranks' in losses and 'i2t_r1' in losses['gt_ranks']
     assert model.training                                                      # switched back (:268)
     loader.close()
+
+
+def test_evalrank_fold5_averages_the_1000_image_folds():
+    """eval_kwargs['fold5'] (eval_utils.py:450-487): the reference's own branch cannot run (t2i() called without its required
+    images_data; an unassigned images_ranking returned), so this pins the evident intent: per 1000-image fold the i2t / t2i
+    metrics of oracle/retrieval.py (pinned by the reference-recorded retrieval fixtures), averaged over the folds."""
+    from cooperativeimagecaptioning_amd import eval_utils
+    from oracle import retrieval as R
+    rs = np.random.RandomState(5)
+    n_img, J = 2000, 48
+    base = rs.randn(n_img, J).astype(np.float32)
+    ims = np.repeat(base, 5, axis=0)
+    caps = (np.repeat(base, 5, axis=0) * 0.6 + rs.randn(n_img * 5, J) * 0.8).astype(np.float32)
+    ims /= np.linalg.norm(ims, axis=1, keepdims=True)
+    caps /= np.linalg.norm(caps, axis=1, keepdims=True)
+    infos = [{'id': 10 + i, 'file_path': f'im{i}.jpg'} for i in range(n_img)]
+    out = eval_utils._evalrank_fold5(ims, caps, infos, useGenSent=False)
+    want = []
+    for f in range(2):
+        sl = slice(f * 5000, (f + 1) * 5000)
+        r, _ = R.i2t(ims[sl], caps[sl])
+        ri, _ = R.t2i(ims[sl], caps[sl])
+        want.append(list(r) + list(ri) + [(r[0] + r[1] + r[2]) / 3, (ri[0] + ri[1] + ri[2]) / 3, sum(r[:3]) + sum(ri[:3])])
+    m = np.array(want).mean(axis=0)
+    assert out['folds'] == 2
+    for key, v in (('i2t_r1', m[0]), ('i2t_r5', m[1]), ('i2t_r10', m[2]), ('i2t_medr', m[3]), ('i2t_meanr', m[4]),
+                   ('t2i_r1', m[5]), ('t2i_r5', m[6]), ('t2i_r10', m[7]), ('t2i_medr', m[8]), ('t2i_meanr', m[9]),
+                   ('i2t_ar', m[10]), ('t2i_ar', m[11]), ('rsum', m[12])):
+        assert out[key] == pytest.approx(v, rel=1e-12, abs=1e-12), key
+    assert out['gt_images_ranking'][3]['caption0']['image_id'] == 13

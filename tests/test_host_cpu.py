@@ -102,8 +102,10 @@ def test_unsupported_configurations_fail_loudly():
     from cooperativeimagecaptioning_amd import models
     z = GU.load_case('joint_gumbel')
     cfg = GU.cfg_dict(z)
-    with pytest.raises(NotImplementedError):
-        models.AlternatingJointModel(GU.make_opt(cfg, 6, share_embed=1))
+    with pytest.raises(NotImplementedError):      # share_embed assigns caption_generator.embed[0]: att2in2 only, as in the reference
+        models.AlternatingJointModel(GU.make_opt(cfg, 6, share_embed=1, caption_model='fc'))
+    m = models.AlternatingJointModel(GU.make_opt(cfg, 6, share_embed=1))
+    assert m.caption_generator.embed[0].weight is m.vse.txt_enc.embed.weight
     with pytest.raises(NotImplementedError):
         models.setup(GU.make_opt(cfg, 6, use_bn=1), 'att2in2', 'caption_model')
     with pytest.raises(Exception):
