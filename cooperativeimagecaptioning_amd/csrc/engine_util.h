@@ -76,6 +76,7 @@ struct TeacherSeqLaunch {
     float *pre_all, *h_all, *c_all, *att_h_all, *att_res_all, *alpha_all, *dot_all, *out_all;
     unsigned* sync;           // cic_cdiv(B, 16) * T * 3 + 1 words
     uint32_t* status;         // the caller's sticky status word (cic.h) or null
+    int bf16;                 // != 0: compute_dtype bf16 - weight tiles and handed-over rows as bf16 MFMA operands, f32 accumulation
     float scale;
     int B, K, T;
 };

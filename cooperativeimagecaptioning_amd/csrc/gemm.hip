@@ -1789,14 +1789,16 @@ __global__ __launch_bounds__(256 * KH) __attribute__((amdgpu_waves_per_eu(KH, KH
 // wave reads the three parts of a k-step (32 k) one step ahead of the MFMAs that use them, and its A fragments are the
 // three parts of its K half (96 VGPRs).  Terms of like magnitude share an accumulator chain (parts 0x2, 2x0, 1x1 | 0x1,
 // 1x0 | 0x0), the chains are added smallest first.
-template <int NG, int EPI, int PRE>   // PRE: the weights arrive already split (three bf16 images [3][N][K], cic_split_bf16x3)
+// NP = 3: f32 results from three bf16 parts per operand; NP = 1 (r4, CIC_PRECISION_BF16): ONE part - operands rounded to bf16
+// once, one MFMA per k-step, a third of the staged bytes - the logit product of the reduced-precision variant.
+template <int NG, int EPI, int PRE, int NP>   // PRE: the weights arrive already cut (NP bf16 images [NP][N][K], cic_split_bf16x3 / cic_round_bf16)
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_ldsb2bf_walk_kernel(
     cic_gemm_args g, int row_groups, int walkers, cic_logit_epilogue epi, const __bf16* __restrict__ wparts) {
     constexpr int KH = 2, K = 16 * NG, NT = 512;
-    constexpr int LDBH = K + 8, PART = 16 * LDBH, TILEH = 3 * PART;   // bf16 per staged row / part / tile
+    constexpr int LDBH = K + 8, PART = 16 * LDBH, TILEH = NP * PART;   // bf16 per staged row / part / tile
     constexpr int JS = K / KH / 32;                        // k-steps of 32 per wave
     constexpr int F4 = 16 * (K / 4) / NT;                  // float4 per thread and staged tile
-    constexpr int NPC = PRE ? 3 * 16 * (K / 8) / NT : F4;  // staged pieces per thread and tile (PRE: 16-byte pieces of the images)
+    constexpr int NPC = PRE ? NP * 16 * (K / 8) / NT : F4;  // staged pieces per thread and tile (PRE: 16-byte pieces of the images)
     static_assert(NPC <= JS && (TILEH % 8) == 0, "the staged pieces ride behind the last k-steps of a tile");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __bf16* ldsh = reinterpret_cast<__bf16*>(lds);
@@ -1853,22 +1855,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         const int j = tid + NT * e;
         const int r = j / (K / 4), c4 = j % (K / 4);
-        bf16x4 parts[3];
-        split_bf16<3>(stg[e], parts);
+        bf16x4 parts[NP];
+        split_bf16<NP>(stg[e], parts);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x4*>(dst + p * PART + r * LDBH + 4 * c4) = parts[p];
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4*>(dst + p * PART + r * LDBH + 4 * c4) = parts[p];
     };
     load_tile(first);
-    bf16x8 ap[3][JS];
+    bf16x8 ap[NP][JS];
     {
         const float* arow = gA + (size_t)mc * g.lda + (K / KH) * kh + 8 * lq;
 #pragma unroll
         for (int j = 0; j < JS; ++j) {
-            bf16x4 pl[3], ph[3];
-            split_bf16<3>(*reinterpret_cast<const f32x4*>(arow + 32 * j), pl);
-            split_bf16<3>(*reinterpret_cast<const f32x4*>(arow + 32 * j + 4), ph);
+            bf16x4 pl[NP], ph[NP];
+            split_bf16<NP>(*reinterpret_cast<const f32x4*>(arow + 32 * j), pl);
+            split_bf16<NP>(*reinterpret_cast<const f32x4*>(arow + 32 * j + 4), ph);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) ap[p][j] = __builtin_shufflevector(pl[p], ph[p], 0, 1, 2, 3, 4, 5, 6, 7);
+            for (int p = 0; p < NP; ++p) ap[p][j] = __builtin_shufflevector(pl[p], ph[p], 0, 1, 2, 3, 4, 5, 6, 7);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1971,23 +1973,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const __bf16* bt = ldsh + buf * TILEH + li * LDBH + (K / KH) * kh + 8 * lq;
             __bf16* nxt = ldsh + (buf ^ 1) * TILEH;        // every wave left this buffer before the last barrier
             f32x4acc aS = {0.f, 0.f, 0.f, 0.f}, aM = {0.f, 0.f, 0.f, 0.f}, aB = {0.f, 0.f, 0.f, 0.f};
-            bf16x8 bq[2][3];
+            bf16x8 bq[2][NP];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bq[0][p] = *reinterpret_cast<const bf16x8*>(bt + p * PART);
+            for (int p = 0; p < NP; ++p) bq[0][p] = *reinterpret_cast<const bf16x8*>(bt + p * PART);
 #pragma unroll
             for (int j = 0; j < JS; ++j) {
                 if (j + 1 < JS) {
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) bq[(j + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(bt + p * PART + 32 * (j + 1));
+                    for (int p = 0; p < NP; ++p) bq[(j + 1) & 1][p] = *reinterpret_cast<const bf16x8*>(bt + p * PART + 32 * (j + 1));
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                const bf16x8 b0 = bq[j & 1][0], b1 = bq[j & 1][1], b2 = bq[j & 1][2];
-                aS = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[0][j], b2, aS, 0, 0, 0);
-                aM = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[0][j], b1, aM, 0, 0, 0);
-                aB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[0][j], b0, aB, 0, 0, 0);
-                aS = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[2][j], b0, aS, 0, 0, 0);
-                aM = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[1][j], b0, aM, 0, 0, 0);
-                aS = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[1][j], b1, aS, 0, 0, 0);
+                if (NP == 3) {
+                    const bf16x8 b0 = bq[j & 1][0], b1 = bq[j & 1][NP > 1 ? 1 : 0], b2 = bq[j & 1][NP > 2 ? 2 : 0];
+                    aS = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[0][j], b2, aS, 0, 0, 0);
+                    aM = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[0][j], b1, aM, 0, 0, 0);
+                    aB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[0][j], b0, aB, 0, 0, 0);
+                    aS = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[NP > 2 ? 2 : 0][j], b0, aS, 0, 0, 0);
+                    aM = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[NP > 1 ? 1 : 0][j], b0, aM, 0, 0, 0);
+                    aS = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[NP > 1 ? 1 : 0][j], b1, aS, 0, 0, 0);
+                } else {
+                    aB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[0][j], bq[j & 1][0], aB, 0, 0, 0);
+                }
                 if (ROLE == 0) {
                     if (j < 4) { finish_row(j); __builtin_amdgcn_sched_barrier(0); }
                 } else if (ROLE != 4) {
@@ -2066,13 +2072,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-__global__ __launch_bounds__(256) void split_bf16x3_kernel(const f32x4* __restrict__ x, int64_t n4, bf16x4* __restrict__ parts) {
+template <int NP>
+__global__ __launch_bounds__(256) void split_bf16_kernel(const f32x4* __restrict__ x, int64_t n4, bf16x4* __restrict__ parts) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
-    bf16x4 p[3];
-    split_bf16<3>(x[i], p);
+    bf16x4 p[NP];
+    split_bf16<NP>(x[i], p);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) parts[(int64_t)q * n4 + i] = p[q];
+    for (int q = 0; q < NP; ++q) parts[(int64_t)q * n4 + i] = p[q];
 }
 
 bool ldsb_walk_ok(const cic_gemm_args& g) {
@@ -2115,28 +2122,34 @@ int launch_ldsb_walk(const cic_gemm_args& g, hipStream_t st) {
         cic_logit_epilogue epi = {};
         if (g.epi) epi = *g.epi;
         if (g_ldsb2 == 2 && g_bfx && g.precision != CIC_PRECISION_F32_MFMA) {
-            // bf16-part form (f32 results): two tiles of three bf16 images + the two hand-off buffers
-            constexpr size_t bf_bytes = 2 * 3 * 16 * (16 * NG + 8) * 2 + 2 * 4 * 1 * 4 * 64 * sizeof(float) + 2 * 4 * 4 * 64 * sizeof(float);
-            static DeviceOnce attr3_set;
-            if (attr3_set.first()) {
-                CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2bf_walk_kernel<NG, 0, 0>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf_bytes));
-                CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2bf_walk_kernel<NG, 1, 0>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf_bytes));
-                CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2bf_walk_kernel<NG, 0, 1>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf_bytes));
-                CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2bf_walk_kernel<NG, 1, 1>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf_bytes));
-            }
+            // bf16-part form: two tiles of NP bf16 images + the two hand-off buffers (NP = 3: f32 results; NP = 1: the
+            // reduced-precision variant, CIC_PRECISION_BF16 - B_parts then holds ONE image, cic_round_bf16)
             const __bf16* wparts = reinterpret_cast<const __bf16*>(g.B_parts);
-            if (wparts && g.epi)
-                hipLaunchKernelGGL((gemm_ldsb2bf_walk_kernel<NG, 1, 1>), dim3(grid), dim3(512), bf_bytes, st, g, row_groups, walkers, epi, wparts);
-            else if (wparts)
-                hipLaunchKernelGGL((gemm_ldsb2bf_walk_kernel<NG, 0, 1>), dim3(grid), dim3(512), bf_bytes, st, g, row_groups, walkers, epi, wparts);
-            else if (g.epi)
-                hipLaunchKernelGGL((gemm_ldsb2bf_walk_kernel<NG, 1, 0>), dim3(grid), dim3(512), bf_bytes, st, g, row_groups, walkers, epi, wparts);
-            else
-                hipLaunchKernelGGL((gemm_ldsb2bf_walk_kernel<NG, 0, 0>), dim3(grid), dim3(512), bf_bytes, st, g, row_groups, walkers, epi, wparts);
+#define WALK_GO(NPv)                                                                                                                 \
+    do {                                                                                                                             \
+        constexpr size_t bf_bytes = 2 * NPv * 16 * (16 * NG + 8) * 2 + 2 * 4 * 1 * 4 * 64 * sizeof(float) + 2 * 4 * 4 * 64 * sizeof(float); \
+        static DeviceOnce attr3_set;                                                                                                 \
+        if (attr3_set.first()) {                                                                                                     \
+            CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2bf_walk_kernel<NG, 0, 0, NPv>),                     \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf_bytes));                                 \
+            CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2bf_walk_kernel<NG, 1, 0, NPv>),                     \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf_bytes));                                 \
+            CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2bf_walk_kernel<NG, 0, 1, NPv>),                     \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf_bytes));                                 \
+            CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ldsb2bf_walk_kernel<NG, 1, 1, NPv>),                     \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bf_bytes));                                 \
+        }                                                                                                                            \
+        if (wparts && g.epi)                                                                                                         \
+            hipLaunchKernelGGL((gemm_ldsb2bf_walk_kernel<NG, 1, 1, NPv>), dim3(grid), dim3(512), bf_bytes, st, g, row_groups, walkers, epi, wparts); \
+        else if (wparts)                                                                                                             \
+            hipLaunchKernelGGL((gemm_ldsb2bf_walk_kernel<NG, 0, 1, NPv>), dim3(grid), dim3(512), bf_bytes, st, g, row_groups, walkers, epi, wparts); \
+        else if (g.epi)                                                                                                              \
+            hipLaunchKernelGGL((gemm_ldsb2bf_walk_kernel<NG, 1, 0, NPv>), dim3(grid), dim3(512), bf_bytes, st, g, row_groups, walkers, epi, wparts); \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((gemm_ldsb2bf_walk_kernel<NG, 0, 0, NPv>), dim3(grid), dim3(512), bf_bytes, st, g, row_groups, walkers, epi, wparts); \
+    } while (0)
+            if (g.precision == CIC_PRECISION_BF16) WALK_GO(1); else WALK_GO(3);
+#undef WALK_GO
             CIC_LAUNCH_CHECK();
             return 0;
         }
@@ -2509,8 +2522,16 @@ extern "C" int cic_gemm_f32(const cic_gemm_args* a, cic_stream_t s) {
 // Average duration of one cic_gemm_f32 launch: `iters` back-to-back launches between two HIP events on `s`.
 extern "C" int cic_split_bf16x3(const float* x, int64_t n, uint16_t* parts, cic_stream_t s) {
     CIC_REQUIRE(x && parts && n > 0 && (n & 3) == 0 && aligned16(x) && ((uintptr_t)parts & 7) == 0);
-    hipLaunchKernelGGL(split_bf16x3_kernel, dim3(cic_cdiv(n / 4, 256)), dim3(256), 0, cic_s(s), reinterpret_cast<const f32x4*>(x),
+    hipLaunchKernelGGL(split_bf16_kernel<3>, dim3(cic_cdiv(n / 4, 256)), dim3(256), 0, cic_s(s), reinterpret_cast<const f32x4*>(x),
                        n / 4, reinterpret_cast<bf16x4*>(parts));
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+// the one-part form: packed[i] = bf16(x[i]) (round to nearest even) - the operand image of the reduced-precision variant
+extern "C" int cic_round_bf16(const float* x, int64_t n, uint16_t* packed, cic_stream_t s) {
+    CIC_REQUIRE(x && packed && n > 0 && (n & 3) == 0 && aligned16(x) && ((uintptr_t)packed & 7) == 0);
+    hipLaunchKernelGGL(split_bf16_kernel<1>, dim3(cic_cdiv(n / 4, 256)), dim3(256), 0, cic_s(s), reinterpret_cast<const f32x4*>(x),
+                       n / 4, reinterpret_cast<bf16x4*>(packed));
     CIC_LAUNCH_CHECK();
     return 0;
 }

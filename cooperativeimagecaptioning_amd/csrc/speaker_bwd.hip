@@ -572,7 +572,16 @@ __device__ unsigned long long* g_bptt_stamps = nullptr;    // development build:
 #endif
 typedef float f32x4acc_b __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4_b __attribute__((ext_vector_type(4)));
-template <int KS>
+typedef __bf16 bf16x8_b __attribute__((ext_vector_type(8)));
+typedef float f32x8_b __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8_b to_bf16x8_b(const f32x4 lo, const f32x4 hi) {
+    const f32x8_b v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_convertvector(v, bf16x8_b);        // round to nearest even; a plain cast keeps a NaN a NaN
+}
+// BF (r4, compute_dtype bf16): the stationary weight columns are bf16 MFMA fragments (v_mfma_f32_16x16x32_bf16; all of them in
+// 64 VGPRs, none in LDS), the handed-over gradient rows (dpre, d att_h) are rounded to bf16 as they are loaded, accumulation f32:
+// 16 bf16 MFMAs per step instead of 128 f32 ones.  The cell backward, the attention backward, dh and dc stay f32.
+template <int KS, bool BF>
 __global__ __launch_bounds__(KS * 64) void spk_bptt_seq_kernel(BpttArgs a) {
     static_assert(KS == 8, "K slices of 128 / 192 / 64 columns per wave");
     constexpr int H = 512, H5 = 5 * H, TJ = H / 16, GA = BPTT_GA, GI = BPTT_GI, GC = BPTT_GC;
@@ -600,14 +609,35 @@ __global__ __launch_bounds__(KS * 64) void spk_bptt_seq_kernel(BpttArgs a) {
     const int mc = min(m0 + li, RE - 1);                  // A rows; rows past the block repeat its last row: their sums are never stored
     unsigned* cnt = a.cnt + (size_t)(a.row0 / 16 + strip) * T * 3;
     // ---- the weight tiles, once --------------------------------------------------------------------------------------
-    f32x4 wh_ab[GA], wh_ifo[GI];
+    f32x4 wh_ab[BF ? 1 : GA], wh_ifo[BF ? 1 : GI];
+    // BF: k-steps of 32 inside a wave's K slice: [0, GA/2) h2h (a, b) rows, then a2c, then h2h (i, f, o) rows, then h2att
+    constexpr int SA = GA / 2, SI = GI / 2, SC = GC / 2;
+    bf16x8_b wb[BF ? 2 * SA + SI + SC : 1];
+    if (BF) {
+        auto gather8 = [&](const float* W, int k0) {      // rows k0 .. k0 + 7 of column col: one fragment
+            f32x4 lo, hi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { lo[e] = W[(size_t)(k0 + e) * H + col]; hi[e] = W[(size_t)(k0 + 4 + e) * H + col]; }
+            return to_bf16x8_b(lo, hi);
+        };
+#pragma unroll
+        for (int j = 0; j < SA; ++j) {
+            wb[BF ? j : 0] = gather8(a.h2h_w, 3 * H + 128 * ks + 32 * j + 8 * lq);
+            wb[BF ? SA + j : 0] = gather8(a.a2c_w, 128 * ks + 32 * j + 8 * lq);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < SI; ++j) { wb[BF ? 2 * SA + j : 0] = gather8(a.h2h_w, 192 * ks + 32 * j + 8 * lq); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+        for (int j = 0; j < SC; ++j) { wb[BF ? 2 * SA + SI + j : 0] = gather8(a.h2att_w, 64 * ks + 32 * j + 8 * lq); __builtin_amdgcn_sched_barrier(0); }
+    } else {
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
         const int k = 128 * ks + 16 * i + 4 * lq;
         f32x4 v;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            wh_ab[i][s] = a.h2h_w[(size_t)(3 * H + k + s) * H + col];
+            wh_ab[BF ? 0 : i][s] = a.h2h_w[(size_t)(3 * H + k + s) * H + col];
             v[s] = a.a2c_w[(size_t)(k + s) * H + col];
         }
         wl[(ks * (GA + GC) + i) * 64 + lane] = v;
@@ -617,7 +647,7 @@ __global__ __launch_bounds__(KS * 64) void spk_bptt_seq_kernel(BpttArgs a) {
     for (int i = 0; i < GI; ++i) {
         const int k = 192 * ks + 16 * i + 4 * lq;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) wh_ifo[i][s] = a.h2h_w[(size_t)(k + s) * H + col];
+        for (int s = 0; s < 4; ++s) wh_ifo[BF ? 0 : i][s] = a.h2h_w[(size_t)(k + s) * H + col];
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -628,6 +658,7 @@ __global__ __launch_bounds__(KS * 64) void spk_bptt_seq_kernel(BpttArgs a) {
         for (int s = 0; s < 4; ++s) v[s] = a.h2att_w[(size_t)(k + s) * H + col];
         wl[(ks * (GA + GC) + GA + i) * 64 + lane] = v;
         __builtin_amdgcn_sched_barrier(0);
+    }
     }
     // attention backward: this wave's 64 columns (float4 column col4), lane -> (c = column quad, rg = region group)
     const int ac = lane & 15, rg = lane >> 4;
@@ -731,17 +762,28 @@ __global__ __launch_bounds__(KS * 64) void spk_bptt_seq_kernel(BpttArgs a) {
         {
             f32x4 af[GA];
 #pragma unroll
+            // (BF: the same loads as runs of eight consecutive k: 32 (i >> 1) + 8 lq + 4 (i & 1))
             for (int i = 0; i < GA; ++i)
                 af[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                    r_dpre, (int)(((size_t)mc_t * H5 + 3 * H + 128 * ks + 16 * i + 4 * lq_t) * 4), so5, 16));
+                    r_dpre, (int)(((size_t)mc_t * H5 + 3 * H + 128 * ks + (BF ? 32 * (i >> 1) + 8 * lq_t + 4 * (i & 1) : 16 * i + 4 * lq_t)) * 4),
+                    so5, 16));
+            if (BF) {
+#pragma unroll
+                for (int j = 0; j < SA; ++j) {
+                    const bf16x8_b ab = to_bf16x8_b(af[2 * j], af[2 * j + 1]);
+                    acc_res = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, wb[BF ? SA + j : 0], acc_res, 0, 0, 0);
+                    acc_dh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, wb[BF ? j : 0], acc_dh, 0, 0, 0);
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < GA; ++i) {
                 const f32x4 bw = wl[(ks * (GA + GC) + i) * 64 + lane_t];
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     acc_res = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bw[s], acc_res, 0, 0, 0);
-                    acc_dh = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], wh_ab[i][s], acc_dh, 0, 0, 0);
+                    acc_dh = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], wh_ab[BF ? 0 : i][s], acc_dh, 0, 0, 0);
                 }
+            }
             }
         }
 #pragma unroll
@@ -828,11 +870,17 @@ __global__ __launch_bounds__(KS * 64) void spk_bptt_seq_kernel(BpttArgs a) {
 #pragma unroll
             for (int i = 0; i < GI; ++i)
                 af[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                    r_dpre, (int)(((size_t)mc_t * H5 + 192 * ks + 16 * i + 4 * lq_t) * 4), so5, 16));
+                    r_dpre, (int)(((size_t)mc_t * H5 + 192 * ks + (BF ? 32 * (i >> 1) + 8 * lq_t + 4 * (i & 1) : 16 * i + 4 * lq_t)) * 4), so5, 16));
+            if (BF) {
+#pragma unroll
+                for (int j = 0; j < SI; ++j)
+                    acc_dh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(to_bf16x8_b(af[2 * j], af[2 * j + 1]), wb[BF ? 2 * SA + j : 0], acc_dh, 0, 0, 0);
+            } else {
 #pragma unroll
             for (int i = 0; i < GI; ++i)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) acc_dh = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], wh_ifo[i][s], acc_dh, 0, 0, 0);
+                for (int s = 0; s < 4; ++s) acc_dh = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], wh_ifo[BF ? 0 : i][s], acc_dh, 0, 0, 0);
+            }
         }
         BPTT_STAMP(6);
         wait_for(cnt + t * 3 + 2, TJ / 2);
@@ -842,12 +890,18 @@ __global__ __launch_bounds__(KS * 64) void spk_bptt_seq_kernel(BpttArgs a) {
 #pragma unroll
             for (int i = 0; i < GC; ++i)
                 ac4[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                    r_dah, (int)(((size_t)mc_t * H + 64 * ks + 16 * i + 4 * lq_t) * 4), so1, 16));
+                    r_dah, (int)(((size_t)mc_t * H + 64 * ks + (BF ? 32 * (i >> 1) + 8 * lq_t + 4 * (i & 1) : 16 * i + 4 * lq_t)) * 4), so1, 16));
+            if (BF) {
+#pragma unroll
+                for (int j = 0; j < SC; ++j)
+                    acc_dh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(to_bf16x8_b(ac4[2 * j], ac4[2 * j + 1]), wb[BF ? 2 * SA + SI + j : 0], acc_dh, 0, 0, 0);
+            } else {
 #pragma unroll
             for (int i = 0; i < GC; ++i) {
                 const f32x4 bw = wl[(ks * (GA + GC) + GA + i) * 64 + lane_t];
 #pragma unroll
                 for (int s = 0; s < 4; ++s) acc_dh = __builtin_amdgcn_mfma_f32_16x16x4f32(ac4[i][s], bw[s], acc_dh, 0, 0, 0);
+            }
             }
         }
 #pragma unroll
@@ -1155,10 +1209,16 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     if (g_bptt_seq && !ps && !fc && H == 512 && A == 512 && K >= 1 && K <= 36 && !bio->device_shared && !io->device_shared) {
         static DeviceOnce attr_set;
         if (attr_set.first())
-            CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spk_bptt_seq_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        {
+            CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spk_bptt_seq_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)BPTT_LDS_BYTES));
+            CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spk_bptt_seq_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)BPTT_LDS_BYTES));
+        }
         // every workgroup of a launch resident at once: one per CU, where the occupancy query admits one
-        const int cus = cic_resident_cus(reinterpret_cast<const void*>(&spk_bptt_seq_kernel<8>), 512, BPTT_LDS_BYTES);
+        const bool bfk = d.compute_dtype == CIC_DTYPE_BF16;
+        const int cus = bfk ? cic_resident_cus(reinterpret_cast<const void*>(&spk_bptt_seq_kernel<8, true>), 512, BPTT_LDS_BYTES)
+                            : cic_resident_cus(reinterpret_cast<const void*>(&spk_bptt_seq_kernel<8, false>), 512, BPTT_LDS_BYTES);
         seq_rows = (cus / (H / 16)) * 16;                     // rows one launch can walk with every workgroup resident
         seq_kernel = seq_rows >= 16;
     }
@@ -1181,7 +1241,10 @@ static int decode_bwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         for (int row0 = 0; row0 < B; row0 += seq_rows) {          // (B = 128: one launch; B = 256: two row blocks)
             ba.row0 = row0;
             ba.row_end = row0 + seq_rows < B ? row0 + seq_rows : B;
-            hipLaunchKernelGGL((spk_bptt_seq_kernel<8>), dim3(cic_cdiv(ba.row_end - row0, 16) * (H / 16)), dim3(512), BPTT_LDS_BYTES, st, ba);
+            if (d.compute_dtype == CIC_DTYPE_BF16)
+                hipLaunchKernelGGL((spk_bptt_seq_kernel<8, true>), dim3(cic_cdiv(ba.row_end - row0, 16) * (H / 16)), dim3(512), BPTT_LDS_BYTES, st, ba);
+            else
+                hipLaunchKernelGGL((spk_bptt_seq_kernel<8, false>), dim3(cic_cdiv(ba.row_end - row0, 16) * (H / 16)), dim3(512), BPTT_LDS_BYTES, st, ba);
             CIC_LAUNCH_CHECK();
         }
     }

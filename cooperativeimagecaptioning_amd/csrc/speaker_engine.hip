@@ -313,7 +313,7 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         L.out_keep = io[0]->out_keep;
         L.pre_all = w[0].pre_all; L.h_all = w[0].h_all; L.c_all = w[0].c_all; L.att_h_all = w[0].att_h_all;
         L.att_res_all = w[0].att_res_all; L.alpha_all = w[0].alpha_all; L.dot_all = w[0].dot_all; L.out_all = w[0].out_all;
-        L.sync = w[0].tsync; L.status = io[0]->status; L.scale = 1.0f / (1.0f - p_drop); L.B = B; L.K = K; L.T = T;
+        L.sync = w[0].tsync; L.status = io[0]->status; L.bf16 = bf ? 1 : 0; L.scale = 1.0f / (1.0f - p_drop); L.B = B; L.K = K; L.T = T;
         RUN(cic_teacher_seq(L, st));
     }
     // The logit weights are read unchanged by every step's logit product: cut them into their three bf16 parts once per

@@ -455,7 +455,19 @@ struct TeacherSeqArgs {
 };
 constexpr size_t TEACHER_LDS_BYTES = sizeof(float) * ((size_t)8 * 8 * 64 * 4 + 8 * 6 * 4 * 64 + 8 * 64);
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-template <int KS>
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x8_t __attribute__((ext_vector_type(8)));
+// eight consecutive f32 -> one bf16 MFMA fragment (round to nearest even; a plain cast keeps a NaN a NaN)
+__device__ __forceinline__ bf16x8_t to_bf16x8(const f32x4 lo, const f32x4 hi) {
+    const f32x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_convertvector(v, bf16x8_t);
+}
+// BF (r4, compute_dtype bf16 = BASELINE configs[1]'s "bf16"): the stationary weight tiles are held as bf16 MFMA fragments
+// (v_mfma_f32_16x16x32_bf16: 8 k per lane and register quad - ALL eight tiles of a workgroup fit in 64 VGPRs, none in LDS), the
+// rows handed over between workgroups (h, att_res) are rounded to bf16 as they are loaded, accumulation stays f32: a step's
+// products are 16 bf16 MFMAs of 16 cycles instead of 128 f32 MFMAs of 32.  Cell, softmax and the slabs the backward pass reads
+// stay f32.  Same tiling, hand-offs and output order as the f32 form.
+template <int KS, bool BF>
 __global__ __launch_bounds__(KS * 64) void spk_teacher_seq_kernel(TeacherSeqArgs a) {
     static_assert(KS == 8, "K = 512 split over 8 waves: 4 k groups of 16 each");
     constexpr int H = 512, H5 = 5 * H, TJ = H / 16, GP = 4;
@@ -483,19 +495,36 @@ __global__ __launch_bounds__(KS * 64) void spk_teacher_seq_kernel(TeacherSeqArgs
     const int mc = min(m0 + li, RE - 1);                  // A rows; rows past the block repeat its last row: their sums are never stored
     unsigned* cnt = a.cnt + (size_t)(a.row0 / 16 + strip) * T * 3;
     // ---- the weight tiles, once: B fragments (k = 16 (4 ks + i) + 4 lq + s, n = unit li of the tile) -----------------------------
-    f32x4 wh[6][GP];
+    f32x4 wh[BF ? 1 : 6][GP];
+    bf16x8_t whb[BF ? 8 : 1][2];                          // BF: tiles 0-4 h2h, 5 h2att, 6-7 a2c; k-steps of 32 inside the wave's 64 k
 #pragma unroll
     for (int tau = 0; tau < 6; ++tau) {
         const float* wrow = tau < 5 ? a.h2h_w + ((size_t)tau * H + col) * H : a.h2att_w + (size_t)col * H;
+        if (BF) {
 #pragma unroll
-        for (int i = 0; i < GP; ++i) wh[tau][i] = *reinterpret_cast<const f32x4*>(wrow + 16 * (GP * ks + i) + 4 * lq);
+            for (int j = 0; j < 2; ++j) {
+                const float* q = wrow + 64 * ks + 32 * j + 8 * lq;
+                whb[BF ? tau : 0][j] = to_bf16x8(*reinterpret_cast<const f32x4*>(q), *reinterpret_cast<const f32x4*>(q + 4));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < GP; ++i) wh[BF ? 0 : tau][i] = *reinterpret_cast<const f32x4*>(wrow + 16 * (GP * ks + i) + 4 * lq);
+        }
     }
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const float* wrow = a.a2c_w + ((size_t)g * H + col) * H;
+        if (BF) {
 #pragma unroll
-        for (int i = 0; i < GP; ++i)
-            wl[((ks * 2 + g) * GP + i) * 64 + lane] = *reinterpret_cast<const f32x4*>(wrow + 16 * (GP * ks + i) + 4 * lq);
+            for (int j = 0; j < 2; ++j) {
+                const float* q = wrow + 64 * ks + 32 * j + 8 * lq;
+                whb[BF ? 6 + g : 0][j] = to_bf16x8(*reinterpret_cast<const f32x4*>(q), *reinterpret_cast<const f32x4*>(q + 4));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < GP; ++i)
+                wl[((ks * 2 + g) * GP + i) * 64 + lane] = *reinterpret_cast<const f32x4*>(wrow + 16 * (GP * ks + i) + 4 * lq);
+        }
     }
     const float b_att = a.h2att_b[col], b_a0 = a.a2c_b[col], b_a1 = a.a2c_b[H + col];
     // attention: this wave's 64 columns (float4 column col4), lane -> (ac = column quad, rg = region group)
@@ -552,20 +581,32 @@ __global__ __launch_bounds__(KS * 64) void spk_teacher_seq_kernel(TeacherSeqArgs
         if (t > 0) {
             wait_for(cnt + (t - 1) * 3 + 2, TJ);            // h_{t-1} of the strip (slab t of h_all)
             f32x4 af[GP];
+            // (BF: the same four 16-byte loads per lane, as two runs of eight consecutive k: 64 ks + 32 j + 8 lq + 0..7)
 #pragma unroll
             for (int i = 0; i < GP; ++i)
                 af[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                    r_h, (int)(((size_t)mc_t * H + 16 * (GP * ks + i) + 4 * lq_t) * 4), so_h, 16));
+                    r_h, (int)(((size_t)mc_t * H + (BF ? 64 * ks + 32 * (i >> 1) + 8 * lq_t + 4 * (i & 1) : 16 * (GP * ks + i) + 4 * lq_t)) * 4),
+                    so_h, 16));
             f32x4acc acc[6];
 #pragma unroll
             for (int tau = 0; tau < 6; ++tau) acc[tau] = f32x4acc{0.f, 0.f, 0.f, 0.f};
+            if (BF) {
 #pragma unroll
-            for (int i = 0; i < GP; ++i)
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
+                for (int j = 0; j < 2; ++j) {
+                    const bf16x8_t ab = to_bf16x8(af[2 * j], af[2 * j + 1]);
 #pragma unroll
                     for (int tau = 0; tau < 6; ++tau)
-                        acc[tau] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], wh[tau][i][s], acc[tau], 0, 0, 0);
+                        acc[tau] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, whb[BF ? tau : 0][j], acc[tau], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < GP; ++i)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int tau = 0; tau < 6; ++tau)
+                            acc[tau] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], wh[BF ? 0 : tau][i][s], acc[tau], 0, 0, 0);
+            }
 #pragma unroll
             for (int tau = 0; tau < 6; ++tau)
 #pragma unroll
@@ -658,15 +699,25 @@ __global__ __launch_bounds__(KS * 64) void spk_teacher_seq_kernel(TeacherSeqArgs
 #pragma unroll
             for (int i = 0; i < GP; ++i)
                 af[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                    r_res, (int)(((size_t)mc_t * H + 16 * (GP * ks + i) + 4 * lq_t) * 4), so_h, 16));
+                    r_res, (int)(((size_t)mc_t * H + (BF ? 64 * ks + 32 * (i >> 1) + 8 * lq_t + 4 * (i & 1) : 16 * (GP * ks + i) + 4 * lq_t)) * 4),
+                    so_h, 16));
             f32x4acc a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+            if (BF) {
 #pragma unroll
-            for (int i = 0; i < GP; ++i) {
-                const f32x4 b0 = wl[((ks * 2 + 0) * GP + i) * 64 + lane_t], b1 = wl[((ks * 2 + 1) * GP + i) * 64 + lane_t];
+                for (int j = 0; j < 2; ++j) {
+                    const bf16x8_t ab = to_bf16x8(af[2 * j], af[2 * j + 1]);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, whb[BF ? 6 : 0][j], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, whb[BF ? 7 : 0][j], a1, 0, 0, 0);
+                }
+            } else {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], b0[s], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], b1[s], a1, 0, 0, 0);
+                for (int i = 0; i < GP; ++i) {
+                    const f32x4 b0 = wl[((ks * 2 + 0) * GP + i) * 64 + lane_t], b1 = wl[((ks * 2 + 1) * GP + i) * 64 + lane_t];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], b0[s], a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], b1[s], a1, 0, 0, 0);
+                    }
                 }
             }
 #pragma unroll
@@ -1748,9 +1799,12 @@ int cic_resident_cus(const void* kernel, int threads, size_t lds_bytes) {
 }
 int cic_teacher_seq(const TeacherSeqLaunch& L, hipStream_t st) {
     static DeviceOnce attr_set;
-    if (attr_set.first())
-        CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spk_teacher_seq_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (attr_set.first()) {
+        CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spk_teacher_seq_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)TEACHER_LDS_BYTES));
+        CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spk_teacher_seq_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)TEACHER_LDS_BYTES));
+    }
     const int strips = cic_cdiv(L.B, 16);
     // (the hand-off counters were cleared by cic_teacher_tokens, which precedes this launch on the stream)
     TeacherSeqArgs a = {};
@@ -1762,13 +1816,17 @@ int cic_teacher_seq(const TeacherSeqLaunch& L, hipStream_t st) {
     a.hg = handoff_guard(L.sync + (size_t)strips * L.T * 3, L.status, CIC_STATUS_TEACHER);
     a.scale = L.scale; a.B = L.B; a.K = L.K; a.T = L.T;
     // every workgroup of a launch must be resident at once: one per CU, and only where the occupancy query admits one
-    const int cus = cic_resident_cus(reinterpret_cast<const void*>(&spk_teacher_seq_kernel<8>), 512, TEACHER_LDS_BYTES);
+    const int cus = L.bf16 ? cic_resident_cus(reinterpret_cast<const void*>(&spk_teacher_seq_kernel<8, true>), 512, TEACHER_LDS_BYTES)
+                           : cic_resident_cus(reinterpret_cast<const void*>(&spk_teacher_seq_kernel<8, false>), 512, TEACHER_LDS_BYTES);
     const int seq_rows = (cus / 32) * 16;                       // rows one launch can walk with every workgroup resident
     if (seq_rows < 16) { cic_set_error("teacher_seq: fewer than 32 CUs admit the kernel"); return 1; }
     for (int row0 = 0; row0 < L.B; row0 += seq_rows) {          // (B = 128: one launch; B = 256: two row blocks)
         a.row0 = row0;
         a.row_end = row0 + seq_rows < L.B ? row0 + seq_rows : L.B;
-        hipLaunchKernelGGL((spk_teacher_seq_kernel<8>), dim3(cic_cdiv(a.row_end - row0, 16) * 32), dim3(512), TEACHER_LDS_BYTES, st, a);
+        if (L.bf16)
+            hipLaunchKernelGGL((spk_teacher_seq_kernel<8, true>), dim3(cic_cdiv(a.row_end - row0, 16) * 32), dim3(512), TEACHER_LDS_BYTES, st, a);
+        else
+            hipLaunchKernelGGL((spk_teacher_seq_kernel<8, false>), dim3(cic_cdiv(a.row_end - row0, 16) * 32), dim3(512), TEACHER_LDS_BYTES, st, a);
         CIC_LAUNCH_CHECK();
     }
     return 0;

@@ -103,7 +103,7 @@ class AlternatingJointModel(nn.Module):
             cg.embed[0] = self.vse.txt_enc.embed
             cg._flat = None                                             # (a layout made before the tie is stale)
         cg._external = ('embed.0.weight',)
-        cg._external_owner = self.vse
+        object.__setattr__(cg, '_external_owner', self.vse)         # (a plain attribute: not a registered sub-module of the speaker)
         if getattr(self.opt, 'phase', None) == 2:                        # second phase (MLE) only: the table is frozen
             for p in cg.embed.parameters():
                 p.requires_grad = False

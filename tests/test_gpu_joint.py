@@ -326,3 +326,19 @@ def test_mle_step_at_edge_batch_sizes_matches_oracle(B, ragged):
                                 is_alternating=0)
     n = _full_size_step(opt, None, {'mle': None}, logged_close=('loss_cap',), ragged=ragged)
     assert n >= 16
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('turn', ['speaker', 'listener'])
+def test_joint_step_bf16_variant_full_size_vs_f32_oracle(turn):
+    """The joint step in the reduced-precision variant (--compute_dtype bf16: bf16 operands in the batched products, bf16
+    region features, and - r4 - the speaker's one-launch recurrences on bf16 MFMA fragments), against the f32 oracle at the
+    tolerance of the MLE variant test: loss 2e-3 relative, every parameter gradient within 3e-2 of its norm.  The
+    configuration is the one whose token ids do not depend on the arithmetic: REINFORCE with the ground-truth baseline and
+    INJECTED multinomial draws, CIDEr term off (a greedy or Gumbel arg-max over 9488 bf16-perturbed logits may legitimately pick
+    another token than the f32 oracle, after which the two losses are losses of different captions)."""
+    from cooperativeimagecaptioning_amd import synthetic
+    opt = synthetic.default_opt(batch_size=128, retrieval_reward='reinforce', reinforce_baseline_type='gt', vse_loss_weight=1.0,
+                                cider_optimization=0, retrieval_reward_weight=1.0, compute_dtype='bf16')
+    n = _full_size_step(opt, turn, {'sample': 'pick'}, loss_rtol=2e-3, grad_tol=3e-2)
+    assert n >= (14 if turn == 'speaker' else 6)
