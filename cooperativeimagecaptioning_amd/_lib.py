@@ -48,7 +48,8 @@ class GemmArgs(C.Structure):
                 ('epi', c_ptr),        # fused vocabulary epilogue (the decode engine's logit product); NULL here
                 ('precision', C.c_int),   # 0 f32 accuracy (default), 1 f32-input MFMA only, 2 bf16 operands
                 ('B_parts', c_ptr),       # B pre-split by cic_split_bf16x3 (the logit weights), or NULL
-                ('live', c_ptr), ('live_b', c_ptr), ('live_min', C.c_int)]   # decode-loop early stop (engines only); NULL here
+                ('live', c_ptr), ('live_b', c_ptr), ('live_min', C.c_int),   # decode-loop early stop (engines only); NULL here
+                ('B2_parts', c_ptr), ('B2_tail_parts', c_ptr)]               # bf16 images of B2 / B2_tail (CIC_PRECISION_BF16) or NULL
 
 
 class SamplerArgs(C.Structure):

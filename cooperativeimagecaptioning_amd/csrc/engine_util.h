@@ -33,6 +33,7 @@ struct SpkWs {
     uint16_t *att_bf, *p_att_bf;              // bf16 copies of att / p_att (compute_dtype bf16 only)
     float *part, *lse_all;                    // row partials of one step's logits [6][B][nparts]; [T,B] log-sum-exp rows
     uint16_t* logit_parts;                    // [3][V+1][H] bf16: the logit weights cut into their parts once per decode
+    uint16_t* gate_parts;                     // compute_dtype bf16: bf16 images of i2h [5H,E], h2h [5H,H], h2att [A,H], once per decode
     unsigned* tsync;                          // spk_teacher_seq_kernel: [strips of 16 rows][T][3] hand-off counters + error word
     size_t bytes;
 };

@@ -1269,7 +1269,9 @@ __global__ __launch_bounds__(KS * 64) void gemm_walk16_kernel(cic_gemm_args g, i
 // gemm_walk16_kernel<8, 8, false>; K slice per wave = 128 = 4 k-steps of 32 (Kt == 1024, K1 % 32 == 0: no K padding).
 //   operand layout: lane l -> (i = l & 15, q = l >> 4); A: row i, k = 32 j + 8 q + 0..7 for k-step j (two dwordx4);
 //   B: column i likewise; D: 4 registers v: row 4q + v, column i.
-template <int KS>
+// NP = 1 (r4, CIC_PRECISION_BF16): one bf16 part per operand, one MFMA per k-step.  B_parts / B2_parts / B2_tail_parts (bf16
+// images of the three weight matrices, cic_round_bf16) replace the f32 weights where given: half the streamed bytes.
+template <int KS, int NP>
 __global__ __launch_bounds__(KS * 64) void gemm_walk16bf_kernel(cic_gemm_args g, int strips) {
     static_assert(KS == 8, "8 accumulator registers (2 row tiles x 4) dealt one per wave");
     constexpr int JS = 4;                                   // k-steps per wave
@@ -1289,14 +1291,14 @@ __global__ __launch_bounds__(KS * 64) void gemm_walk16bf_kernel(cic_gemm_args g,
     const int K1 = g.K;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     if (gemm_skipped(g)) return;                            // every caption has ended (grid-uniform)
-    auto parts8 = [](const f32x4 lo, const f32x4 hi, bf16x8 (&dst)[3][JS], int j) {
-        bf16x4 pl[3], ph[3];
-        split_bf16<3>(lo, pl);
-        split_bf16<3>(hi, ph);
+    auto parts8 = [](const f32x4 lo, const f32x4 hi, bf16x8 (&dst)[NP][JS], int j) {
+        bf16x4 pl[NP], ph[NP];
+        split_bf16<NP>(lo, pl);
+        split_bf16<NP>(hi, ph);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) dst[p][j] = __builtin_shufflevector(pl[p], ph[p], 0, 1, 2, 3, 4, 5, 6, 7);
+        for (int p = 0; p < NP; ++p) dst[p][j] = __builtin_shufflevector(pl[p], ph[p], 0, 1, 2, 3, 4, 5, 6, 7);
     };
-    bf16x8 ap[2][3][JS];
+    bf16x8 ap[2][NP][JS];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
         const int m = m0 + 16 * rt + li;
@@ -1312,9 +1314,31 @@ __global__ __launch_bounds__(KS * 64) void gemm_walk16bf_kernel(cic_gemm_args g,
         }
     }
     f32x4 raw[2 * JS];
+    // the weights as bf16 images (NP == 1 only): one 16-byte load per k-step instead of two, no conversion
+    const bool img = NP == 1 && g.B_parts && g.B2_parts && (g.n_split == 0 || g.B2_tail_parts);
+    bf16x8 rawh[NP == 1 ? JS : 1];
     // column split (see cic.h): tiles at or beyond n_split take the second operand pair only, from B2_tail
     const int split_t = g.n_split > 0 ? g.n_split / 16 : tiles_n;
     auto load_raw = [&](int t) {
+        if (NP == 1 && img) {
+            const int tt = t < tiles_n ? t : tiles_n - 1;
+            const int n = tt * 16 + li;
+            const bool nok = t < tiles_n && n < g.N;
+            const int nc = n < g.N ? n : g.N - 1;
+            const bool tail = tt >= split_t;
+#pragma unroll
+            for (int j = 0; j < JS; ++j) {
+                const int k0 = 32 * (ks * JS + j);
+                const bool second = k0 >= K1;
+                const uint16_t* B = second ? (tail ? g.B2_tail_parts : g.B2_parts) : g.B_parts;
+                const int ldb = second ? (tail ? g.ldb2_tail : g.ldb2) : g.ldb;
+                const int row = tail ? nc - g.n_split : nc;
+                const bool use = nok && (second || !tail);
+                const uint16_t* pb = use ? B + (size_t)row * ldb + (second ? k0 - K1 : k0) + 8 * lq : reinterpret_cast<const uint16_t*>(g_zero16);
+                rawh[NP == 1 ? j : 0] = *reinterpret_cast<const bf16x8*>(pb);
+            }
+            return;
+        }
         const int tt = t < tiles_n ? t : tiles_n - 1;
         const int n = tt * 16 + li;
         const bool nok = t < tiles_n && n < g.N;
@@ -1348,15 +1372,22 @@ __global__ __launch_bounds__(KS * 64) void gemm_walk16bf_kernel(cic_gemm_args g,
         if (tail) { if (g.bias_tail) bias_v = g.bias_tail[ncl - g.n_split]; }
         else if (g.bias) bias_v = g.bias[ncl];
         if (g.accumulate && !tail) cold = gC[(size_t)mcl * g.ldc + ncl];
-        bf16x8 bp[3][JS];
+        bf16x8 bp[NP][JS];
+        if (NP == 1 && img) {
 #pragma unroll
-        for (int j = 0; j < JS; ++j) parts8(raw[2 * j], raw[2 * j + 1], bp, j);
+            for (int j = 0; j < JS; ++j) bp[0][j] = rawh[NP == 1 ? j : 0];
+        } else {
+#pragma unroll
+            for (int j = 0; j < JS; ++j) parts8(raw[2 * j], raw[2 * j + 1], bp, j);
+        }
         load_raw(t + step);                             // next tile in flight under the MFMAs and the cross-wave sum
         f32x4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        // part products with pa + pb <= 2, smallest first (parts 0 / 1 / 2 carry bits 1-8 / 9-16 / 17-24)
-        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+        // part products with pa + pb <= 2, smallest first (parts 0 / 1 / 2 carry bits 1-8 / 9-16 / 17-24); NP = 1: the one product
+        constexpr int NC = NP == 3 ? 6 : 1;
+        constexpr int PA[6] = {NP == 3 ? 0 : 0, NP == 3 ? 2 : 0, NP == 3 ? 1 : 0, 0, NP == 3 ? 1 : 0, 0};
+        constexpr int PB[6] = {NP == 3 ? 2 : 0, 0, NP == 3 ? 1 : 0, NP == 3 ? 1 : 0, 0, 0};
 #pragma unroll
-        for (int c = 0; c < 6; ++c)
+        for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int j = 0; j < JS; ++j) {
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[0][PA[c]][j], bp[PB[c]][j], acc0, 0, 0, 0);
@@ -2203,8 +2234,10 @@ int launch_rega(const cic_gemm_args& g, hipStream_t st) {
         if (nb < 1) nb = 1;
         // f32 results either way: three bf16 parts per operand (2.67x the MFMA rate) unless the caller asks for the
         // f32-input instruction
-        if (g_bfx && g.precision != CIC_PRECISION_F32_MFMA && (g.K % 32) == 0)
-            hipLaunchKernelGGL((gemm_walk16bf_kernel<8>), dim3(strips * nb), dim3(512), 0, st, g, strips);
+        if (g_bfx && g.precision == CIC_PRECISION_BF16 && (g.K % 32) == 0)
+            hipLaunchKernelGGL((gemm_walk16bf_kernel<8, 1>), dim3(strips * nb), dim3(512), 0, st, g, strips);
+        else if (g_bfx && g.precision != CIC_PRECISION_F32_MFMA && (g.K % 32) == 0)
+            hipLaunchKernelGGL((gemm_walk16bf_kernel<8, 3>), dim3(strips * nb), dim3(512), 0, st, g, strips);
         else
             hipLaunchKernelGGL((gemm_walk16_kernel<8, 8, false>), dim3(strips * nb), dim3(512), 0, st, g, strips);
         CIC_LAUNCH_CHECK();

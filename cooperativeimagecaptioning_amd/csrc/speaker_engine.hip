@@ -119,6 +119,7 @@ SpkWs spk_carve(const cic_speaker_dims& d, void* base) {
     w.part = c.f32((size_t)CIC_PART_PLANES * CIC_PART_MAX_ENTRIES);
     w.lse_all = c.f32(T * B);
     w.logit_parts = c.u16(3 * V1 * H);
+    w.gate_parts = c.u16(5 * H * E + 5 * H * H + A * H);
     w.tsync = reinterpret_cast<unsigned*>(c.i32((((B + 15) / 16) * T * 3 + 1 + 3) / 4 * 4));
     w.bytes = c.used();
     return w;
@@ -319,7 +320,20 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     // The logit weights are read unchanged by every step's logit product: cut them into their three bf16 parts once per
     // decode (8 us) instead of once per weight tile and workgroup inside the walker (cic_gemm_args.B_parts; bit-identical)
     const bool presplit_logit = !teacher_batched && !ps && H == 512 && V1 >= 2048 && ((size_t)V1 * H) % 4 == 0;   // the walker's shapes
-    if (presplit_logit) RUN(cic_split_bf16x3(p->logit_w, (int64_t)V1 * H, w[0].logit_parts, s));
+    // compute_dtype bf16: ONE part - the logit weights and the three gate matrices as packed bf16 images, made once per decode;
+    // the per-timestep products then stream 2 bytes per weight and issue one MFMA per k-step
+    if (presplit_logit) RUN(bf ? cic_round_bf16(p->logit_w, (int64_t)V1 * H, w[0].logit_parts, s)
+                               : cic_split_bf16x3(p->logit_w, (int64_t)V1 * H, w[0].logit_parts, s));
+    const bool gate_img = bf && !fc && !teacher_seq && (((size_t)5 * H * E) % 8) == 0 && (((size_t)5 * H * H) % 8) == 0 && (((size_t)A * H) % 4) == 0 &&
+                          (E % 8) == 0 && (H % 8) == 0;
+    uint16_t* img_i2h = w[0].gate_parts;
+    uint16_t* img_h2h = img_i2h + (size_t)5 * H * E;
+    uint16_t* img_h2att = img_h2h + (size_t)5 * H * H;
+    if (gate_img) {
+        RUN(cic_round_bf16(p->i2h_w, (int64_t)5 * H * E, img_i2h, s));
+        RUN(cic_round_bf16(p->h2h_w, (int64_t)5 * H * H, img_h2h, s));
+        RUN(cic_round_bf16(p->h2att_w, (int64_t)A * H, img_h2att, s));
+    }
     bool early_stop = g_early_stop && !fc && !ps && !teacher_batched;
     for (int q = 0; q < nb; ++q) early_stop = early_stop && !io[q]->first_token;
     bool len_in_sampler = !ps && !teacher_batched && !teacher_seq;
@@ -368,6 +382,8 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
             g.C = pre.a; g.ldc = 5 * H; g.bias = w[0].bias_ih;
             g.n_split = 5 * H; g.B2_tail = p->h2att_w; g.ldb2_tail = H; g.bias_tail = p->h2att_b;
             g.C_tail = att_h.a; g.C_tail_b = att_h.b; g.ldc_tail = A;
+            if (bf) g.precision = CIC_PRECISION_BF16;
+            if (gate_img) { g.B_parts = img_i2h; g.B2_parts = img_h2h; g.B2_tail_parts = img_h2att; }
             if (nb == 2) { g.rows_blk = B; g.A_b = x.b; g.A2_b = h.b; g.C_b = pre.b; }
             g.live = live.a; g.live_b = live.b;
             if (g_gates_att_fused && cic_gemm_split_ok(&g)) {
@@ -426,6 +442,7 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         lg.M = M; lg.N = V1; lg.K = H; lg.A = out.a; lg.lda = H; lg.a_kc = 1; lg.B = p->logit_w; lg.ldb = H; lg.b_kc = 1;
         lg.C = logp.a; lg.ldc = V1; lg.bias = p->logit_b;
         if (presplit_logit) lg.B_parts = w[0].logit_parts;
+        if (bf) lg.precision = CIC_PRECISION_BF16;
         if (nb == 2) { lg.rows_blk = B; lg.A_b = out.b; lg.C_b = logp.b; }
         lg.live = live.a; lg.live_b = live.b;
         cic_logit_epilogue epi = {};

@@ -25,6 +25,7 @@ _gemm = _sig('cic_gemm_f32', [C.POINTER(GemmArgs), P])
 _sig('cic_gemm_logit_parts', [C.POINTER(GemmArgs)])
 _sig('cic_gemm_split_ok', [C.POINTER(GemmArgs)])
 _split3 = _sig('cic_split_bf16x3', [P, L64, P, P])
+_round1 = _sig('cic_round_bf16', [P, L64, P, P])
 _sig('cic_gemm_f32_timed', [C.POINTER(GemmArgs), I, C.POINTER(C.c_double), P])
 _sig('cic_logit_partials', [P, I, I, I, P, I, P])
 _sig('cic_attn_fwd_timed', [P] * 7 + [I] * 5 + [P, L64, C.POINTER(C.c_double), P])
@@ -68,6 +69,12 @@ def split_bf16x3_(x, parts):
     """parts (int16 / uint16 view, 3 * x.numel() elements) <- the three bf16 parts of f32 x."""
     check(_split3(ptr(_dev(x)), x.numel(), ptr(_dev(parts)), stream()), 'cic_split_bf16x3')
     return parts
+
+
+def round_bf16_(x, packed):
+    """packed (int16 / uint16 view, x.numel() elements) <- bf16(x), round to nearest even."""
+    check(_round1(ptr(_dev(x)), x.numel(), ptr(_dev(packed)), stream()), 'cic_round_bf16')
+    return packed
 
 
 def gemm(A, B, C_, a_kc=True, b_kc=True, bias=None, accumulate=False, relu=False, A2=None, B2=None,

@@ -156,6 +156,11 @@ typedef struct {
     const int32_t* live;
     const int32_t* live_b;
     int live_min;
+    /* CIC_PRECISION_BF16 only (optional): B2 and B2_tail as packed bf16 images (cic_round_bf16), beside B_parts holding ONE image
+     * of B - the per-timestep gate product of a decode then streams 2 bytes per weight.  Same leading dimensions as the f32
+     * matrices.  NULL: the f32 matrices are read and rounded on the fly. */
+    const uint16_t* B2_parts;
+    const uint16_t* B2_tail_parts;
 } cic_gemm_args;
 enum { CIC_PRECISION_F32 = 0, CIC_PRECISION_F32_MFMA = 1, CIC_PRECISION_BF16 = 2 };
 /* Row partials of the vocabulary: the columns of a row are dealt to `nparts` parts; a part reduces its columns
@@ -186,6 +191,8 @@ int cic_gemm_f32(const cic_gemm_args* a, cic_stream_t s);
 /* x[i] = p0 + p1 + p2 with p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1) (round to nearest even; the residuals
  * are exact): parts[0..n), [n..2n), [2n..3n) - the split every bf16-part kernel applies to its operands on the fly. */
 int cic_split_bf16x3(const float* x, int64_t n, uint16_t* parts, cic_stream_t s);
+/* packed[i] = bf16(x[i]), round to nearest even: the one-part operand image of CIC_PRECISION_BF16 (n % 4 == 0) */
+int cic_round_bf16(const float* x, int64_t n, uint16_t* packed, cic_stream_t s);
 /* number of parts per row the fused epilogue of cic_gemm_f32 writes for these arguments; 0: not fused for them */
 int cic_gemm_logit_parts(const cic_gemm_args* a);
 /* the same partials from logits already in memory (any shape): rows of `logits` [M, ld], nparts parts of contiguous
