@@ -144,7 +144,8 @@ def test_paired_decodes_equal_sequential_decodes(B, dims):
     lse_b = (T * B * 4 + 255) // 256 * 256
     parts_b = (3 * (d.V + 1) * d.H * 2 + 255) // 256 * 256
     tsync_b = ((((B + 15) // 16) * T * 3 + 1 + 3) // 4 * 4 * 4 + 255) // 256 * 256     # hand-off counters of the teacher-forced kernel
-    tail = 6 * 16384 * 4 + lse_b + parts_b + tsync_b
+    gate_b = ((5 * d.H * d.E + 5 * d.H * d.H + d.A * d.H) * 2 + 255) // 256 * 256      # bf16 weight images of the bf16 variant (unused here)
+    tail = 6 * 16384 * 4 + lse_b + parts_b + gate_b + tsync_b
     for x, y in ((a0, a1), (b0, b1)):
         for k in ('seq', 'L'):
             assert torch.equal(x[k], y[k]), k
