@@ -245,6 +245,9 @@ def main():
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N > 1: 'nccl' (= RCCL over xGMI, the "
                     "default) or 'gloo' (rehearsal of the multi-process path on a box with fewer GPUs than ranks)")
     ap.add_argument('--same-device', action='store_true', help='rehearsal: every rank uses cuda:0 (gloo backend only)')
+    ap.add_argument('--compute-dtype', default='f32', choices=['f32', 'bf16'],
+                    help="'f32' (default: the reference's arithmetic - THE bench line) or 'bf16': the reduced-precision variant "
+                         "(profiling only: its line says dtype bf16 and is not the headline)")
     args = ap.parse_args()
 
     if os.environ.get('CIC_HANG_DUMP'):          # diagnostics: Python stacks of every thread after N seconds, then exit
@@ -282,7 +285,7 @@ def main():
     from cooperativeimagecaptioning_amd import models, optimizer as optim, synthetic, engine, status
     from cooperativeimagecaptioning_amd.misc import rewards
 
-    opt = synthetic.default_opt(batch_size=args.batch)
+    opt = synthetic.default_opt(batch_size=args.batch, compute_dtype=args.compute_dtype)
     torch.manual_seed(0)                       # identical initial weights on every rank
     rewards.init_scorer('corpus')
     model = models.AlternatingJointModel(opt).to(dev).train()
@@ -394,7 +397,7 @@ def main():
             'median_ms_per_step': median_ms,
             'host_enqueue_ms_per_step': host_ms, 'device_behind_host_ms': {'first': ahead[0], 'median': sorted(ahead)[len(ahead) // 2],
                                                                           'last': ahead[-1]},
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.compute_dtype, 'data': 'synthetic',
             'config': {'workload': 'AlternatingJointModel joint step, att2in2 speaker + VSE-fc listener, ST-Gumbel '
                                    'tau=1 + self-critical CIDEr-D, 36x2048 att_feats, vocab 9487, seq_len 16, '
                                    'dropout 0.5, clamp 0.1 + Adam both agents (BASELINE configs[2])',

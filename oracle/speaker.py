@@ -35,7 +35,23 @@ def att_embed(P, att_raw, keep, p, att_masks=None):
     len_b = sum_k att_masks[b, k] region rows of every image (sort_pack_padded_sequence :30-36), applies the
     module to the packed rows only and pads back with zeros (pad_unsort_packed_sequence :38-41): rows k >= len_b
     of the embedded features are exactly 0 (not relu(bias)), and the keep mask covers the packed rows only."""
-    y = F.linear(att_raw, P['att_embed.0.weight'], P['att_embed.0.bias'])
+    lin = 'att_embed.0'
+    if 'att_embed.1.weight' in P:
+        # use_bn = 1 (:82-85): BatchNorm1d(att_feat_size) in front of the Linear.  pack_wrapper hands the module the PACKED valid
+        # region rows [N, D], so the batch statistics run over an image's own regions only; training mode: biased variance
+        # in the normalisation (eps 1e-5), as torch.nn.functional.batch_norm.  Without att_masks the reference feeds the 3-D
+        # [B, K, D] tensor, which BatchNorm1d(D) rejects (K channels): the option cannot run there, and does not here.
+        if att_masks is None:
+            raise ValueError('use_bn = 1 needs att_masks: BatchNorm1d(att_feat_size) rejects the unpacked [B, K, D] features')
+        valid_rows = att_masks > 0
+        x = att_raw[valid_rows]                                      # [N, D] (the statistics do not depend on the row order)
+        if P.get('_bn_training', True):
+            mean, var = x.mean(0), x.var(0, unbiased=False)
+        else:
+            mean, var = P['att_embed.0.running_mean'], P['att_embed.0.running_var']
+        att_raw = (att_raw - mean) / torch.sqrt(var + 1e-5) * P['att_embed.0.weight'] + P['att_embed.0.bias']
+        lin = 'att_embed.1'
+    y = F.linear(att_raw, P[lin + '.weight'], P[lin + '.bias'])
     y = dropout(torch.relu(y), keep, p)
     if att_masks is not None:
         lens = att_masks.long().sum(1)

@@ -767,9 +767,10 @@ def main():
             sample_case(name, rr, kw, opts_, eos)
 
     # ------------------------------------------------------------------ S2 MLE
-    def mle_case(name, kw, ss, masked=False):
+    def mle_case(name, kw, ss, masked=False, seed=3):
+        # (seed: a model with other state-dict keys - use_bn = 1 - takes a base-weight file of its own)
         opt = make_opt(**kw)
-        m = build(opt, 3)
+        m = build(opt, seed)
         cg = m.caption_generator
         cg.train()
         cg.ss_prob = ss
@@ -788,7 +789,12 @@ def main():
         if 'ps_u' in nd:
             nd['ss_u'] = nd.pop('ps_u')
         grads = digests((k, p.grad) for k, p in cg.named_parameters() if p.grad is not None)
-        save(name, **weights_of(m._wkey, cg, 'caption_generator.'), **opt_np(opt), **flat_noise('noise', nd), **grads, loss=loss,
+        # use_bn = 1: the running statistics AFTER this one training-mode forward (momentum 0.1, unbiased variance)
+        after = {'after.' + k: v.detach().numpy().copy() for k, v in cg.state_dict().items() if 'running_' in k or 'num_batches' in k}
+        cfg = opt_np(opt)
+        if getattr(opt, 'use_bn', 0):
+            cfg['cfg.use_bn'] = np.float64(1)
+        save(name, **weights_of(m._wkey, cg, 'caption_generator.'), **cfg, **flat_noise('noise', nd), **grads, **after, loss=loss,
              ss_prob=np.float64(ss), att_raw=batch['att_feats'], fc=batch['fc_feats'], att_masks=am,
              labels=batch['labels'], masks=batch['masks'])
 
@@ -1041,6 +1047,9 @@ def main():
         save('clamp_adam', p0=p0, grads=torch.stack(gs), traj=torch.stack(traj), lr=np.float64(5e-4),
              grad_clip=np.float64(0.1))
     JOINT_MASKED = [('masked_joint_gumbel', dict(retrieval_reward='gumbel', drop_prob_lm=0.5), 'speaker', 2.5)]
+    if '--only-bn' in sys.argv:      # use_bn = 1 on ragged region counts (the only input the option can run on, AttModel.py:44-51,82-85)
+        mle_case('bn_masked_mle', {'drop_prob_lm': 0.5, 'use_bn': 1}, 0.0, masked=True, seed=33)
+        return
     if not only_masks:
         kernel_cases()
         listener_cases()
@@ -1056,6 +1065,7 @@ def main():
     for name, rr, kw, opts_, eos in SAMPLE_MASKED:
         sample_case(name, rr, kw, opts_, eos, masked=True)
     mle_case('masked_mle', {'drop_prob_lm': 0.5}, 0.0, masked=True)
+    mle_case('bn_masked_mle', {'drop_prob_lm': 0.5, 'use_bn': 1}, 0.0, masked=True, seed=33)
     for name, kw, turn, eos in JOINT_MASKED:
         joint_case(name, kw, turn, eos, masked=True)
     gen_beam(torch, models, rec, BEAM_CASES_MASKED)
