@@ -378,6 +378,37 @@ def clamp_adam(p, g, m, v, lr, step, grad_clip=0.1, betas=(0.9, 0.999), eps=1e-8
                                      status.ptr(p.device) if guarded else None, stream()), 'cic_clamp_adam_guarded')
 
 
+# ---- use_bn: BatchNorm1d folded into att_embed's Linear (cic.h, csrc/batchnorm.hip) ----------------------------------
+lib.cic_bn_stats.argtypes = [P, P, C.c_int, C.c_int, P, P, P, P]
+lib.cic_bn_running_update.argtypes = [P, P, P, C.c_float, C.c_int, P, P, P]
+lib.cic_bn_fold_fwd.argtypes = [P] * 6 + [C.c_float, C.c_int, C.c_int, P, P, P]
+lib.cic_bn_fold_bwd.argtypes = [P] * 7 + [C.c_float, C.c_int, C.c_int, P, P, P, P, P]
+for _f in (lib.cic_bn_stats, lib.cic_bn_running_update, lib.cic_bn_fold_fwd, lib.cic_bn_fold_bwd):
+    _f.restype = C.c_int
+
+
+def bn_stats(x, masks, rows, D, mean, var, count):
+    assert x.is_contiguous() and masks.is_contiguous() and masks.numel() == rows and x.numel() == rows * D
+    check(lib.cic_bn_stats(_p(x), _p(masks), rows, D, _p(mean), _p(var), _p(count), stream()), 'cic_bn_stats')
+
+
+def bn_running_update(mean, var, count, momentum, running_mean, running_var):
+    check(lib.cic_bn_running_update(_p(mean), _p(var), _p(count), float(momentum), mean.numel(), _p(running_mean),
+                                    _p(running_var), stream()), 'cic_bn_running_update')
+
+
+def bn_fold_fwd(W, bias, gamma, beta, mean, var, eps, W_folded, bias_folded):
+    H, D = W.shape
+    check(lib.cic_bn_fold_fwd(_p(W), _p(bias), _p(gamma), _p(beta), _p(mean), _p(var), float(eps), H, D, _p(W_folded),
+                              _p(bias_folded), stream()), 'cic_bn_fold_fwd')
+
+
+def bn_fold_bwd(dW_raw, db_raw, W, gamma, beta, mean, var, eps, dW, dbias, dgamma, dbeta):
+    H, D = W.shape
+    check(lib.cic_bn_fold_bwd(_p(dW_raw), _p(db_raw), _p(W), _p(gamma), _p(beta), _p(mean), _p(var), float(eps), H, D,
+                              _p(dW), _p(dbias), _p(dgamma), _p(dbeta), stream()), 'cic_bn_fold_bwd')
+
+
 TIMED_IDS = {'attn_fwd': 0, 'logit_gemm': 1, 'attn_bwd': 2, 'sampler': 3}
 lib.cic_timer_create.restype = C.c_void_p
 lib.cic_timer_destroy.argtypes = [C.c_void_p]

@@ -163,7 +163,7 @@ class AlternatingJointModel(nn.Module):
         T = cg.seq_length
         terms = []          # (weight, device scalar)
         bwd_steps = []      # closures run in order by backward(go)
-        att_pre = cg.att_embed_pre(att_feats)
+        att_pre = cg.att_embed_pre(att_feats, att_masks)
         cw, vw, dw, ciw = self.caption_loss_weight, self.vse_loss_weight, self.retrieval_reward_weight, self.cider_optimization
 
         # MLE (ce_loss :196-207)

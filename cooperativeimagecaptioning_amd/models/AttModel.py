@@ -76,8 +76,6 @@ class AttModel(nn.Module):
         self.prob_gumbel_softmax = getattr(opt, 'prob_gumbel_softmax', 1)
         self.prob_multinomial_soft = getattr(opt, 'prob_multinomial_soft', 1)
         self.use_bn = getattr(opt, 'use_bn', 0)
-        if self.use_bn:
-            raise NotImplementedError('use_bn=1 (BatchNorm1d in att_embed) is outside the MI355X hot path')
         if self.num_layers != 1:
             raise NotImplementedError('att2in2 is a single-layer maxout LSTM (models/AttModel.py:492-531)')
         self.ss_prob = 0.0
@@ -86,14 +84,19 @@ class AttModel(nn.Module):
                                    nn.Dropout(self.drop_prob_lm))
         self.relu_dropout = nn.Sequential(nn.ReLU(), nn.Dropout(self.drop_prob_lm))
         _ = nn.Linear(self.fc_feat_size, self.rnn_size)   # fc_embed: created then deleted by Att2in2Model (:538)
-        self.att_embed = nn.Sequential(nn.Linear(self.att_feat_size, self.rnn_size), nn.ReLU(),
-                                       nn.Dropout(self.drop_prob_lm))
+        # use_bn: BatchNorm1d over the packed valid region rows in front of the Linear (AttModel.py:82-85): state-dict keys
+        # att_embed.0 = the norm (weight, bias, running_mean, running_var, num_batches_tracked), att_embed.1 = the Linear
+        self.att_embed = nn.Sequential(*(((nn.BatchNorm1d(self.att_feat_size),) if self.use_bn else ()) +
+                                         (nn.Linear(self.att_feat_size, self.rnn_size), nn.ReLU(),
+                                          nn.Dropout(self.drop_prob_lm))))
         self.logit = nn.Linear(self.rnn_size, self.vocab_size + 1)
         self.ctx2att = nn.Linear(self.rnn_size, self.att_hid_size)
         self.decoding_constraint = getattr(opt, 'decoding_constraint', 0)
         # 'f32': the reference's arithmetic.  'bf16': the reduced-precision variant of BASELINE configs[1] (cic.h,
         # cic_speaker_dims.compute_dtype): bf16 operands in the batched products, bf16 storage of the region features
         self.compute_dtype = getattr(opt, 'compute_dtype', 'f32') or 'f32'
+        if self.use_bn and self.compute_dtype != 'f32':
+            raise NotImplementedError('use_bn=1 is built for compute_dtype f32 only')
         self._loss = {}
         self._flat = None
         self.noise = NoiseSource()
@@ -125,15 +128,88 @@ class AttModel(nn.Module):
                                 str(att_feats.device) + ' (there is no CPU fallback path)')
         assert att_feats.dim() == 3 and att_feats.shape[2] == self.att_feat_size
 
-    def att_embed_pre(self, att_feats):
+    # ---- use_bn: BatchNorm1d folded into att_embed's Linear (csrc/batchnorm.hip) ------------------
+    def _bn_buffers(self, dev):
+        D, H = self.att_feat_size, self.rnn_size
+        g = lambda k, shape: self._buf.get(('bn', k), shape, torch.float32, dev)
+        return dict(mean=g('mean', (D,)), var=g('var', (D,)), count=g('count', (1,)), Wf=g('Wf', (H, D)), bf=g('bf', (H,)),
+                    dW=g('dW', (H, D)), db=g('db', (H,)))
+
+    def _bn_masks(self, att_feats, att_masks):
+        if att_masks is None:
+            # the reference feeds a [B,K,D] tensor to BatchNorm1d then (pack_wrapper, AttModel.py:44-51): a shape error
+            raise ValueError('use_bn=1 normalises the packed valid region rows: att_masks is required')
+        return self._buf.stage('att_masks', att_masks, torch.float32)
+
+    def _bn_stats(self, att_raw, att_masks):
+        """Statistics of this batch's valid region rows (training mode) or the running ones (eval), then the fold."""
+        bn, lin = self.att_embed[0], self.att_embed[1]
+        b = self._bn_buffers(att_raw.device)
+        rows = att_raw.shape[0] * att_raw.shape[1]
+        if self.training:
+            engine.bn_stats(att_raw, att_masks, rows, self.att_feat_size, b['mean'], b['var'], b['count'])
+            mean, var = b['mean'], b['var']
+        else:
+            mean, var = bn.running_mean, bn.running_var
+        engine.bn_fold_fwd(lin.weight.data, lin.bias.data, bn.weight.data, bn.bias.data, mean, var, bn.eps, b['Wf'], b['bf'])
+        self._bn_used = (mean, var)
+
+    def _bn_tick(self):
+        """One reference forward in training mode = one update of the running statistics (every decode of a step runs
+        att_embed again there; here they share one evaluation)."""
+        if self.use_bn and self.training:
+            bn, b = self.att_embed[0], self._bn_buffers(self.att_embed[1].weight.device)
+            engine.bn_running_update(b['mean'], b['var'], b['count'], bn.momentum, bn.running_mean, bn.running_var)
+            bn.num_batches_tracked += 1
+
+    def _speaker_tensors(self, fl):
+        """The engine's parameter pointers under the reference's non-bn names; use_bn: att_embed = the folded Linear."""
+        t = fl.tensors()
+        if not self.use_bn:
+            return t
+        b = self._bn_buffers(self.att_embed[1].weight.device)
+        t = dict(t)
+        t['att_embed.0.weight'], t['att_embed.0.bias'] = b['Wf'], b['bf']
+        return t
+
+    def _speaker_grads(self, fl):
+        """Gradient targets of one backward; use_bn: the Linear's raw gradients land in zeroed scratch (_bn_backward)."""
+        g = fl.grad_tensors()
+        if not self.use_bn:
+            return g
+        b = self._bn_buffers(self.att_embed[1].weight.device)
+        self._bn_targets = (g['att_embed.1.weight'], g['att_embed.1.bias'], g['att_embed.0.weight'], g['att_embed.0.bias'])
+        g = dict(g)
+        if self._bn_targets[0] is None:                  # a frozen speaker: no att_embed gradient at all (null pointers)
+            g['att_embed.0.weight'] = g['att_embed.0.bias'] = None
+            return g
+        b['dW'].zero_(), b['db'].zero_()
+        g['att_embed.0.weight'], g['att_embed.0.bias'] = b['dW'], b['db']
+        return g
+
+    def _bn_backward(self):
+        if not self.use_bn:
+            return
+        bn, lin = self.att_embed[0], self.att_embed[1]
+        b = self._bn_buffers(lin.weight.device)
+        dW, dbias, dgamma, dbeta = self._bn_targets
+        if dW is None:
+            return
+        mean, var = self._bn_used
+        engine.bn_fold_bwd(b['dW'], b['db'], lin.weight.data, bn.weight.data, bn.bias.data, mean, var, bn.eps, dW, dbias,
+                           dgamma, dbeta)
+
+    def att_embed_pre(self, att_feats, att_masks=None):
         """relu(att_embed(att_feats)) before the dropout — computed once per training step and shared
-        by all decodes of the step (AttModel.py:315; their dropout masks differ)."""
+        by all decodes of the step (AttModel.py:315; their dropout masks differ).  att_masks: needed by use_bn only."""
         self._check_inputs(att_feats)
         fl = self.flat()
         B, K, _ = att_feats.shape
         dims = self._dims(B, K, self.seq_length)
-        params = engine.speaker_params(fl.tensors())
         att_raw = self._buf.stage('att_raw', att_feats, torch.float32)
+        if self.use_bn:
+            self._bn_stats(att_raw, self._bn_masks(att_feats, att_masks))
+        params = engine.speaker_params(self._speaker_tensors(fl))
         self._staged_att, self._staged_raw = att_feats, att_raw     # the decodes of this step reuse the staged tensor
         att_pre = self._buf.get('att_pre', (B, K, self.rnn_size), torch.float32, att_raw.device)
         return engine.speaker_att_embed_fwd(dims, params, att_raw, att_pre)
@@ -166,12 +242,16 @@ class AttModel(nn.Module):
         B, K, _ = att_feats.shape
         T = T or self.seq_length
         dims = self._dims(B, K, T)
-        params = engine.speaker_params(fl.tensors())
         if att_pre is not None and getattr(self, '_staged_att', None) is att_feats:
             att_raw = self._staged_raw                                   # staged by att_embed_pre
         else:
             att_raw = self._buf.stage('att_raw', att_feats, torch.float32)
             self._staged_att = None
+        if self.use_bn:
+            if att_pre is None:
+                self._bn_stats(att_raw, self._bn_masks(att_feats, att_masks))
+            self._bn_tick()
+        params = engine.speaker_params(self._speaker_tensors(fl))
         if att_pre is None:
             att_pre = engine.speaker_att_embed_fwd(dims, params, att_raw,
                                                    self._buf.get('att_pre', (B, K, self.rnn_size), torch.float32, att_raw.device))
@@ -236,27 +316,30 @@ class AttModel(nn.Module):
                 dslp = dslp * dslp_scale if dslp is not None else None
                 dslp_scale = None
         kw = dict(d_onehot=d_onehot, dslp=dslp, dslp_scale=dslp_scale)
+        grads = self._speaker_grads(fl)
         if logit_grads_ready is not None and res.soft is None:
             # data-parallel runs: the logit layer's gradient is final after the first phase.  The BPTT loop is ONE launch that
             # fills every CU (a collective cannot run beside it): exchanges already in flight land first (before_loop), the loop
             # runs, and the logit bucket starts behind it, under the batched weight-gradient products of the last phase.
-            self._ws[key] = engine.speaker_decode_bwd(res.dims, res.params, res.fwd, fl.grad_tensors(), res.att_raw,
+            self._ws[key] = engine.speaker_decode_bwd(res.dims, res.params, res.fwd, grads, res.att_raw,
                                                       ws_bwd=self._ws.get(key), phase=_lib.BWD_LOGIT, **kw)
             if before_loop is None:
                 before_loop = getattr(self, 'exchange_barrier', None)
             if before_loop is not None:
                 before_loop()
-            engine.speaker_decode_bwd(res.dims, res.params, res.fwd, fl.grad_tensors(), res.att_raw,
+            engine.speaker_decode_bwd(res.dims, res.params, res.fwd, grads, res.att_raw,
                                       ws_bwd=self._ws[key], phase=_lib.BWD_LOOP, **kw)
             logit_grads_ready()
-            engine.speaker_decode_bwd(res.dims, res.params, res.fwd, fl.grad_tensors(), res.att_raw,
+            engine.speaker_decode_bwd(res.dims, res.params, res.fwd, grads, res.att_raw,
                                       ws_bwd=self._ws[key], phase=_lib.BWD_TAIL, **kw)
+            self._bn_backward()
             return
         barrier = before_loop if before_loop is not None else getattr(self, 'exchange_barrier', None)
         if barrier is not None:
             barrier()             # (data-parallel runs: see optimizer.overlap_gradient_exchange)
-        self._ws[key] = engine.speaker_decode_bwd(res.dims, res.params, res.fwd, fl.grad_tensors(), res.att_raw,
+        self._ws[key] = engine.speaker_decode_bwd(res.dims, res.params, res.fwd, grads, res.att_raw,
                                                   ws_bwd=self._ws.get(key), **kw)
+        self._bn_backward()
         if logit_grads_ready is not None:
             logit_grads_ready()
 
@@ -291,9 +374,12 @@ class AttModel(nn.Module):
         B, K, _ = att_feats.shape
         dims = self._dims(B, K, self.seq_length)
         dims.p_drop = 0.0
-        params = engine.speaker_params(fl.tensors())
         att_raw = self._buf.stage('att_raw', att_feats, torch.float32)
         self._staged_att = None
+        if self.use_bn:
+            self._bn_stats(att_raw, self._bn_masks(att_feats, att_masks))
+            self._bn_tick()
+        params = engine.speaker_params(self._speaker_tensors(fl))
         att_pre = engine.speaker_att_embed_fwd(dims, params, att_raw,
                                                self._buf.get('att_pre', (B, K, self.rnn_size), torch.float32, att_raw.device))
         if att_masks is not None:

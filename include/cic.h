@@ -320,6 +320,24 @@ typedef struct {
 int cic_speaker_att_embed_fwd(const cic_speaker_dims* d, const cic_speaker_params* p,
                               const float* att_raw, float* att_pre, cic_stream_t s);
 
+/* use_bn = 1: BatchNorm1d(att_feat_size) in front of att_embed's Linear (AttModel.py:82-85), applied by pack_wrapper (:44-51) to the
+ * VALID region rows of a batch with ragged region counts (masks[r] > 0 marks them; rows = B*K).  The normalisation is folded into
+ * the Linear, whose product then reads the raw features (csrc/batchnorm.hip):
+ *   cic_bn_stats          per feature: mean and biased variance over the valid rows, and their count N           (training mode)
+ *   cic_bn_running_update running_mean / running_var <- (1 - momentum) old + momentum batch (unbiased variance), one forward
+ *   cic_bn_fold_fwd       W' = W diag(a), bias' = bias + W b with a = gamma / sqrt(var + eps), b = beta - mean a  -> cic_speaker_att_embed_fwd
+ *   cic_bn_fold_bwd       from the Linear's RAW gradients (dW_raw = d_pre^T x, db_raw: what cic_speaker_decode_bwd accumulates into
+ *                         grads->att_embed_w / _b when handed zeroed scratch): dW += gamma G + beta (x) db, dbias += db,
+ *                         dgamma += colsum(W . G), dbeta += W^T db, G = (dW_raw - mean (x) db) / sqrt(var + eps)                    */
+int cic_bn_stats(const float* x, const float* masks, int rows, int D, float* mean, float* var, float* count, cic_stream_t s);
+int cic_bn_running_update(const float* mean, const float* var, const float* count, float momentum, int D, float* running_mean,
+                          float* running_var, cic_stream_t s);
+int cic_bn_fold_fwd(const float* W, const float* bias, const float* gamma, const float* beta, const float* mean, const float* var,
+                    float eps, int H, int D, float* W_folded, float* bias_folded, cic_stream_t s);
+int cic_bn_fold_bwd(const float* dW_raw, const float* db_raw, const float* W, const float* gamma, const float* beta,
+                    const float* mean, const float* var, float eps, int H, int D, float* dW, float* dbias, float* dgamma,
+                    float* dbeta, cic_stream_t s);
+
 typedef struct {
     int mode;                 /* CIC_SAMPLE_* (not NONE) */
     float temp;               /* temperature / gumbel_temp / multinomial_temp */

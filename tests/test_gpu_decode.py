@@ -153,8 +153,8 @@ def test_paired_decodes_equal_sequential_decodes(B, dims):
             if x[k] is not None:
                 np.testing.assert_allclose(x[k].cpu().numpy(), y[k].cpu().numpy(), rtol=0, atol=2e-6, err_msg=k)
         assert torch.equal(x['ws'][:-tail], y['ws'][:-tail]), 'saved activations'
-        lse_x = x['ws'][-(lse_b + parts_b + tsync_b):][:T * B * 4].view(torch.float32)
-        lse_y = y['ws'][-(lse_b + parts_b + tsync_b):][:T * B * 4].view(torch.float32)
+        lse_x = x['ws'][-(lse_b + parts_b + gate_b + tsync_b):][:T * B * 4].view(torch.float32)
+        lse_y = y['ws'][-(lse_b + parts_b + gate_b + tsync_b):][:T * B * 4].view(torch.float32)
         np.testing.assert_allclose(lse_x.cpu().numpy(), lse_y.cpu().numpy(), rtol=0, atol=4e-6)
 
 

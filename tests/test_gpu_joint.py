@@ -144,6 +144,54 @@ def test_mle_forward_backward_matches_reference(name):
             np.testing.assert_allclose(d[2:], z[k][2:], rtol=5e-4, atol=5e-4 * scale + 1e-5 * glob, err_msg=k)
 
 
+def test_use_bn_mle_forward_backward_and_running_stats_match_reference():
+    """use_bn = 1: BatchNorm1d(att_feat_size) over the PACKED valid region rows in front of att_embed's Linear
+    (models/AttModel.py:82-85, pack_wrapper :44-51), ragged region counts.  The product folds the normalisation into the
+    Linear (csrc/batchnorm.hip); loss, every gradient (the norm's weight and bias included) and the running statistics
+    after the forward pass are the reference's (fixture bn_masked_mle, recorded from the reference, tools/gen_golden.py)."""
+    from cooperativeimagecaptioning_amd import models
+    z = GU.load_case('bn_masked_mle')
+    cfg = GU.cfg_dict(z)
+    assert cfg['use_bn'] == 1
+    B = z['fc'].shape[0]
+    opt = GU.make_opt(cfg, B, use_bn=1)
+    cg = models.setup(opt, 'att2in2', 'caption_model')
+    sd = cg.state_dict()
+    assert {'att_embed.0.running_mean', 'att_embed.0.running_var', 'att_embed.0.num_batches_tracked', 'att_embed.1.weight'} <= set(sd)
+    cg.load_state_dict({k: T_(v) for k, v in z['weights'].items()})
+    cg.cuda().train()
+    cg.noise.override = {'mle': GU.noise_dict(z, 'noise')}
+    cg.ss_prob = float(z['ss_prob'])
+    cg.zero_grad()
+    args = (T_(z['fc']).cuda(), T_(z['att_raw']).cuda(), T_(z['att_masks']).cuda(), T_(z['labels']).cuda(), T_(z['masks']).cuda())
+    loss = cg(*args)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(z['loss']), rtol=5e-5)
+    grads = {k: p.grad for k, p in cg.named_parameters()}
+    glob = max(float(np.abs(z[k][1]) / max(grads[k[5:]].numel(), 1)) for k in z if k.startswith('gdig.'))
+    for k in z:
+        if k.startswith('gdig.'):
+            g = grads[k[5:]]
+            d = GU.digest(g.detach().cpu().numpy())
+            scale = abs(z[k][1]) / max(g.numel(), 1)
+            np.testing.assert_allclose(d[2:], z[k][2:], rtol=5e-4, atol=5e-4 * scale + 1e-5 * glob, err_msg=k)
+    bn = cg.att_embed[0]
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), z['after.att_embed.0.running_mean'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), z['after.att_embed.0.running_var'], rtol=1e-5, atol=1e-6)
+    assert int(bn.num_batches_tracked) == int(z['after.att_embed.0.num_batches_tracked'])
+    # evaluation mode: the running statistics normalise; identical to torch's own modules on the same rows
+    cg.eval()
+    with torch.no_grad():
+        ev = cg(*args).item()
+        att = args[1][args[2] > 0]
+        y = torch.relu(cg.att_embed[1](cg.att_embed[0](att)))
+    assert np.isfinite(ev) and abs(ev - loss.item()) > 0            # other statistics, no dropout: another value
+    pre = cg.att_embed_pre(args[1], args[2])
+    np.testing.assert_allclose(pre[args[2] > 0].cpu().numpy(), y.cpu().numpy(), rtol=2e-5, atol=2e-5)
+    with pytest.raises(ValueError):
+        cg.att_embed_pre(args[1], None)                               # the reference: a BatchNorm1d shape error
+
+
 def _full_size_step(opt, turn, decodes, logged_exact=(), logged_close=(), loss_rtol=1e-4, grad_tol=1e-3, ragged=False,
                     eos_prob=0.07, want_L_below=None):
     """One step of the mirrored AlternatingJointModel on the GPU against the CPU oracle: same weights, batch, dropout

@@ -106,8 +106,10 @@ def test_unsupported_configurations_fail_loudly():
         models.AlternatingJointModel(GU.make_opt(cfg, 6, share_embed=1, caption_model='fc'))
     m = models.AlternatingJointModel(GU.make_opt(cfg, 6, share_embed=1))
     assert m.caption_generator.embed[0].weight is m.vse.txt_enc.embed.weight
+    bn = models.setup(GU.make_opt(cfg, 6, use_bn=1), 'att2in2', 'caption_model')    # att_embed.0 = BatchNorm1d, .1 = Linear (AttModel.py:82-85)
+    assert {'att_embed.0.running_mean', 'att_embed.0.num_batches_tracked', 'att_embed.1.weight'} <= set(bn.state_dict())
     with pytest.raises(NotImplementedError):
-        models.setup(GU.make_opt(cfg, 6, use_bn=1), 'att2in2', 'caption_model')
+        models.setup(GU.make_opt(cfg, 6, use_bn=1, compute_dtype='bf16'), 'att2in2', 'caption_model')
     with pytest.raises(Exception):
         models.setup(GU.make_opt(cfg, 6), 'topdown', 'caption_model')
 

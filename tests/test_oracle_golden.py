@@ -21,7 +21,7 @@ def params(z, prefix='', grad=False):
     for k, v in z['weights'].items():
         if k.startswith(prefix):
             t = T(v).clone()
-            if grad:
+            if grad and t.is_floating_point() and 'running_' not in k:      # (buffers of a BatchNorm layer stay plain tensors)
                 t.requires_grad_(True)
             out[k[len(prefix):]] = t
     return out
@@ -97,7 +97,7 @@ def test_sample(name):
         close(res[i], z[f'res{i}'], rtol=5e-5, atol=5e-6)
 
 
-@pytest.mark.parametrize('name', ['mle_plain', 'mle_dropout', 'mle_ss', 'masked_mle'])
+@pytest.mark.parametrize('name', ['mle_plain', 'mle_dropout', 'mle_ss', 'masked_mle', 'bn_masked_mle'])
 def test_mle(name):
     z = GU.load_case(name)
     P = params(z, grad=True)
