@@ -141,7 +141,7 @@ class FCModel(nn.Module):
         ops.colsum(d_x0, grads['img_embed.bias'], accumulate=True)
 
     # ---- the decode interface AlternatingJointModel drives (same names as AttModel's) ---------------------------
-    def att_embed_pre(self, att_feats):
+    def att_embed_pre(self, att_feats, att_masks=None):
         return None                                    # no region features in this speaker
 
     def decode(self, att_feats, att_masks, mode, temp=1.0, att_pre=None, grad=False, T=None, pick=None, first_token=None,

@@ -159,6 +159,10 @@ def test_use_bn_mle_forward_backward_and_running_stats_match_reference():
     sd = cg.state_dict()
     assert {'att_embed.0.running_mean', 'att_embed.0.running_var', 'att_embed.0.num_batches_tracked', 'att_embed.1.weight'} <= set(sd)
     cg.load_state_dict({k: T_(v) for k, v in z['weights'].items()})
+    # the fixture's w.* buffers were read off the reference model AFTER its forward pass (tools/gen_golden.py: mle_case); the
+    # reference model started from a fresh BatchNorm1d: running_mean 0, running_var 1, no batch tracked
+    bn = cg.att_embed[0]
+    bn.running_mean.zero_(), bn.running_var.fill_(1.0), bn.num_batches_tracked.zero_()
     cg.cuda().train()
     cg.noise.override = {'mle': GU.noise_dict(z, 'noise')}
     cg.ss_prob = float(z['ss_prob'])
@@ -381,12 +385,14 @@ def test_mle_step_at_edge_batch_sizes_matches_oracle(B, ragged):
 def test_joint_step_bf16_variant_full_size_vs_f32_oracle(turn):
     """The joint step in the reduced-precision variant (--compute_dtype bf16: bf16 operands in the batched products, bf16
     region features, and - r4 - the speaker's one-launch recurrences on bf16 MFMA fragments), against the f32 oracle at the
-    tolerance of the MLE variant test: loss 2e-3 relative, every parameter gradient within 3e-2 of its norm.  The
+    tolerance of the MLE variant test for the loss (2e-3 relative) and every parameter gradient within 6e-2 of its norm
+    (the table gradient, measured 3.8e-2 since the per-step logit / gate products read ONE bf16 image of their weights, sums
+    every rounding of a 16-step recurrence; 3e-2 held while those products were still f32).  The
     configuration is the one whose token ids do not depend on the arithmetic: REINFORCE with the ground-truth baseline and
     INJECTED multinomial draws, CIDEr term off (a greedy or Gumbel arg-max over 9488 bf16-perturbed logits may legitimately pick
     another token than the f32 oracle, after which the two losses are losses of different captions)."""
     from cooperativeimagecaptioning_amd import synthetic
     opt = synthetic.default_opt(batch_size=128, retrieval_reward='reinforce', reinforce_baseline_type='gt', vse_loss_weight=1.0,
                                 cider_optimization=0, retrieval_reward_weight=1.0, compute_dtype='bf16')
-    n = _full_size_step(opt, turn, {'sample': 'pick'}, loss_rtol=2e-3, grad_tol=3e-2)
+    n = _full_size_step(opt, turn, {'sample': 'pick'}, loss_rtol=2e-3, grad_tol=6e-2)
     assert n >= (14 if turn == 'speaker' else 6)
