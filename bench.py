@@ -178,9 +178,10 @@ def pmc_traffic(images):
     """HBM-side bytes per attention launch from the committed PMC summary (profiles/, separate FETCH_SIZE and
     WRITE_SIZE passes of this same command, tools/pmc_summary.py), for the launch geometry of the step."""
     doc = _profile_doc(['r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'])
-    for k in (doc or {}).get('kernels', []):
-        if k['kernel'].startswith('attn_fwd_cols_kernel') and k['grid_threads'] == images * 1024:
-            return k['total_bytes']
+    for prefix in ('attn_a2c_cell_kernel', 'attn_fwd_cols_kernel'):      # (r4: the fused launch; before: the attention alone)
+        for k in (doc or {}).get('kernels', []):
+            if k['kernel'].startswith(prefix) and k['grid_threads'] == images * 1024:
+                return k['total_bytes']
     return None
 
 
@@ -192,6 +193,33 @@ def pmc_mfma_util():
         if k['kernel'].startswith('gemm_ldsb2'):
             return k.get('mfma_util')
     return None
+
+
+def attention_phase_stamps(live):
+    """Duration of the attention phase INSIDE attn_a2c_cell_kernel (attention -> in-launch hand-off -> att2ctx + cell; the
+    attention is no launch of its own any more), from s_memrealtime stamps of the development build: tools/attn_phase_stamps.py
+    run as a child process on this GPU (live), else the summary committed under profiles/.  -> (dict or None, source)."""
+    import subprocess
+    if live:
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'attn_phase_stamps.py')], capture_output=True,
+                               text=True, timeout=240)
+            for ln in reversed(r.stdout.strip().splitlines()):
+                if ln.startswith('{'):
+                    d = json.loads(ln)
+                    if d.get('phase_span_us'):
+                        return d, 'live: tools/attn_phase_stamps.py (development build) as a child process of this run'
+        except Exception as e:                  # reporting only: never lose the measured line over it
+            print(f'bench.py: live attention-phase stamps failed ({type(e).__name__}: {e}); using profiles/', file=sys.stderr)
+    for name in ('r04_attn_phase_stamps.json',):
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as f:
+                d = json.load(f)
+            if d.get('phase_span_us'):
+                return d, 'profiles/' + name
+        except (OSError, ValueError):
+            continue
+    return None, None
 
 
 def trace_kernel_us(prefix):
@@ -240,6 +268,7 @@ def main():
     ap.add_argument('--batch', type=int, default=128)
     ap.add_argument('--batches', type=int, default=4, help='distinct synthetic batches resident in HBM, served round robin')
     ap.add_argument('--profile-steps', type=int, default=5, help='extra steps after the timed region with in-step kernel timing')
+    ap.add_argument('--no-phase-stamps', action='store_true', help='attention-phase stamps from profiles/ instead of a live child process')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N > 1: 'nccl' (= RCCL over xGMI, the "
@@ -360,6 +389,10 @@ def main():
             prof = timer.collect()
             prof['bracket_overhead_us'] = timer.bracket_overhead_us()
             prof['attn_microbench'] = attention_launch_time(model, batch, stream)['attn_fwd']
+            # (no child process under a profiler - its preloaded library would trace the child into the same output -, nor
+            # next to other ranks)
+            profiled = any(k in os.environ.get('LD_PRELOAD', '') for k in ('rocprof', 'roctracer')) or 'ROCPROF' in ''.join(os.environ)
+            prof['attn_phase'] = attention_phase_stamps(live=(world == 1 and not profiled and not args.no_phase_stamps))
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -380,8 +413,23 @@ def main():
         # uses the duration of launches of the step's geometry in the step's cache state (cic_attn_fwd_timed: HIP events
         # over 200 launches interleaved with a kernel that streams what a decode step moves between two attention
         # launches, that kernel's own time subtracted) - the figure the rocprofv3 trace of the in-step launches agrees with.
-        attn_us = micro_us
+        # (r4) In the step the attention is the first PHASE of attn_a2c_cell_kernel (attention -> in-launch hand-off -> att2ctx
+        # product + cell: one launch per decode step).  Its duration comes from s_memrealtime stamps of the development build:
+        # earliest wave start -> last att_res store issued, over all workgroups of a launch (the chip-wide span the launch's
+        # algorithmic bytes are divided by).  The stand-alone attention launch (the events above) and the whole fused kernel
+        # (in-step brackets; rocprofv3 trace) are reported beside it.
+        phase, phase_src = prof.get('attn_phase', (None, None))
+        attn_us = phase['phase_span_us'] if phase else micro_us
         achieved = (ATTN_BYTES_PER_IMAGE * n_img) / (attn_us * 1e-6) / 1e9 if attn_us > 0 else 0.0
+        fused_bracket_us = max(attn_raw_us - ovh, 0.0)
+        fused_trace_us = trace_kernel_us('attn_a2c_cell_kernel')
+        fused_us = max(fused_bracket_us, fused_trace_us or 0.0)
+        H_ = opt.rnn_size
+        # second phase, per launch: a2c weights once, the five gate pre-activations read + the two candidates written back, c, h, c',
+        # out, att_res written and read, the keep bytes
+        cell_bytes = 2 * H_ * H_ * 4 + n_img * H_ * 4 * (5 + 2 + 1 + 3 + 2) + n_img * H_
+        fused_bytes = ATTN_BYTES_PER_IMAGE * n_img + cell_bytes
+        fused_gbs = fused_bytes / (fused_us * 1e-6) / 1e9 if fused_us > 0 else 0.0
         lg = prof.get('logit_gemm', dict(ms=0.0, n=0))
         lg_bracket_us = max(lg['ms'] * 1e3 / max(lg['n'], 1) - ovh, 0.0)
         # The in-step bracket minus an empty event pair UNDER-reads a ~29 us kernel by a few percent (round 2: 27.8 us against
@@ -411,18 +459,32 @@ def main():
                        if isinstance(optimizer_dict.get('speaker'), dict) else None},
             # HBM-bound kernel of the path: the per-timestep attention.  achieved = algorithmic bytes of one launch / the
             # average duration of the in-step launches (HIP events of a cic_timer on the step's stream)
-            'roofline': {'bound': 'hbm', 'kernel': 'attn_fwd_cols_kernel<5, 1, float> (per-timestep top-down attention, 2B images per launch)',
+            'roofline': {'bound': 'hbm',
+                         'kernel': 'attn_a2c_cell_kernel<5, float>, attention phase (per-timestep top-down attention of 2B rows; the '
+                                   'att2ctx product + cell of the step follow in the same launch behind an in-launch hand-off)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          # the level the kernel actually reads from: its 37.7 MB working set is Infinity-Cache resident
                          'frac_of_cache_level': achieved / MALL_38MB_GBS, 'cache_level_peak': MALL_38MB_GBS,
                          'cache_level': 'Infinity Cache, 38 MB gathered table: 8.6 TB/s chip-wide (MI355X_MICROARCH.md)',
-                         'traffic': pmc_traffic(n_img), 'avg_launch_us': attn_us, 'launches_timed': micro.get('n', 0),
-                         'timing': 'HIP events on the step\'s stream over launches of the step\'s geometry interleaved with a '
-                                   'cache-polluting kernel (its time subtracted); in-step event brackets alongside',
-                         'in_step_bracket_us': attn_raw_us, 'in_step_launches_bracketed': attn['n'],
-                         'empty_bracket_us': ovh, 'in_step_bracket_minus_empty_us': max(attn_raw_us - ovh, 0.0),
-                         'avg_launch_us_l2_warm': micro.get('warm_us'),
+                         'traffic': pmc_traffic(n_img), 'avg_launch_us': attn_us,
+                         'launches_timed': (phase or {}).get('launches_stamped', 0),
+                         'timing': 'attention phase of the in-step launches: s_memrealtime stamps of the development build, earliest '
+                                   'wave start -> last att_res store issued over all 256 workgroups of a launch (median over launches)'
+                                   if phase else 'stand-alone attention launches (HIP events); no phase stamps available',
+                         'phase_source': phase_src, 'phase_per_workgroup_median_us': (phase or {}).get('per_workgroup_median_us'),
+                         # the whole fused launch: HIP-event brackets around every in-step launch (cic_timer) minus an empty pair, and
+                         # the committed rocprofv3 trace; priced at the longer one against the bytes of BOTH phases
+                         'whole_kernel': {'avg_launch_us': fused_us, 'avg_launch_us_bracket': fused_bracket_us,
+                                          'avg_launch_us_trace': fused_trace_us, 'launches_bracketed': attn['n'],
+                                          'algorithmic_bytes_per_launch': fused_bytes, 'achieved': fused_gbs,
+                                          'frac': fused_gbs / HBM_PEAK_GBS},
+                         # the attention as a launch of its own (the form a process on a shared GPU runs), HIP events over 200
+                         # launches of the step's geometry interleaved with a cache-polluting kernel (its time subtracted)
+                         'standalone_launch_us': micro_us, 'standalone_launches_timed': micro.get('n', 0),
+                         'standalone_launch_us_l2_warm': micro.get('warm_us'),
+                         'in_step_bracket_us': attn_raw_us, 'empty_bracket_us': ovh,
                          'images_per_launch': n_img, 'algorithmic_bytes_per_launch': ATTN_BYTES_PER_IMAGE * n_img,
+                         'traffic_covers': 'the whole fused launch (both phases): compare with whole_kernel.algorithmic_bytes_per_launch',
                          'traffic_source': 'profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_summary.py)'},
             # MFMA-bound kernel of the path: the hidden -> vocabulary logit product (with its fused log-softmax / sampler
             # partials), exact-f32 MFMA

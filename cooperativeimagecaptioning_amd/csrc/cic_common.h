@@ -334,18 +334,22 @@ __device__ __forceinline__ RowChoice row_choice(const cic_sampler_args& a, const
     c.lse = rp.m1 + logf(rp.s1);
     const bool gumbel_mode = a.mode == CIC_SAMPLE_GUMBEL_ST;
     const bool ss_on = a.mode == CIC_SAMPLE_TEACHER && a.ss_u && a.ss_prob > 0.f;
-    int it = rp.kidx;
+    // a row of NaN logits (state poisoned by a failed hand-off, NaN weights) has no arg max - no key compares greater - and
+    // leaves the empty partial's column: the token then is 0 (<eos>), never an index outside the embedding table.  Its
+    // log-prob is NaN, which is what the loss shows.
+    const int kidx = (unsigned)rp.kidx < (unsigned)a.V1 ? rp.kidx : 0;
+    int it = kidx;
     int it_feed = -1;                                   // teacher mode: token fed to the next step
     if (a.mode == CIC_SAMPLE_TEACHER) {
         const int target = (int)a.pick[b];
-        const int drawn = a.ss_pick ? (int)a.ss_pick[b] : rp.kidx;
+        const int drawn = a.ss_pick ? (int)a.ss_pick[b] : kidx;
         it_feed = (ss_on && a.ss_u[b] < a.ss_prob) ? drawn : target;   // AttModel.py:119-128
         it = target;                                     // the loss gathers log p(target)
     } else if (a.pick && a.mode != CIC_SAMPLE_GREEDY && !gumbel_mode) {
         it = (int)a.pick[b];
     }
     float x_it = rp.xbest;
-    if (it != rp.kidx) {
+    if (it != kidx || kidx != rp.kidx) {
         const int cons = (a.decoding_constraint && a.step >= 2) ? a.seq[(size_t)b * a.seq_ld + (a.step - 2)] : -1;
         x_it = it == cons ? -INFINITY : a.logits[(size_t)b * a.ld + it];
     }

@@ -56,6 +56,26 @@ int cic_cell_fwd2(Dual<const float> pre, Dual<const float> c_prev, Dual<const ui
 int cic_embed_fwd2(const float* E, Dual<const int32_t> it, Dual<const uint8_t> keep, float p_drop, Dual<float> x, int B,
                    int nb, int Ed, hipStream_t st, int plain = 0);
 bool cic_a2c_cell_fused_ok(int H);
+// attention + att2ctx product + cell of a decode step as ONE launch (speaker_fwd.hip: attn_a2c_cell_kernel)
+struct AttnCellLaunch {
+    Dual<const float> att_h, p_att, att;
+    Dual<const uint16_t> p_att_bf, att_bf;       // compute_dtype bf16: packed bf16 region features instead of p_att / att
+    const float *w_alpha, *b_alpha, *masks;
+    Dual<float> att_res, alpha, dot;
+    const float *Wa, *ba;
+    Dual<float> pre;
+    Dual<const float> c_prev;
+    Dual<const uint8_t> keep;
+    float p_drop;
+    Dual<float> h_new, c_new, out;
+    Dual<const int32_t> live;
+    unsigned* cnt;                               // [nb * ceil(B / 32)] arrival counters of this step, zero before the launch
+    unsigned* err;                               // the decode's error word
+    uint32_t* status;                            // the caller's sticky status word or null (cic.h)
+    int B, nb, K;
+};
+bool cic_attn_cell_fused_ok(int B, int nb, int K, int A, int H, bool bf, int device_shared);
+int cic_attn_a2c_cell(const AttnCellLaunch& L, hipStream_t st);
 int cic_a2c_cell_fused(Dual<const float> att_res, const float* Wa, const float* ba, Dual<float> pre, Dual<const float> c_prev,
                        Dual<const uint8_t> keep, float p_drop, Dual<float> h_new, Dual<float> c_new, Dual<float> out, int B,
                        int nb, int H, hipStream_t st, Dual<const int32_t> live = Dual<const int32_t>{nullptr, nullptr});

@@ -39,6 +39,8 @@ struct DecodeInit {
     float* bias_ih;            // [5H]
     float* x0;                 // [B,E] or null: (r4) the input of core step 0, x = dropout(relu(E[first token])) (AttModel.py:74-76,
     const uint8_t* keep0;      //       399; embed_fwd_kernel's arithmetic) - one launch less at the head of every decode
+    unsigned* zero_words;      // or null: the hand-off counters + error word of the decode's in-launch hand-offs (attn_a2c_cell_kernel)
+    int n_zero;
 };
 __global__ __launch_bounds__(256) void decode_init_kernel(DecodeInit a, DecodeInit b, const float* __restrict__ i2h_b,
                                                           const float* __restrict__ h2h_b, int BH4, int B, int T1, int H5,
@@ -51,6 +53,7 @@ __global__ __launch_bounds__(256) void decode_init_kernel(DecodeInit a, DecodeIn
         if (d.c) reinterpret_cast<f32x4*>(d.c)[i] = z4;
     }
     if (i < T1) d.any_unf[i] = 0;
+    if (d.zero_words && i < d.n_zero) d.zero_words[i] = 0u;
     if (i < B) {
         d.unfinished[i] = 1;
         d.it[i] = d.first_token ? (int32_t)d.first_token[i] : bos;
@@ -218,6 +221,12 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
     // teacher forcing without scheduled sampling embeds all its steps in one launch of its own (below)
     const bool init_embeds = !(nb == 1 && !fc && ios[0]->mode == CIC_SAMPLE_TEACHER && ios[0]->pick &&
                                !(ios[0]->ss_u && ios[0]->ss_prob > 0.f));
+    // attention + att2ctx + cell of every sampling step as one launch with an in-launch hand-off: needs all its workgroups resident
+    // and this process alone on the GPU.  Counters: [T][nb * ceil(B / 32)] words at the head of the (otherwise unused) hand-off
+    // region of the teacher-forced kernel, the error word behind that region as there; zeroed with the decode's other state.
+    bool attn_cell = !fc && cic_attn_cell_fused_ok(B, nb, K, A, H, bf, 0);
+    for (int q = 0; q < nb; ++q) attn_cell = attn_cell && !io[q]->device_shared;
+    const int n_tsync = cic_cdiv(B, 16) * T * 3 + 1;
     {
         DecodeInit di[2] = {};
         for (int q = 0; q < nb; ++q) {
@@ -231,9 +240,11 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
                 di[q].keep0 = fc ? nullptr : io[q]->x_keep;     // (row 0 of the [T+1,B,E] masks; the fc speaker embeds plain rows)
             }
         }
+        if (attn_cell) { di[0].zero_words = w[0].tsync; di[0].n_zero = n_tsync; }
         const int BH4 = B * H / 4;
         int span = BH4 > 5 * H ? BH4 : 5 * H;
         if (span < T + 1) span = T + 1;
+        if (attn_cell && span < n_tsync) span = n_tsync;
         if (span < B) span = B;
         if (init_embeds && span < B * E / 4) span = B * E / 4;
         hipLaunchKernelGGL(decode_init_kernel, dim3(cic_cdiv(span, 256), nb), dim3(256), 0, st, di[0], di[1], p->i2h_b, p->h2h_b,
@@ -401,7 +412,25 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
         }
         // att_masks are an input of the step (the same images in both decodes)
         CIC_REQUIRE(nb == 1 || io[0]->att_masks == io[1]->att_masks);
-        if (!fc) {
+        const bool step_fused = attn_cell && gates_done;
+        if (step_fused) {
+            AttnCellLaunch L = {};
+            L.att_h = Dual<const float>{att_h.a, att_h.b};
+            L.p_att = Dual<const float>{w[0].p_att, w[1].p_att}; L.att = Dual<const float>{w[0].att, w[1].att};
+            if (bf) {
+                L.p_att_bf = Dual<const uint16_t>{w[0].p_att_bf, w[1].p_att_bf};
+                L.att_bf = Dual<const uint16_t>{w[0].att_bf, w[1].att_bf};
+            }
+            L.w_alpha = p->alpha_w; L.b_alpha = p->alpha_b; L.masks = io[0]->att_masks;
+            L.att_res = att_res; L.alpha = SLAB(alpha_all, B * K); L.dot = SLAB(dot_all, B * K);
+            L.Wa = p->a2c_w; L.ba = p->a2c_b; L.pre = pre; L.c_prev = c; L.keep = ok; L.p_drop = ok.a ? p_drop : 0.f;
+            L.h_new = h_new; L.c_new = c_new; L.out = out; L.live = live;
+            L.cnt = w[0].tsync + (size_t)t * nb * cic_cdiv(B, 32); L.err = w[0].tsync + (n_tsync - 1); L.status = io[0]->status;
+            L.B = B; L.nb = nb; L.K = K;
+            CIC_TIMED(io[0]->timer, CIC_TIMED_ATTN_FWD, st, rc = cic_attn_a2c_cell(L, st));
+            if (rc) return rc;
+        }
+        if (!fc && !step_fused) {
             CIC_TIMED(io[0]->timer, CIC_TIMED_ATTN_FWD, st,
                      rc = cic_attn_fwd2(Dual<const float>{att_h.a, att_h.b}, Dual<const float>{w[0].p_att, w[1].p_att},
                                         Dual<const float>{w[0].att, w[1].att}, p->alpha_w, p->alpha_b, io[0]->att_masks, att_res,
@@ -418,7 +447,8 @@ static int decode_fwd_impl(const cic_speaker_dims* dp, const cic_speaker_params*
             g.C = pre.a; g.ldc = 5 * H; g.bias = w[0].bias_ih;
             RUN(pair_gemm(g, x.b, h.b, pre.b));
         }
-        if (!fc && cic_a2c_cell_fused_ok(H)) {
+        if (step_fused) {
+        } else if (!fc && cic_a2c_cell_fused_ok(H)) {
             // a2c product + cell in one launch (flagship width)
             RUN(cic_a2c_cell_fused(Dual<const float>{att_res.a, att_res.b}, p->a2c_w, p->a2c_b, pre, c, ok, ok.a ? p_drop : 0.f,
                                    h_new, c_new, out, B, nb, H, st, live));

@@ -177,20 +177,30 @@ __device__ __forceinline__ f32x4 ld_feat4<uint16_t>(const uint16_t* __restrict__
                  __uint_as_float(v.y & 0xffff0000u)};
 }
 
-template <int JMAX, int NCG, typename ST = float>   // region groups of 8: K <= 8*JMAX;  NCG 32-column groups per wave
-__global__ __launch_bounds__(1024) void attn_fwd_cols_kernel(Dual<const float> att_h_d, Dual<const ST> p_att_d,
-                                                             Dual<const ST> att_d, const float* __restrict__ w_alpha,
-                                                             const float* __restrict__ b_alpha, const float* __restrict__ masks,
-                                                             Dual<float> att_res_d, Dual<float> alpha_d, Dual<float> dot_d, int B0,
-                                                             int K, int H, int att_div, Dual<const int32_t> live) {
-    __shared__ float sp[16 * 64];
-    if (live.a && *live.a == 0 && (!live.b || *live.b == 0)) return;   // every caption has ended (AttModel.py:401-408)
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+// a wave-uniform buffer descriptor over [ptr, ptr + bytes): raw buffer loads / stores with aux = 16 (sc1) are the write-through
+// stores and cache-bypassing loads of the in-launch hand-offs
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc_f32(const float* ptr, size_t bytes) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(ptr);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo), 0, (int)bytes, 0x00020000);
+}
+
+// The attention of ONE row (image x decode) by one workgroup of H / (32 NCG) waves: the body of attn_fwd_cols_kernel, and the
+// first phase of attn_a2c_cell_kernel (WT: att_res leaves through write-through stores - it is handed over inside the launch).
+// `bx` = the row's index in [0, nb * B0); `wg` = the workgroup's index (stamps).
+template <int JMAX, int NCG, typename ST, bool WT>   // region groups of 8: K <= 8*JMAX;  NCG 32-column groups per wave
+__device__ __forceinline__ void attn_cols_row(int bx, int wg, float* sp, Dual<const float> att_h_d, Dual<const ST> p_att_d,
+                                              Dual<const ST> att_d, const float* __restrict__ w_alpha,
+                                              const float* __restrict__ b_alpha, const float* __restrict__ masks,
+                                              Dual<float> att_res_d, Dual<float> alpha_d, Dual<float> dot_d, int B0, int K, int H,
+                                              int att_div, float poison) {
     unsigned long long* stamps = CIC_STAMP_BUF(g_attn_stamps);
     unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     if (stamps) s0 = __builtin_amdgcn_s_memrealtime();
     // rows [0,B0) are images of decode a, rows [B0, 2*B0) the same images in decode b (its own activations)
-    const bool second = (int)blockIdx.x >= B0;
-    const int b = second ? blockIdx.x - B0 : blockIdx.x;
+    const bool second = bx >= B0;
+    const int b = second ? bx - B0 : bx;
     const float* __restrict__ att_h = att_h_d.sel(second);
     const ST* __restrict__ p_att = p_att_d.sel(second);
     const ST* __restrict__ att = att_d.sel(second);
@@ -260,6 +270,8 @@ __global__ __launch_bounds__(1024) void attn_fwd_cols_kernel(Dual<const float> a
     float aj[JMAX];
 #pragma unroll
     for (int j = 0; j < JMAX; ++j) aj[j] = __shfl(al, 8 * j + rg, 64);      // lanes >= K hold 0
+    __amdgpu_buffer_rsrc_t r_res;
+    if (WT) r_res = uniform_rsrc_f32(att_res + (size_t)b * H, (size_t)H * sizeof(float));
 #pragma unroll
     for (int i = 0; i < NCG; ++i) {
         f32x4 acc = z4;
@@ -267,12 +279,28 @@ __global__ __launch_bounds__(1024) void attn_fwd_cols_kernel(Dual<const float> a
         for (int j = 0; j < JMAX; ++j) acc += aj[j] * av[i][j];
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = sum_over_rg(acc[e]);
-        if (rg == 0) reinterpret_cast<f32x4*>(att_res + (size_t)b * H)[col4[i]] = acc;
+        if (WT && poison != 0.f) acc = f32x4{poison, poison, poison, poison};
+        if (rg == 0) {
+            if (WT) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc), r_res, col4[i] * 16, 0, 16);
+            else reinterpret_cast<f32x4*>(att_res + (size_t)b * H)[col4[i]] = acc;
+        }
     }
     if (stamps && lane == 0) {
-        unsigned long long* o = stamps + ((size_t)blockIdx.x * 16 + w) * 5;
+        unsigned long long* o = stamps + ((size_t)wg * 16 + w) * 5;
         o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3; o[4] = __builtin_amdgcn_s_memrealtime();
     }
+}
+
+template <int JMAX, int NCG, typename ST = float>
+__global__ __launch_bounds__(1024) void attn_fwd_cols_kernel(Dual<const float> att_h_d, Dual<const ST> p_att_d,
+                                                             Dual<const ST> att_d, const float* __restrict__ w_alpha,
+                                                             const float* __restrict__ b_alpha, const float* __restrict__ masks,
+                                                             Dual<float> att_res_d, Dual<float> alpha_d, Dual<float> dot_d, int B0,
+                                                             int K, int H, int att_div, Dual<const int32_t> live) {
+    __shared__ float sp[16 * 64];
+    if (live.a && *live.a == 0 && (!live.b || *live.b == 0)) return;   // every caption has ended (AttModel.py:401-408)
+    attn_cols_row<JMAX, NCG, ST, false>((int)blockIdx.x, (int)blockIdx.x, sp, att_h_d, p_att_d, att_d, w_alpha, b_alpha, masks, att_res_d,
+                                        alpha_d, dot_d, B0, K, H, att_div, 0.f);
 }
 
 
@@ -331,23 +359,22 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(Dual<const float> pre_d, 
 // decode pair go through the .b pointers.
 // ---------------------------------------------------------------------------------------------
 typedef float f32x4acc __attribute__((ext_vector_type(4)));
-template <int GPS, int KS>   // H = 16*GPS*KS
-__global__ __launch_bounds__(KS * 64) void a2c_cell_fused_kernel(Dual<const float> att_res_d, const float* __restrict__ Wa,
-                                                             const float* __restrict__ ba, Dual<float> pre_d,
-                                                             Dual<const float> c_prev_d, Dual<const uint8_t> keep_d, float scale,
-                                                             Dual<float> h_new_d, Dual<float> c_new_d, Dual<float> out_d,
-                                                             int B0, int nb, int H, Dual<const int32_t> live) {
+// One (32-row strip, 16-unit tile) of the fused a2c product + cell: the body of a2c_cell_fused_kernel and the second phase of
+// attn_a2c_cell_kernel.  `gstrip` counts the strips of decode a, then those of decode b; only `worker` waves (the first KS of the
+// workgroup) compute, every wave meets the barriers.  wait_att_res(): called by every thread right before att_res is read - the
+// fused kernel waits there for the strip's attention rows (and returns NaN when it gave up), SC1 then reads them past the caches.
+template <int GPS, int KS, bool SC1, typename WaitF>   // H = 16*GPS*KS
+__device__ __forceinline__ void a2c_cell_tile(int gstrip, int jt, bool worker, float* red, Dual<const float> att_res_d,
+                                              const float* __restrict__ Wa, const float* __restrict__ ba, Dual<float> pre_d,
+                                              Dual<const float> c_prev_d, Dual<const uint8_t> keep_d, float scale,
+                                              Dual<float> h_new_d, Dual<float> c_new_d, Dual<float> out_d, int B0, int H,
+                                              WaitF wait_att_res) {
     static_assert(KS == 8, "8 accumulator registers (2 row tiles x 4) dealt one per wave");
-    __shared__ float red[2 * KS * 8 * 64];
-    if (live.a && *live.a == 0 && (!live.b || *live.b == 0)) return;   // every caption has ended (AttModel.py:401-408)
-    const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, ks = worker ? tid >> 6 : 0;
     const int li = lane & 15, lq = lane >> 4;
-    const int tiles_j = H / 16;
     const int strips_per = (B0 + 31) / 32;
-    int strip = blockIdx.x / tiles_j;
-    const int jt = blockIdx.x % tiles_j;
-    const bool second = strip >= strips_per;
-    if (second) strip -= strips_per;
+    const bool second = gstrip >= strips_per;
+    const int strip = second ? gstrip - strips_per : gstrip;
     const float* __restrict__ att_res = att_res_d.sel(second);
     float* __restrict__ pre = pre_d.sel(second);
     const float* __restrict__ c_prev = c_prev_d.sel(second);
@@ -361,50 +388,61 @@ __global__ __launch_bounds__(KS * 64) void a2c_cell_fused_kernel(Dual<const floa
     const int orow = m0 + 16 * (ks >> 2) + 4 * lq + (ks & 3);     // the output this wave finishes after the cross-wave sums
     const int orc = orow < B0 ? orow : B0 - 1;
     // epilogue operands first (used last)
-    const float* prow = pre + (size_t)orc * 5 * H;
-    const float pi = prow[col], pf = prow[H + col], po = prow[2 * H + col], pa = prow[3 * H + col], pb = prow[4 * H + col];
-    const float cp = c_prev[(size_t)orc * H + col];
-    const float kf = keep ? (float)keep[(size_t)orc * H + col] * scale : 1.0f;
-    f32x4 af[2][GPS];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        const int m = m0 + 16 * rt + li;
-        const int mc = m < B0 ? m : B0 - 1;
-#pragma unroll
-        for (int i = 0; i < GPS; ++i) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(att_res + (size_t)mc * H + 16 * (ks * GPS + i) + 4 * lq);
-            af[rt][i] = m < B0 ? a : z4;
-        }
-    }
+    float pi = 0.f, pf = 0.f, po = 0.f, pa = 0.f, pb = 0.f, cp = 0.f, kf = 1.0f;
     // both maxout halves' weight tiles are requested up front (the second one used to be requested behind the first one's MFMAs:
     // a dependent round trip), both products run back to back, ONE barrier covers both cross-wave sums; per element the
     // arithmetic and its order are unchanged
     f32x4 bf[2][GPS];
+    if (worker) {
+        const float* prow = pre + (size_t)orc * 5 * H;
+        pi = prow[col]; pf = prow[H + col]; po = prow[2 * H + col]; pa = prow[3 * H + col]; pb = prow[4 * H + col];
+        cp = c_prev[(size_t)orc * H + col];
+        kf = keep ? (float)keep[(size_t)orc * H + col] * scale : 1.0f;
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const float* wrow = Wa + ((size_t)g * H + col) * H;
+        for (int g = 0; g < 2; ++g) {
+            const float* wrow = Wa + ((size_t)g * H + col) * H;
 #pragma unroll
-        for (int i = 0; i < GPS; ++i) bf[g][i] = *reinterpret_cast<const f32x4*>(wrow + 16 * (ks * GPS + i) + 4 * lq);
+            for (int i = 0; i < GPS; ++i) bf[g][i] = *reinterpret_cast<const f32x4*>(wrow + 16 * (ks * GPS + i) + 4 * lq);
+        }
     }
-    float av[2];
+    const float poison = wait_att_res();
+    if (worker) {
+        f32x4 af[2][GPS];
+        __amdgpu_buffer_rsrc_t r_res;
+        if (SC1) r_res = uniform_rsrc_f32(att_res, (size_t)B0 * H * sizeof(float));
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        f32x4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int rt = 0; rt < 2; ++rt) {
+            const int m = m0 + 16 * rt + li;
+            const int mc = m < B0 ? m : B0 - 1;
 #pragma unroll
-        for (int i = 0; i < GPS; ++i)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][i][s], bf[g][i][s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][i][s], bf[g][i][s], acc1, 0, 0, 0);
+            for (int i = 0; i < GPS; ++i) {
+                const size_t off = (size_t)mc * H + 16 * (ks * GPS + i) + 4 * lq;
+                const f32x4 a = SC1 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)(off * 4), 0, 16))
+                                    : *reinterpret_cast<const f32x4*>(att_res + off);
+                af[rt][i] = m < B0 ? a : z4;
             }
-        float* rb = red + g * (KS * 8 * 64);
+        }
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            rb[(ks * 8 + v) * 64 + lane] = acc0[v];
-            rb[(ks * 8 + 4 + v) * 64 + lane] = acc1[v];
+        for (int g = 0; g < 2; ++g) {
+            f32x4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < GPS; ++i)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][i][s], bf[g][i][s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][i][s], bf[g][i][s], acc1, 0, 0, 0);
+                }
+            float* rb = red + g * (KS * 8 * 64);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                rb[(ks * 8 + v) * 64 + lane] = acc0[v];
+                rb[(ks * 8 + 4 + v) * 64 + lane] = acc1[v];
+            }
         }
     }
     __syncthreads();
+    if (!worker) return;
+    float av[2];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const float* rb = red + g * (KS * 8 * 64);
@@ -419,12 +457,90 @@ __global__ __launch_bounds__(KS * 64) void a2c_cell_fused_kernel(Dual<const floa
         pw[3 * H + col] = a;
         pw[4 * H + col] = b;
         const float ig = fast_sigmoid(pi), fg = fast_sigmoid(pf), og = fast_sigmoid(po);
-        const float c2 = fg * cp + ig * fmaxf(a, b);              // :523-526
-        const float h2 = og * fast_tanh(c2);                      // :527
+        float c2 = fg * cp + ig * fmaxf(a, b);                    // :523-526
+        float h2 = og * fast_tanh(c2);                            // :527
+        if (SC1 && poison != 0.f) { c2 = poison; h2 = poison; }
         c_new[(size_t)orow * H + col] = c2;
         h_new[(size_t)orow * H + col] = h2;
         out[(size_t)orow * H + col] = keep ? h2 * kf : h2;        // :529
     }
+}
+
+template <int GPS, int KS>   // H = 16*GPS*KS
+__global__ __launch_bounds__(KS * 64) void a2c_cell_fused_kernel(Dual<const float> att_res_d, const float* __restrict__ Wa,
+                                                             const float* __restrict__ ba, Dual<float> pre_d,
+                                                             Dual<const float> c_prev_d, Dual<const uint8_t> keep_d, float scale,
+                                                             Dual<float> h_new_d, Dual<float> c_new_d, Dual<float> out_d,
+                                                             int B0, int nb, int H, Dual<const int32_t> live) {
+    __shared__ float red[2 * KS * 8 * 64];
+    if (live.a && *live.a == 0 && (!live.b || *live.b == 0)) return;   // every caption has ended (AttModel.py:401-408)
+    const int tiles_j = H / 16;
+    a2c_cell_tile<GPS, KS, false>((int)blockIdx.x / tiles_j, (int)blockIdx.x % tiles_j, true, red, att_res_d, Wa, ba, pre_d, c_prev_d,
+                                  keep_d, scale, h_new_d, c_new_d, out_d, B0, H, [] { return 0.f; });
+}
+
+// ---------------------------------------------------------------------------------------------
+// (r4) Attention + att2ctx product + cell of a decode step in ONE launch (flagship width H = 512, all workgroups resident): workgroup
+// i first runs the attention of row i exactly as attn_fwd_cols_kernel does, hands att_res over inside the launch (write-through
+// stores, drain, barrier, ONE counter add per workgroup on its 32-row strip's counter), then - as tile i of the
+// (strip, 16-unit tile) grid of a2c_cell_fused_kernel - waits for its strip's rows (one poller, bounded: cic_common.h) and runs that
+// kernel's body on sc1 loads.  Same arithmetic in the same order as the two launches: bit-identical activations and tokens.  What
+// the fusion saves is one dependent launch boundary per step (~1 us) and the refetch of the cell's operands behind the attention
+// (they are requested before the wait).  With 8 strips in a 256-workgroup grid a strip's rows and tiles share one XCD.
+// A workgroup that gives up raises the error / status words and writes NaN into h, c and out of its tile.
+// ---------------------------------------------------------------------------------------------
+template <typename ST>
+struct AttnCellArgs {
+    Dual<const float> att_h;
+    Dual<const ST> p_att, att;
+    const float *w_alpha, *b_alpha, *masks;
+    Dual<float> att_res, alpha, dot;
+    const float *Wa, *ba;
+    Dual<float> pre;
+    Dual<const float> c_prev;
+    Dual<const uint8_t> keep;
+    float scale;
+    Dual<float> h_new, c_new, out;
+    Dual<const int32_t> live;
+    unsigned* cnt;                // [nb * strips] arrival counters of THIS step (zeroed once per decode)
+    HandoffGuard hg;
+    int B0, nb, K;
+};
+template <int JMAX, typename ST>
+__global__ __launch_bounds__(1024) void attn_a2c_cell_kernel(AttnCellArgs<ST> a) {
+    constexpr int H = 512, TJ = H / 16;
+    __shared__ float sp[16 * 64];
+    __shared__ float red[2 * 8 * 8 * 64];
+    __shared__ int ok_s;
+    if (a.live.a && *a.live.a == 0 && (!a.live.b || *a.live.b == 0)) return;   // every caption has ended (grid-uniform)
+    const int tid = threadIdx.x;
+    const int rows = a.nb * a.B0, strips_per = (a.B0 + 31) / 32, nstrips = a.nb * strips_per;
+    // workgroup -> (attention row, cell tile).  8 strips of 32 rows in a 256-workgroup grid: strip x = the workgroups of XCD x
+    int row = blockIdx.x, gstrip = blockIdx.x / TJ, jt = blockIdx.x % TJ;
+    if (gridDim.x == 256 && nstrips == 8 && (a.B0 & 31) == 0) {
+        gstrip = blockIdx.x & 7; jt = blockIdx.x >> 3;
+        row = 32 * gstrip + jt;
+    }
+    if (tid == 0) ok_s = 1;
+    if (row < rows) {
+        attn_cols_row<JMAX, 1, ST, true>(row, (int)blockIdx.x, sp, a.att_h, a.p_att, a.att, a.w_alpha, a.b_alpha, a.masks, a.att_res,
+                                         a.alpha, a.dot, a.B0, a.K, H, 1, 0.f);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave drains before the signal
+        __syncthreads();
+        const bool second = row >= a.B0;
+        const int rs = (second ? strips_per : 0) + (second ? row - a.B0 : row) / 32;
+        if (tid == 0) handoff_arrive(a.cnt + rs, a.hg);
+    }
+    if (gstrip >= nstrips) return;
+    const int s_local = gstrip % strips_per;
+    const unsigned want = (unsigned)min(32, a.B0 - 32 * s_local);
+    a2c_cell_tile<4, 8, true>(gstrip, jt, tid < 512, red, Dual<const float>{a.att_res.a, a.att_res.b}, a.Wa, a.ba, a.pre, a.c_prev, a.keep,
+                              a.scale, a.h_new, a.c_new, a.out, a.B0, H, [&] {
+                                  if (tid == 0) ok_s = handoff_poll(a.cnt + gstrip, want, a.hg);
+                                  __syncthreads();
+                                  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler only: no load of handed-off bytes above the poll
+                                  return ok_s ? 0.f : __builtin_nanf("");
+                              });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -454,7 +570,6 @@ struct TeacherSeqArgs {
     int row0, row_end;                                        // rows [row0, row_end) of the batch: one launch per row block
 };
 constexpr size_t TEACHER_LDS_BYTES = sizeof(float) * ((size_t)8 * 8 * 64 * 4 + 8 * 6 * 4 * 64 + 8 * 64);
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x8_t __attribute__((ext_vector_type(8)));
 // eight consecutive f32 -> one bf16 MFMA fragment (round to nearest even; a plain cast keeps a NaN a NaN)
@@ -1591,6 +1706,64 @@ int cic_a2c_cell_fused(Dual<const float> att_res, const float* Wa, const float* 
     const int grid = nb * cic_cdiv(B, 32) * (H / 16);
     hipLaunchKernelGGL((a2c_cell_fused_kernel<4, 8>), dim3(grid), dim3(512), 0, st, att_res, Wa, ba, pre, c_prev, keep,
                        1.0f / (1.0f - p_drop), h_new, c_new, out, B, nb, H, live);
+    CIC_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- attention + att2ctx + cell as one launch (attn_a2c_cell_kernel) ------------------------------------------------------------
+CIC_SWITCH(g_attn_cell_fused, 1);
+#ifdef CIC_DEVTOOLS
+extern "C" int cic_debug_attn_cell_fused(int on) {
+    g_attn_cell_fused = on;
+    return 0;
+}
+#endif
+template <int J, typename ST>
+static int attn_cell_resident() {
+    return cic_resident_cus(reinterpret_cast<const void*>(&attn_a2c_cell_kernel<J, ST>), 1024, 0);
+}
+static int attn_cell_grid(int B, int nb) {
+    const int rows = nb * B, tiles = nb * cic_cdiv(B, 32) * 32;
+    return rows > tiles ? rows : tiles;
+}
+// the fused launch needs every workgroup resident at once (one 16-wave workgroup per CU) and this process alone on the GPU
+bool cic_attn_cell_fused_ok(int B, int nb, int K, int A, int H, bool bf, int device_shared) {
+    if (!g_attn_cell_fused || device_shared || H != 512 || A != 512 || K < 1 || K > 40 || !cic_a2c_cell_fused_ok(H)) return false;
+    const int cus = bf ? attn_cell_resident<5, uint16_t>() : attn_cell_resident<5, float>();
+    return attn_cell_grid(B, nb) <= cus;
+}
+int cic_attn_a2c_cell(const AttnCellLaunch& L, hipStream_t st) {
+    const bool bf = L.p_att_bf.a != nullptr;
+    CIC_REQUIRE(L.att_h.a && L.w_alpha && L.b_alpha && L.att_res.a && L.alpha.a && L.Wa && L.ba && L.pre.a && L.c_prev.a && L.h_new.a &&
+                L.c_new.a && L.out.a && L.cnt && L.err && L.B > 0 && (L.nb == 1 || L.nb == 2));
+    CIC_REQUIRE(bf ? (L.att_bf.a != nullptr) : (L.p_att.a && L.att.a));
+    CIC_REQUIRE(L.nb == 1 || (L.att_h.b && L.att_res.b && L.alpha.b && L.pre.b && L.c_prev.b && L.h_new.b && L.c_new.b && L.out.b));
+    CIC_REQUIRE(cic_attn_cell_fused_ok(L.B, L.nb, L.K, 512, 512, bf, 0));
+    const int grid = attn_cell_grid(L.B, L.nb);
+    const HandoffGuard hg = handoff_guard(L.err, L.status, CIC_STATUS_DECODE_STEP);
+#define FILL(a)                                                                                                                  \
+    a.att_h = L.att_h; a.w_alpha = L.w_alpha; a.b_alpha = L.b_alpha; a.masks = L.masks; a.att_res = L.att_res; a.alpha = L.alpha;     \
+    a.dot = L.dot; a.Wa = L.Wa; a.ba = L.ba; a.pre = L.pre; a.c_prev = L.c_prev; a.keep = L.keep;                                      \
+    a.scale = 1.0f / (1.0f - L.p_drop); a.h_new = L.h_new; a.c_new = L.c_new; a.out = L.out; a.live = L.live; a.cnt = L.cnt;           \
+    a.hg = hg; a.B0 = L.B; a.nb = L.nb; a.K = L.K
+#define GOJ(ST, J) hipLaunchKernelGGL((attn_a2c_cell_kernel<J, ST>), dim3(grid), dim3(1024), 0, st, a)
+#define GOK(ST)                                                                                                                  \
+    do {                                                                                                                         \
+        if (L.K <= 8) GOJ(ST, 1); else if (L.K <= 16) GOJ(ST, 2); else if (L.K <= 24) GOJ(ST, 3); else if (L.K <= 32) GOJ(ST, 4);   \
+        else GOJ(ST, 5);                                                                                                         \
+    } while (0)
+    if (bf) {
+        AttnCellArgs<uint16_t> a;
+        FILL(a); a.p_att = L.p_att_bf; a.att = L.att_bf;
+        GOK(uint16_t);
+    } else {
+        AttnCellArgs<float> a;
+        FILL(a); a.p_att = L.p_att; a.att = L.att;
+        GOK(float);
+    }
+#undef GOK
+#undef GOJ
+#undef FILL
     CIC_LAUNCH_CHECK();
     return 0;
 }

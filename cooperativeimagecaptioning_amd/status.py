@@ -12,12 +12,13 @@ import torch
 
 from ._lib import CicError
 
-GRU_FWD, GRU_BWD, TEACHER, BPTT, UPDATE_SKIPPED = 1, 2, 4, 8, 256
+GRU_FWD, GRU_BWD, TEACHER, BPTT, DECODE_STEP, UPDATE_SKIPPED = 1, 2, 4, 8, 16, 256
 LOOPS = {
     GRU_FWD: "the listener's GRU pass (gru_seq_kernel)",
     GRU_BWD: "the listener's GRU BPTT loop (gru_seq_bwd_kernel)",
     TEACHER: "the speaker's teacher-forced recurrence (spk_teacher_seq_kernel)",
     BPTT: "the speaker's BPTT loop (spk_bptt_seq_kernel)",
+    DECODE_STEP: "a sampling decode step's attention -> att2ctx + cell launch (attn_a2c_cell_kernel)",
 }
 _WORDS = {}
 

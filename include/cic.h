@@ -36,12 +36,13 @@ const char* cic_last_error(void);
 
 /* ---- status word: failures of the one-launch recurrences, reported without a host synchronisation -------------------
  * Four loops of a step run as ONE launch whose workgroups hand state to each other inside the launch (the listener's GRU pass
- * and its BPTT loop, the speaker's teacher-forced recurrence and its BPTT loop).  They need every workgroup RESIDENT at once:
+ * and its BPTT loop, the speaker's teacher-forced recurrence and its BPTT loop), and so does the attention + att2ctx + cell
+ * launch of every sampling decode step (one hand-off).  They need every workgroup RESIDENT at once:
  * one per CU.  When something else holds CUs (a second process on the GPU that did not say so through device_shared, a
  * CU-masked queue) a workgroup waits for partners that never start; every such wait is bounded (1 s), the workgroup that gives
  * up poisons what it produces with NaN, and - new in round 4 - sets its loop's bit in the caller-owned device word
  * `status` of the io struct (cic_decode_io.status, cic_listener_io.status; NULL = not reported):
- *     CIC_STATUS_GRU_FWD | CIC_STATUS_GRU_BWD | CIC_STATUS_TEACHER | CIC_STATUS_BPTT.
+ *     CIC_STATUS_GRU_FWD | CIC_STATUS_GRU_BWD | CIC_STATUS_TEACHER | CIC_STATUS_BPTT | CIC_STATUS_DECODE_STEP.
  * The word is STICKY: the library only ever ORs into it; the caller zeroes it once and reads it when it likes (the trainer
  * copies it to pinned memory beside the step's loss and raises; no extra synchronisation).  cic_clamp_adam_guarded reads the
  * same word on the device: while it is non-zero the update is SKIPPED - parameters, moments and the gradient stay as they
@@ -52,6 +53,7 @@ enum {
     CIC_STATUS_GRU_BWD = 2,          /* gru_seq_bwd_kernel */
     CIC_STATUS_TEACHER = 4,          /* spk_teacher_seq_kernel (AttModel.py:103-148) */
     CIC_STATUS_BPTT = 8,             /* spk_bptt_seq_kernel    (AttModel.py:465-531 reversed) */
+    CIC_STATUS_DECODE_STEP = 16,     /* attn_a2c_cell_kernel   (one decode step's attention -> att2ctx + cell, AttModel.py:465-529) */
     CIC_STATUS_UPDATE_SKIPPED = 256  /* cic_clamp_adam_guarded found the word set and left the weights alone */
 };
 

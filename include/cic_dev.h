@@ -20,6 +20,7 @@ int cic_debug_stream_probe(const float* src, int64_t region_floats, int regions,
 /* diagnostics: per-workgroup phase stamps of the register-streaming GEMM (NULL = off) */
 int cic_debug_set_stamps(unsigned long long* buf);
 int cic_debug_set_attn_stamps(unsigned long long* buf);
+int cic_debug_attn_cell_fused(int on);          /* 0: attention and att2ctx + cell of a decode step as two launches again */
 /* diagnostics: per-workgroup phase stamps of the per-timestep GEMMs (rega / LDS-staged walker) and of the row kernels
  * (attention, sampler); NULL = off */
 /* diagnostics, A/B timing of the GEMM dispatch: bit 0 clear = K-sliced tail tiles and K split over workgroups off (fixed

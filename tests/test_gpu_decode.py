@@ -158,6 +158,72 @@ def test_paired_decodes_equal_sequential_decodes(B, dims):
         np.testing.assert_allclose(lse_x.cpu().numpy(), lse_y.cpu().numpy(), rtol=0, atol=4e-6)
 
 
+@pytest.mark.parametrize('B,pair,ragged', [(128, True, False), (100, True, True), (32, False, False), (48, False, True)])
+def test_fused_attention_cell_launch_equals_the_two_launches(B, pair, ragged):
+    """(r4) attn_a2c_cell_kernel - attention, in-launch hand-off of att_res inside a 32-row strip, att2ctx product + cell - leaves
+    exactly the bytes the two launches (attn_fwd_cols_kernel, a2c_cell_fused_kernel) leave: token ids, log-probs and the whole
+    workspace of saved activations.  The two-launch form is what a process that declared its GPU shared runs (device_shared).
+    B = 128 paired: 256 workgroups, a strip's rows and tiles on one XCD; B = 100 (a pair of that size runs as two decodes): 100 attention rows, 128 cell tiles, a
+    partial last strip; single decodes of 32 / 48 rows; ragged region counts (att_masks)."""
+    from cooperativeimagecaptioning_amd import engine, _lib, status
+    K, D, H, V, T = 36, 64, 512, 9487, 16
+    g = torch.Generator().manual_seed(500 + B)
+
+    def lin(o, i, s=1.0):
+        r = s / np.sqrt(i)
+        return ((torch.rand(o, i, generator=g) * 2 - 1) * r).cuda(), ((torch.rand(o, generator=g) * 2 - 1) * r).cuda()
+    W = {'embed.0.weight': torch.randn(V + 2, H, generator=g).cuda()}
+    for nm, (o, i, s) in {'att_embed.0': (H, D, 1), 'logit': (V + 1, H, 6), 'ctx2att': (H, H, 1), 'core.a2c': (2 * H, H, 1),
+                          'core.i2h': (5 * H, H, 1), 'core.h2h': (5 * H, H, 1), 'core.attention.h2att': (H, H, 1),
+                          'core.attention.alpha_net': (1, H, 3)}.items():
+        W[nm + '.weight'], W[nm + '.bias'] = lin(o, i, s)
+    p = 0.5
+    d = engine.speaker_dims(B, K, D, H, H, H, V, T, p)
+    params = engine.speaker_params(W)
+    att_pre = engine.speaker_att_embed_fwd(d, params, (torch.randn(B, K, D, generator=g).abs() * 0.5).cuda())
+    masks = None
+    if ragged:
+        n = torch.randint(20, K + 1, (B,), generator=g)
+        masks = (torch.arange(K)[None, :] < n[:, None]).float().cuda()
+
+    def noise():
+        return dict(att_keep=(torch.rand(B, K, H, generator=g) >= p).to(torch.uint8).cuda(),
+                    x_keep=(torch.rand(T + 1, B, H, generator=g) >= p).to(torch.uint8).cuda(),
+                    out_keep=(torch.rand(T + 1, B, H, generator=g) >= p).to(torch.uint8).cuda())
+    na, nb_ = noise(), noise()
+    U = torch.rand(T + 1, B, V + 1, generator=g).cuda()
+
+    def run(shared):
+        old = engine.DEVICE_SHARED[0]
+        engine.DEVICE_SHARED[0] = shared
+        try:
+            a = engine.speaker_decode_io(d, params, att_pre, _lib.SAMPLE_GUMBEL_ST, 1.0, U=U, want_stv=True, att_masks=masks, **na)
+            a['ws'].zero_()
+            if pair:
+                b = engine.speaker_decode_io(d, params, att_pre, _lib.SAMPLE_GREEDY, 1.0, att_masks=masks, **nb_)
+                b['ws'].zero_()
+                engine.speaker_decode_fwd_pair(d, params, a, b)      # (B = 100: two sequential decodes, row blocks need B % 32 == 0)
+            else:
+                b = None
+                engine.speaker_decode_launch(d, params, a)
+        finally:
+            engine.DEVICE_SHARED[0] = old
+        torch.cuda.synchronize()
+        return a, b
+    two = run(True)
+    one = run(False)
+    status.check(None, 'fused attention + cell launch')
+    tsync_b = ((((B + 15) // 16) * T * 3 + 1 + 3) // 4 * 4 * 4 + 255) // 256 * 256     # the hand-off counters (last in the workspace)
+    for x, y in zip(two, one):
+        if x is None:
+            continue
+        assert 0 < int(x['L']) <= T
+        for k in ('seq', 'L', 'slp', 'stv'):
+            if x[k] is not None:
+                assert torch.equal(x[k], y[k]), k
+        assert torch.equal(x['ws'][:-tsync_b], y['ws'][:-tsync_b]), 'saved activations'
+
+
 @pytest.mark.parametrize('B,dims', [(32, dict(K=36, D=64, H=512, V=9487, T=16)), (6, dict(K=9, D=32, H=64, V=199, T=16))])
 @pytest.mark.parametrize('mode', ['gumbel_st', 'multinomial'])
 def test_in_kernel_philox_noise_equals_the_materialised_uniform_stream(B, dims, mode):

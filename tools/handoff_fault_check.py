@@ -2,8 +2,8 @@
 """What happens when a hand-off inside a one-launch recurrence FAILS, and what a kernel that holds CUs beside one costs
 (development build: include/cic_dev.h).
 
-Part 1 - forced time-out, once per loop (listener GRU pass, its BPTT loop, speaker BPTT loop on a full-width joint step;
-the teacher-forced recurrence on a full-width MLE step): the spin bound is lowered to 2 ms and ONE workgroup of the loop is
+Part 1 - forced time-out, once per loop (listener GRU pass, its BPTT loop, speaker BPTT loop and the sampling decode's fused
+attention -> cell launches on a full-width joint step; the teacher-forced recurrence on a full-width MLE step): the spin bound is lowered to 2 ms and ONE workgroup of the loop is
 told never to count itself in (cic_debug_handoff_fault), so its partners give up.  Required: the loop's bit appears in the
 sticky status word; the clamp+Adam kernels SKIP their updates (weights, moments and step counters' buffers bit-equal to
 before the step, CIC_STATUS_UPDATE_SKIPPED set); train.LossLog raises CicError naming the loop; the whole step still ends
@@ -65,7 +65,7 @@ def main():
 
     # ---- part 1: forced time-outs ---------------------------------------------------------------------------------
     cases = (('gru_fwd', status.GRU_FWD, False), ('gru_bwd', status.GRU_BWD, False), ('bptt', status.BPTT, False),
-             ('teacher', status.TEACHER, True))
+             ('decode_step', status.DECODE_STEP, False), ('teacher', status.TEACHER, True))
     sets = {}
     for name, bit, mle in cases:
         if mle not in sets:
