@@ -36,11 +36,13 @@ __global__ __launch_bounds__(256) void prep_generated_kernel(const int32_t* __re
                                       const float* __restrict__ E, float* __restrict__ x_emb, int Ed) {
     // dense != 0 (soft caption rows): positions 1..T are embedded by a dense product added afterwards, so
     // their gather contributes nothing (val = 0)
-    // one wave per caption, lane j = token j (T <= 63; longer captions: lanes stride): one round trip per row instead of T
+    // one workgroup (4 waves) per caption, lane j = token j (T <= 63; longer captions: lanes stride): every wave reads the row (one
+    // round trip), wave 0 keeps the books, the T + 1 embedded rows are dealt over the four waves (was: one wave per caption walking
+    // its 17 rows one dependent gather after the other, 20 us)
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
     for (int i = gtid; i < nsync; i += gridDim.x * blockDim.x) sync[i] = 0u;    // hand-off counters of gru_seq_kernel
-    const int b = gtid >> 6, lane = threadIdx.x & 63;
-    if (b >= B) return;                                     // whole waves
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    if (b >= B) return;
     const int L = *Lp;
     int cnt = 0;
     int tok_l = 0;                 // this lane's position j = lane (captions of up to 63 tokens: the fused embedding's case)
@@ -49,15 +51,17 @@ __global__ __launch_bounds__(256) void prep_generated_kernel(const int32_t* __re
         const int tok = seq[(size_t)b * T + j];
         const int ti = (j < L && !dense) ? tok : 0;
         const float tv = dense ? 0.0f : ((j < L && stv) ? stv[(size_t)b * T + j] : 1.0f);
-        idx[(size_t)b * (T + 1) + 1 + j] = ti;
-        val[(size_t)b * (T + 1) + 1 + j] = tv;
+        if (wv == 0) {
+            idx[(size_t)b * (T + 1) + 1 + j] = ti;
+            val[(size_t)b * (T + 1) + 1 + j] = tv;
+        }
         if (j == lane) { tok_l = ti; val_l = tv; }
         if (j < L - 1 && tok > 0) ++cnt;
     }
     if (x_emb && T < 64) {
         // position p of the caption: p = 0 is <bos> (value 1), p >= 1 the token lane p-1 holds; time-major rows [p, b, :]
         const int E4 = Ed >> 2;
-        for (int p = 0; p <= T; ++p) {
+        for (int p = wv; p <= T; p += nwv) {
             const int tok = p == 0 ? bos : __shfl(tok_l, p - 1, 64);
             const float v = p == 0 ? 1.0f : __shfl(val_l, p - 1, 64);
             const f32x4* er = reinterpret_cast<const f32x4*>(E + (size_t)tok * Ed);
@@ -65,6 +69,7 @@ __global__ __launch_bounds__(256) void prep_generated_kernel(const int32_t* __re
             for (int c = lane; c < E4; c += 64) xr[c] = er[c] * v;
         }
     }
+    if (wv != 0) return;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
     if (lane == 0) {
@@ -970,7 +975,7 @@ static int listener_fwd_impl(const cic_listener_dims* dp, const cic_listener_par
     } else {
         CIC_REQUIRE(io->seq && io->L && Lp == d.T + 1);
         embedded = d.T < 64 && (E & 3) == 0;
-        hipLaunchKernelGGL(prep_generated_kernel, dim3(cic_cdiv(B, 4)), dim3(256), 0, st, io->seq, io->stv, io->L, B,
+        hipLaunchKernelGGL(prep_generated_kernel, dim3(B), dim3(256), 0, st, io->seq, io->stv, io->L, B,
                            d.T, d.V + 1, io->soft ? 1 : 0, w.idx, w.val, w.len, w.sync, w.nsync,
                            embedded ? p->embed_w : nullptr, embedded ? w.x_emb : nullptr, E);
     }

@@ -3,7 +3,7 @@
 clamp_adam launches (two per step), the last `steps` steps are kept (warm-up and the roofline timing loop after the
 timed region are left out), and the attention kernel is reported separately for the in-step launches.
 
-usage: trace_summary.py <kernel_trace.csv> <steps> [out.md] [sequence.txt]
+usage: trace_summary.py <kernel_trace.csv> <steps> [out.md] [sequence.txt] [clamp_adam launches per step: 2]
 sequence.txt: every launch of the last step in order (start offset, duration, gap since the previous kernel ended)."""
 import collections
 import csv
@@ -22,7 +22,8 @@ def main():
     ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), short(r['Kernel_Name']),
                  int(r['Grid_Size_X']) if 'Grid_Size_X' in r else 0) for r in rows)
     adam = [i for i, e in enumerate(ev) if e[2].startswith('clamp_adam')]
-    s0, s1 = adam[-2 * steps - 1] + 1, adam[-1] + 1
+    per = int(sys.argv[5]) if len(sys.argv) > 5 else 2          # (one agent trained: 1)
+    s0, s1 = adam[-per * steps - 1] + 1, adam[-1] + 1
     seg = ev[s0:s1]
     busy = sum(e[1] - e[0] for e in seg)
     span = seg[-1][1] - seg[0][0]
@@ -42,7 +43,7 @@ def main():
     if len(sys.argv) > 3:
         open(sys.argv[3], 'w').write(text + '\n')
     if len(sys.argv) > 4:
-        last = ev[adam[-3] + 1:adam[-1] + 1]
+        last = ev[adam[-per - 1] + 1:adam[-1] + 1]
         with open(sys.argv[4], 'w') as f:
             prev = last[0][0]
             for e in last:
