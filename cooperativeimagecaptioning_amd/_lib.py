@@ -123,7 +123,7 @@ class CiderdArgs(C.Structure):
 class ListenerDims(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('B', 'F', 'E', 'J', 'V', 'T', 'Lp')] + [
         ('margin', C.c_float), ('max_violation', C.c_int), ('no_imgnorm', C.c_int), ('use_abs', C.c_int),
-        ('pool', C.c_int)]
+        ('pool', C.c_int), ('compute_dtype', C.c_int)]
 
 
 LISTENER_PARAM_FIELDS = [

@@ -270,9 +270,19 @@ __global__ __launch_bounds__(KS * 64) void gru_step_fused_kernel(const float* __
 // step moves 64 KB of h rows per workgroup instead of 128.  The weight tile (3 gates x 32 units x J floats = 393 KB) is split:
 // GRUF_WR of a wave's 48 fragments in registers, the rest in LDS in fragment order.  Per element the arithmetic is unchanged
 // (same K slice per wave, same MFMA order, same cross-wave order), so the pass is still bit-identical to the per-step kernel.
+// BF (r4, cic_listener_dims.compute_dtype = bf16): the weight tile is held as bf16 MFMA fragments (v_mfma_f32_16x16x32_bf16: 24
+// fragments of 8 k per lane = 96 VGPRs, none in LDS), the strip's h rows are rounded to bf16 as they are loaded, accumulation, gate
+// arithmetic and everything stored stay f32: a step's products are 24 MFMAs of 16 cycles per wave instead of 192 of 32.  Same tiling,
+// hand-off and output order.
+typedef __bf16 lbf16x8_t __attribute__((ext_vector_type(8)));
+typedef float lf32x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ lbf16x8_t l_to_bf16x8(const f32x4 lo, const f32x4 hi) {
+    const lf32x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_convertvector(v, lbf16x8_t);       // round to nearest even; a NaN stays a NaN
+}
 constexpr int GRUF_WR = 33, GRUF_WL = 48 - GRUF_WR;
 constexpr size_t GRUF_LDS_BYTES = sizeof(float) * ((size_t)8 * GRUF_WL * 64 * 4 + 2 * 8 * 8 * 64);
-template <int GPS, int KS>
+template <int GPS, int KS, bool BF = false>
 __global__ __launch_bounds__(KS * 64) void gru_seq_kernel(float* __restrict__ h_all, const float* __restrict__ W,
                                                           const float* __restrict__ b_hh, const float* __restrict__ gi_all,
                                                           const int32_t* __restrict__ len, float* __restrict__ gh_all,
@@ -305,14 +315,24 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_kernel(float* __restrict__ h_
     unsigned* cnt = cnt_base + (size_t)(row0 / 16 + strip) * (Lp + 1);  // cnt[t]: workgroups of this strip that have published h_t
     const size_t slab = (size_t)B * J;
     // the weight tile, once: B fragments f = (gate g, unit tile ct, k group i) of this wave's K slice
-    f32x4 wf[WR];
+    f32x4 wf[BF ? 1 : WR];
+    lbf16x8_t wb[BF ? 24 : 1];                             // BF: fragment (gate g, unit tile ct, k-step j of 32): k = 128 ks + 32 j + 8 lq + 0..7
+    if (BF) {
 #pragma unroll
-    for (int f = 0; f < 48; ++f) {
-        const int g = f / 16, ct = (f / 8) & 1, i = f & 7;
-        const float* wrow = W + ((size_t)g * J + jt * 32 + 16 * ct + li) * J;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(wrow + 16 * (ks * GPS + i) + 4 * lq);
-        if (f < WR) wf[f < WR ? f : 0] = v;
-        else wl[(ks * WL + (f - WR)) * 64 + lane] = v;
+        for (int f = 0; f < 24; ++f) {
+            const int g = f / 8, ct = (f / 4) & 1, j = f & 3;
+            const float* q = W + ((size_t)g * J + jt * 32 + 16 * ct + li) * J + 128 * ks + 32 * j + 8 * lq;
+            wb[BF ? f : 0] = l_to_bf16x8(*reinterpret_cast<const f32x4*>(q), *reinterpret_cast<const f32x4*>(q + 4));
+        }
+    } else {
+#pragma unroll
+        for (int f = 0; f < 48; ++f) {
+            const int g = f / 16, ct = (f / 8) & 1, i = f & 7;
+            const float* wrow = W + ((size_t)g * J + jt * 32 + 16 * ct + li) * J;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(wrow + 16 * (ks * GPS + i) + 4 * lq);
+            if (f < WR) wf[(!BF && f < WR) ? f : 0] = v;
+            else wl[(ks * WL + (f - WR)) * 64 + lane] = v;
+        }
     }
     const float bh0 = b_hh[col], bh1 = b_hh[J + col], bh2 = b_hh[2 * J + col];
     float poison = 0.f;
@@ -340,24 +360,38 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_kernel(float* __restrict__ h_
             const int mc = min(m0 + li, row_end - 1);       // rows past the block repeat its last row: their sums are never stored
 #pragma unroll
             for (int i = 0; i < GPS; ++i) {
-                const int k = 16 * (ks * GPS + i) + 4 * lq;
+                // (BF: the same eight 16-byte loads per lane, as four runs of eight consecutive k: 128 ks + 32 j + 8 lq + 0..7)
+                const int k = BF ? 128 * ks + 32 * (i >> 1) + 8 * lq + 4 * (i & 1) : 16 * (ks * GPS + i) + 4 * lq;
                 af[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hsrc, (int)(((size_t)mc * J + k) * 4), 0, 16));
             }
             hp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hsrc, (int)(((size_t)orc * J + col) * 4), 0, 16));
             __builtin_amdgcn_sched_barrier(0);      // all of the wave's h rows are requested before the first MFMA waits
+            lbf16x8_t ab[BF ? 4 : 1];
+            if (BF) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ab[BF ? j : 0] = l_to_bf16x8(af[2 * j], af[2 * j + 1]);
+            }
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
                 f32x4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                if (BF) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[BF ? j : 0], wb[BF ? g * 8 + j : 0], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[BF ? j : 0], wb[BF ? g * 8 + 4 + j : 0], acc1, 0, 0, 0);
+                    }
+                } else {
 #pragma unroll
                 for (int i = 0; i < GPS; ++i) {
                     const int f0 = g * 16 + i, f1 = g * 16 + 8 + i;
-                    const f32x4 b0 = f0 < WR ? wf[f0 < WR ? f0 : 0] : wl[(ks * WL + (f0 < WR ? 0 : f0 - WR)) * 64 + lane];
-                    const f32x4 b1 = f1 < WR ? wf[f1 < WR ? f1 : 0] : wl[(ks * WL + (f1 < WR ? 0 : f1 - WR)) * 64 + lane];
+                    const f32x4 b0 = (!BF && f0 < WR) ? wf[(!BF && f0 < WR) ? f0 : 0] : wl[(ks * WL + (f0 < WR ? 0 : f0 - WR)) * 64 + lane];
+                    const f32x4 b1 = (!BF && f1 < WR) ? wf[(!BF && f1 < WR) ? f1 : 0] : wl[(ks * WL + (f1 < WR ? 0 : f1 - WR)) * 64 + lane];
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], b0[s], acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], b1[s], acc1, 0, 0, 0);
                     }
+                }
                 }
                 float* rb = red + (g & 1) * (KS * 8 * 64);
 #pragma unroll
@@ -419,7 +453,9 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_kernel(float* __restrict__ h_
 // nor the product runs (the same decision in every workgroup of the strip: it depends on the strip's lengths only).
 constexpr int GRUB_GPS = 24, GRUB_GR = 16, GRUB_GL = GRUB_GPS - GRUB_GR;       // k groups of 16 per wave: in registers / in LDS
 constexpr size_t GRUB_LDS_BYTES = sizeof(float) * ((size_t)8 * GRUB_GL * 2 * 64 * 4 + 8 * 8 * 64);
-template <int KS>   // 3J = 16 * GRUB_GPS * KS
+// BF (r4): as gru_seq_kernel's - the wave's 384 k of the weight columns as 12 x 2 bf16 fragments (96 VGPRs, none in LDS), the strip's
+// dgh rows rounded to bf16 as they are loaded (chunks of four k-steps, two in flight), f32 accumulation and gate arithmetic.
+template <int KS, bool BF = false>   // 3J = 16 * GRUB_GPS * KS
 __global__ __launch_bounds__(KS * 64) void gru_seq_bwd_kernel(const float* __restrict__ h_all, const float* __restrict__ W,
                                                               const float* __restrict__ gi_all, const float* __restrict__ gh_all,
                                                               const int32_t* __restrict__ len, const float* __restrict__ dh_init,
@@ -461,17 +497,33 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_bwd_kernel(const float* __res
     __syncthreads();
     if (tid < 16) atomicMax(&smax_s, len[min(m0 + tid, row_end - 1)]);
     // the weight tile, once: B fragments (k = 16*group + 4*lq + s, n = column li of tile ct) of this wave's K slice
-    f32x4 wf[GR][2];
+    f32x4 wf[BF ? 1 : GR][2];
+    constexpr int JSB = GPS / 2;                          // BF: k-steps of 32 per wave (12): k = 384 ks + 32 j + 8 lq + 0..7
+    lbf16x8_t wb[BF ? JSB : 1][2];
+    if (BF) {
 #pragma unroll
-    for (int i = 0; i < GPS; ++i) {
+        for (int j = 0; j < JSB; ++j) {
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            const float* wk = W + (size_t)(16 * (ks * GPS + i) + 4 * lq) * J + jt * 32 + 16 * ct + li;
-            f32x4 v;
+            for (int ct = 0; ct < 2; ++ct) {
+                const float* wk = W + (size_t)(16 * GPS * ks + 32 * j + 8 * lq) * J + jt * 32 + 16 * ct + li;
+                f32x4 lo, hi;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) v[s] = wk[(size_t)s * J];
-            if (i < GR) wf[i < GR ? i : 0][ct] = v;
-            else wl[((ks * GL + (i - GR)) * 2 + ct) * 64 + lane] = v;
+                for (int e = 0; e < 4; ++e) { lo[e] = wk[(size_t)e * J]; hi[e] = wk[(size_t)(4 + e) * J]; }
+                wb[BF ? j : 0][ct] = l_to_bf16x8(lo, hi);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < GPS; ++i) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const float* wk = W + (size_t)(16 * (ks * GPS + i) + 4 * lq) * J + jt * 32 + 16 * ct + li;
+                f32x4 v;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) v[s] = wk[(size_t)s * J];
+                if (i < GR) wf[(!BF && i < GR) ? i : 0][ct] = v;
+                else wl[((ks * GL + (i - GR)) * 2 + ct) * 64 + lane] = v;
+            }
         }
     }
     __syncthreads();
@@ -548,6 +600,31 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_bwd_kernel(const float* __res
         if (!ok_s) poison = __builtin_nanf("");
         GRU_STAMP(3);
         const int mc = min(m0 + li, row_end - 1);           // rows past the block repeat its last row: their sums are never stored
+        f32x4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if (BF) {
+            // chunks of four k-steps (eight 16-byte loads per lane), two chunks in flight
+            constexpr int CS = 4, NCB = JSB / CS;
+            f32x4 ab[2][2 * CS];
+            auto load_chunk_b = [&](int c) {                // every load of the handed-off bytes is sc1 (aux 16)
+#pragma unroll
+                for (int i = 0; i < 2 * CS; ++i) {
+                    const int k = 16 * GPS * ks + 32 * (c * CS + (i >> 1)) + 8 * lq + 4 * (i & 1);
+                    ab[c & 1][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hdst, (int)(((size_t)mc * J3 + k) * 4), 0, 16));
+                }
+            };
+            load_chunk_b(0);
+            load_chunk_b(1);
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) {
+#pragma unroll
+                for (int jj = 0; jj < CS; ++jj) {
+                    const lbf16x8_t a8 = l_to_bf16x8(ab[c & 1][2 * jj], ab[c & 1][2 * jj + 1]);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, wb[BF ? c * CS + jj : 0][0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, wb[BF ? c * CS + jj : 0][1], acc1, 0, 0, 0);
+                }
+                if (c + 2 < NCB) load_chunk_b(c + 2);       // into the registers this chunk's MFMAs have just read
+            }
+        }
         f32x4 af[NBUF][GPC];
         auto load_chunk = [&](int c) {                      // every load of the handed-off bytes is sc1 (aux 16)
 #pragma unroll
@@ -556,16 +633,15 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_bwd_kernel(const float* __res
                 af[c % NBUF][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hdst, (int)(((size_t)mc * J3 + k) * 4), 0, 16));
             }
         };
-        f32x4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < NBUF; ++c) load_chunk(c);
+        for (int c = 0; c < NBUF && !BF; ++c) load_chunk(c);
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
+        for (int c = 0; c < NCH && !BF; ++c) {
 #pragma unroll
             for (int i = 0; i < GPC; ++i) {
                 const int gidx = c * GPC + i;
                 f32x4 b0, b1;
-                if (gidx < GR) { b0 = wf[gidx < GR ? gidx : 0][0]; b1 = wf[gidx < GR ? gidx : 0][1]; }
+                if (!BF && gidx < GR) { b0 = wf[(!BF && gidx < GR) ? gidx : 0][0]; b1 = wf[(!BF && gidx < GR) ? gidx : 0][1]; }
                 else {
                     b0 = wl[((ks * GL + (gidx - GR)) * 2 + 0) * 64 + lane];
                     b1 = wl[((ks * GL + (gidx - GR)) * 2 + 1) * 64 + lane];
@@ -963,6 +1039,10 @@ static int listener_fwd_impl(const cic_listener_dims* dp, const cic_listener_par
     CIC_REQUIRE(ws_bytes >= w.bytes);
     CIC_REQUIRE(io->fc_feats && io->loss_rows && io->loss_sum);
     hipStream_t st = cic_s(s);
+    // compute_dtype bf16: the text encoder's batched products on one bf16 part, its GRU pass on bf16 fragments; the image encoder, the
+    // similarity matrix and the loss stay f32
+    const bool bf = d.compute_dtype == CIC_DTYPE_BF16;
+    const GemmCtx stb(st, bf ? CIC_PRECISION_BF16 : CIC_PRECISION_F32);
     const int B = d.B, J = d.J, E = d.E, Lp = d.Lp;
     int rc;
 #define RUN(x) if ((rc = (x)) != 0) return rc
@@ -992,9 +1072,9 @@ static int listener_fwd_impl(const cic_listener_dims* dp, const cic_listener_par
     }
     if (io->soft && !io->labels) {
         // soft caption rows: x_emb[1..T] += soft @ embed[0:V+1]          (VSEFCModel.py:102-104)
-        RUN(gemm_nn_fwd(io->soft, d.V + 1, p->embed_w, E, w.x_emb + (size_t)B * E, E, (Lp - 1) * B, E, d.V + 1, true, st));
+        RUN(gemm_nn_fwd(io->soft, d.V + 1, p->embed_w, E, w.x_emb + (size_t)B * E, E, (Lp - 1) * B, E, d.V + 1, true, stb));
     }
-    RUN(gemm_nt(w.x_emb, E, p->w_ih, E, w.gi_all, 3 * J, Lp * B, 3 * J, E, p->b_ih, false, false, st));
+    RUN(gemm_nt(w.x_emb, E, p->w_ih, E, w.gi_all, 3 * J, Lp * B, 3 * J, E, p->b_ih, false, false, stb));
     const bool fused_step = g_gru_fused && J == 1024;       // the flagship width: one launch per step (see the kernel)
     bool seq_kernel = false;
     int seq_rows = 0;
@@ -1002,20 +1082,28 @@ static int listener_fwd_impl(const cic_listener_dims* dp, const cic_listener_par
         // the one-launch form needs every workgroup resident at once: one per CU (512 threads holding the weight tile in
         // ~200 VGPRs each fill a CU's register file)
         static DeviceOnce attr_set;
-        if (attr_set.first())
-            CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_kernel<8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (attr_set.first()) {
+            CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_kernel<8, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)GRUF_LDS_BYTES));
-        const int cus = cic_resident_cus(reinterpret_cast<const void*>(&gru_seq_kernel<8, 8>), 512, GRUF_LDS_BYTES);
+            CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_kernel<8, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)GRUF_LDS_BYTES));
+        }
+        const int cus = bf ? cic_resident_cus(reinterpret_cast<const void*>(&gru_seq_kernel<8, 8, true>), 512, GRUF_LDS_BYTES)
+                           : cic_resident_cus(reinterpret_cast<const void*>(&gru_seq_kernel<8, 8, false>), 512, GRUF_LDS_BYTES);
         seq_rows = (cus / (J / 32)) * 16;            // rows one launch can walk with every workgroup resident
         seq_kernel = seq_rows >= 16;
     }
     if (seq_kernel) {
         for (int row0 = 0; row0 < B; row0 += seq_rows) {      // (B = 128: one launch; B = 256: two row blocks)
             const int row_end = row0 + seq_rows < B ? row0 + seq_rows : B;
-            hipLaunchKernelGGL((gru_seq_kernel<8, 8>), dim3(cic_cdiv(row_end - row0, 16) * (J / 32)), dim3(512), GRUF_LDS_BYTES, st, w.h_all,
-                               p->w_hh, p->b_hh, w.gi_all, w.len, w.gh_all, w.sync,
-                               handoff_guard(w.sync + 2 * (size_t)cic_cdiv(B, 16) * (Lp + 1), io->status, CIC_STATUS_GRU_FWD), B, J, Lp,
-                               row0, row_end);
+            const HandoffGuard hg = handoff_guard(w.sync + 2 * (size_t)cic_cdiv(B, 16) * (Lp + 1), io->status, CIC_STATUS_GRU_FWD);
+            const dim3 grid(cic_cdiv(row_end - row0, 16) * (J / 32));
+            if (bf)
+                hipLaunchKernelGGL((gru_seq_kernel<8, 8, true>), grid, dim3(512), GRUF_LDS_BYTES, st, w.h_all, p->w_hh, p->b_hh, w.gi_all, w.len,
+                                   w.gh_all, w.sync, hg, B, J, Lp, row0, row_end);
+            else
+                hipLaunchKernelGGL((gru_seq_kernel<8, 8, false>), grid, dim3(512), GRUF_LDS_BYTES, st, w.h_all, p->w_hh, p->b_hh, w.gi_all, w.len,
+                                   w.gh_all, w.sync, hg, B, J, Lp, row0, row_end);
             CIC_LAUNCH_CHECK();
         }
     } else {
@@ -1066,6 +1154,8 @@ static int listener_bwd_impl(const cic_listener_dims* dp, const cic_listener_par
     CIC_REQUIRE(ws_bytes >= w.bytes);
     CIC_REQUIRE(bio->g_rows || bio->g_scalar);
     hipStream_t st = cic_s(s);
+    const bool bf = d.compute_dtype == CIC_DTYPE_BF16;      // (see listener_fwd_impl)
+    const GemmCtx stb(st, bf ? CIC_PRECISION_BF16 : CIC_PRECISION_F32);
     const int B = d.B, J = d.J, E = d.E, Lp = d.Lp;
     const cic_listener_params* g = bio->grads;   // may be NULL: no parameter gradients wanted
     int rc;
@@ -1093,10 +1183,14 @@ static int listener_bwd_impl(const cic_listener_dims* dp, const cic_listener_par
     if (g_gru_fused >= 2 && J == 1024 && !io->device_shared) {
         // as in the forward pass: every workgroup resident at once, one per CU
         static DeviceOnce attr_set;
-        if (attr_set.first())
-            CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_bwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (attr_set.first()) {
+            CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_bwd_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)GRUB_LDS_BYTES));
-        const int cus = cic_resident_cus(reinterpret_cast<const void*>(&gru_seq_bwd_kernel<8>), 512, GRUB_LDS_BYTES);
+            CIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_bwd_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)GRUB_LDS_BYTES));
+        }
+        const int cus = bf ? cic_resident_cus(reinterpret_cast<const void*>(&gru_seq_bwd_kernel<8, true>), 512, GRUB_LDS_BYTES)
+                           : cic_resident_cus(reinterpret_cast<const void*>(&gru_seq_bwd_kernel<8, false>), 512, GRUB_LDS_BYTES);
         seq_rows = (cus / (J / 32)) * 16;
         seq_kernel = seq_rows >= 16;
     }
@@ -1104,9 +1198,16 @@ static int listener_bwd_impl(const cic_listener_dims* dp, const cic_listener_par
         unsigned* cnt_b = w.sync + (size_t)cic_cdiv(B, 16) * (Lp + 1);
         for (int row0 = 0; row0 < B; row0 += seq_rows) {
             const int row_end = row0 + seq_rows < B ? row0 + seq_rows : B;
-            hipLaunchKernelGGL((gru_seq_bwd_kernel<8>), dim3(cic_cdiv(row_end - row0, 16) * (J / 32)), dim3(512), GRUB_LDS_BYTES, st, w.h_all,
-                               p->w_hh, w.gi_all, w.gh_all, w.len, dh, w.dgi_all, w.dgh_all, cnt_b,
-                               handoff_guard(cnt_b + (size_t)cic_cdiv(B, 16) * (Lp + 1), io->status, CIC_STATUS_GRU_BWD), B, J, Lp, d.pool, w.d_pool, w.pool_arg, E <= J ? w.dx_emb : nullptr, E, row0, row_end);
+            const HandoffGuard hg = handoff_guard(cnt_b + (size_t)cic_cdiv(B, 16) * (Lp + 1), io->status, CIC_STATUS_GRU_BWD);
+            const dim3 grid(cic_cdiv(row_end - row0, 16) * (J / 32));
+            if (bf)
+                hipLaunchKernelGGL((gru_seq_bwd_kernel<8, true>), grid, dim3(512), GRUB_LDS_BYTES, st, w.h_all, p->w_hh, w.gi_all, w.gh_all, w.len,
+                                   dh, w.dgi_all, w.dgh_all, cnt_b, hg, B, J, Lp, d.pool, w.d_pool, w.pool_arg, E <= J ? w.dx_emb : nullptr, E,
+                                   row0, row_end);
+            else
+                hipLaunchKernelGGL((gru_seq_bwd_kernel<8, false>), grid, dim3(512), GRUB_LDS_BYTES, st, w.h_all, p->w_hh, w.gi_all, w.gh_all, w.len,
+                                   dh, w.dgi_all, w.dgh_all, cnt_b, hg, B, J, Lp, d.pool, w.d_pool, w.pool_arg, E <= J ? w.dx_emb : nullptr, E,
+                                   row0, row_end);
             CIC_LAUNCH_CHECK();
         }
     }
@@ -1121,25 +1222,25 @@ static int listener_bwd_impl(const cic_listener_dims* dp, const cic_listener_par
         float* tmp = dh; dh = dh2; dh2 = tmp;
     }
     if (g) {
-        RUN(gemm_tn(w.dgh_all, 3 * J, w.h_all, J, g->w_hh, J, 3 * J, J, Lp * B, true, st, g->b_hh));
-        RUN(gemm_tn(w.dgi_all, 3 * J, w.x_emb, E, g->w_ih, E, 3 * J, E, Lp * B, true, st, g->b_ih));
+        RUN(gemm_tn(w.dgh_all, 3 * J, w.h_all, J, g->w_hh, J, 3 * J, J, Lp * B, true, stb, g->b_hh));
+        RUN(gemm_tn(w.dgi_all, 3 * J, w.x_emb, E, g->w_ih, E, 3 * J, E, Lp * B, true, stb, g->b_ih));
     }
     if ((g && g->embed_w) || bio->d_onehot) {
         // dx_emb = dgi W_ih            [Lp*B, 3J] x [3J, E]
-        RUN(gemm_nn(w.dgi_all, 3 * J, p->w_ih, E, w.dx_emb, E, Lp * B, E, 3 * J, false, st, true, seq_kernel && E <= J));   // (cleared by the BPTT kernel)
+        RUN(gemm_nn(w.dgi_all, 3 * J, p->w_ih, E, w.dx_emb, E, Lp * B, E, 3 * J, false, stb, true, seq_kernel && E <= J));   // (cleared by the BPTT kernel)
         if (g && g->embed_w) {
             const int64_t n = (int64_t)Lp * B * E;
             hipLaunchKernelGGL(embed_st_bwd_kernel, dim3(cic_cdiv(n, 256)), dim3(256), 0, st, w.dx_emb, w.idx, w.val,
                                w.len, g->embed_w, B, Lp, E);
             CIC_LAUNCH_CHECK();
             if (io->soft && !io->labels)   // dense rows: d embed[0:V+1] += soft^T dx_emb[1..T]
-                RUN(gemm_tn(io->soft, d.V + 1, w.dx_emb + (size_t)B * E, E, g->embed_w, E, d.V + 1, E, (Lp - 1) * B, true, st));
+                RUN(gemm_tn(io->soft, d.V + 1, w.dx_emb + (size_t)B * E, E, g->embed_w, E, d.V + 1, E, (Lp - 1) * B, true, stb));
         }
         if (bio->d_onehot) {
             // straight-through path back to the speaker: d one_hot[t,b,0:V+1] = dx_emb[t,b,:] E[0:V+1,:]^T for the
             // generated positions t = 1..T (position 0 is <bos>); time-major [T,B,V+1]   (VSEFCModel.py:104)
             RUN(gemm_nt(w.dx_emb + (size_t)B * E, E, p->embed_w, E, bio->d_onehot, d.V + 1, (Lp - 1) * B, d.V + 1, E,
-                        nullptr, false, false, st));
+                        nullptr, false, false, stb));
         }
     }
 #undef RUN

@@ -216,11 +216,12 @@ def speaker_beam_search(dims, params, att_pre, beam, att_masks=None, decoding_co
     return out
 
 
-def listener_dims(B, F, E, J, V, T, Lp, margin=0.2, max_violation=1, no_imgnorm=0, use_abs=0, pool='last'):
+def listener_dims(B, F, E, J, V, T, Lp, margin=0.2, max_violation=1, no_imgnorm=0, use_abs=0, pool='last', compute_dtype='f32'):
     d = ListenerDims()
     d.B, d.F, d.E, d.J, d.V, d.T, d.Lp = B, F, E, J, V, T, Lp
     d.margin, d.max_violation, d.no_imgnorm, d.use_abs = float(margin), int(max_violation), int(no_imgnorm), int(use_abs)
     d.pool = {'mean': 1, 'max': 2}.get(pool, 0)
+    d.compute_dtype = {'f32': 0, 'bf16': 1}[compute_dtype]
     return d
 
 

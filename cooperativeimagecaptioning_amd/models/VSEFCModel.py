@@ -77,6 +77,8 @@ class VSEFCModel(nn.Module):
         self.embed_size = opt.vse_embed_size
         self.vocab_size = opt.vocab_size
         self.seq_length = opt.seq_length
+        # 'bf16': the reduced-precision variant (cic.h, cic_listener_dims.compute_dtype); 'f32': the reference's arithmetic
+        self.compute_dtype = getattr(opt, 'compute_dtype', 'f32') or 'f32'
         self._loss = {}
         self._flat = None
         self._ws = {}
@@ -94,7 +96,7 @@ class VSEFCModel(nn.Module):
         return engine.listener_dims(B, self.img_enc.fc_feat_size, e.input_encoding_size, self.embed_size,
                                     self.vocab_size, self.seq_length, Lp, self.margin,
                                     self.contrastive_loss.max_violation, self.img_enc.no_imgnorm, self.img_enc.use_abs,
-                                    pool=e.pool_type)
+                                    pool=e.pool_type, compute_dtype=self.compute_dtype)
 
     def run(self, fc_feats, labels=None, masks=None, decode=None, only_one_retrieval='off', slot=0, want_emb=False):
         """Forward on the device.  Captions come either from ground-truth ``labels``/``masks`` or from a

@@ -473,6 +473,9 @@ typedef struct {
     int no_imgnorm;      /* vse_no_imgnorm */
     int use_abs;         /* vse_use_abs */
     int pool;            /* vse_pool_type: 0 'last' (the scripts' setting), 1 'mean', 2 'max' (VSEFCModel.py:118-129) */
+    int compute_dtype;   /* (r4) CIC_DTYPE_F32 (0) / CIC_DTYPE_BF16: as cic_speaker_dims.compute_dtype - the reduced-precision variant
+                            runs the GRU pass and its BPTT loop on bf16 MFMA fragments and the batched products of the text encoder on
+                            one bf16 part, f32 accumulation; image encoder, similarities, contrastive loss and all stored values f32 */
 } cic_listener_dims;
 
 typedef struct {

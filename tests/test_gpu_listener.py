@@ -122,3 +122,47 @@ def test_listener_pooling_modes(name, pool):
     for k in grads:
         ref = P[k].grad.numpy()
         np.testing.assert_allclose(grads[k].cpu().numpy(), ref, rtol=2e-4, atol=2e-4 * np.abs(ref).mean() + 1e-8, err_msg=k)
+
+
+def test_listener_bf16_variant_full_size_vs_f32():
+    """(r4) cic_listener_dims.compute_dtype = bf16 at the flagship widths: the GRU pass and its BPTT loop on bf16 MFMA fragments
+    (gru_seq_kernel<8, 8, true>, gru_seq_bwd_kernel<8, true>), the text encoder's batched products on one bf16 part; image
+    encoder, similarities and loss f32.  Against the f32 engine on the same inputs (ragged generated captions): loss 2e-3,
+    every parameter gradient and the straight-through gradient within 3e-2 of its norm - the variant's tolerance."""
+    from cooperativeimagecaptioning_amd import engine, status
+    B, J, E, F, V, T = 128, 1024, 512, 2048, 9487, 16
+    g = torch.Generator().manual_seed(77)
+    r = 2.0 / np.sqrt(J)                                # nn.GRU's own initialisation: U(-1/sqrt(J), 1/sqrt(J))
+    W = {'img_enc.fc.weight': torch.randn(J, F, generator=g) * 0.05, 'img_enc.fc.bias': torch.randn(J, generator=g) * .1,
+         'txt_enc.embed.weight': (torch.rand(V + 2, E, generator=g) - .5) * .2,
+         'txt_enc.rnn.weight_ih_l0': (torch.rand(3 * J, E, generator=g) - .5) * r,
+         'txt_enc.rnn.weight_hh_l0': (torch.rand(3 * J, J, generator=g) - .5) * r,
+         'txt_enc.rnn.bias_ih_l0': (torch.rand(3 * J, generator=g) - .5) * r,
+         'txt_enc.rnn.bias_hh_l0': (torch.rand(3 * J, generator=g) - .5) * r}
+    Wd = {k: v.cuda().contiguous() for k, v in W.items()}
+    params = engine.listener_params(Wd)
+    fc = torch.randn(B, F, generator=g).abs().cuda()
+    seq = torch.randint(1, V + 1, (B, T), generator=g)
+    for b in range(B):
+        seq[b, int(torch.randint(2, T + 1, (1,), generator=g)):] = 0
+    seq = seq.int().cuda()
+    stv = torch.ones(B, T).cuda()
+    L = torch.tensor([T], dtype=torch.int32).cuda()
+    out = {}
+    for dt in ('f32', 'bf16'):
+        dims = engine.listener_dims(B, F, E, J, V, T, T + 1, 0.2, 1, compute_dtype=dt)
+        f = engine.listener_fwd(dims, params, fc, seq=seq, stv=stv, L=L)
+        grads = {k: torch.zeros_like(v) for k, v in Wd.items()}
+        d_onehot = torch.zeros(T, B, V + 1).cuda()
+        engine.listener_bwd(dims, params, f, g_scalar=torch.ones(1).cuda(), grads=grads, d_onehot=d_onehot)
+        torch.cuda.synchronize()
+        out[dt] = (float(f['loss_sum']), {k: v.double().cpu() for k, v in grads.items()}, d_onehot.double().cpu())
+    status.check(None, 'bf16 listener')
+    l32, g32, d32 = out['f32']
+    l16, g16, d16 = out['bf16']
+    assert l16 != l32                                   # another arithmetic did run
+    np.testing.assert_allclose(l16, l32, rtol=2e-3)
+    errs = {k: float((g16[k] - g32[k]).norm() / g32[k].norm()) for k in g32}
+    errs['d_onehot'] = float((d16 - d32).norm() / d32.norm())
+    print('bf16 listener: loss', l16, l32, 'gradient errors', {k: round(v, 4) for k, v in errs.items()})
+    assert max(errs.values()) < 3e-2, errs
