@@ -23,7 +23,8 @@ def _free_port():
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize('extra', [['--small', '--batch', '8', '--steps', '3'], ['--batch', '32', '--steps', '2']])
+@pytest.mark.parametrize('extra', [['--small', '--batch', '8', '--steps', '3'], ['--batch', '32', '--steps', '2'],
+                                   ['--small', '--batch', '8', '--steps', '3', '--share-embed']])
 def test_two_ranks_equal_one_rank_accumulating_two_micro_batches(extra):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',

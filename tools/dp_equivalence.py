@@ -38,6 +38,7 @@ def main():
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--small', action='store_true', help='reduced widths (quick rehearsal); default: the flagship widths')
+    ap.add_argument('--share-embed', action='store_true', help='share_embed = 1: one table in both agents, its gradient in the listener bucket')
     args = ap.parse_args()
     world, rank = int(os.environ['WORLD_SIZE']), int(os.environ['RANK'])
     local_rank = 0 if args.same_device else int(os.environ.get('LOCAL_RANK', '0'))
@@ -56,6 +57,8 @@ def main():
     if args.small:
         kw.update(vocab_size=199, rnn_size=64, input_encoding_size=64, att_hid_size=64, fc_feat_size=128,
                   att_feat_size=128, vse_embed_size=128)
+    if args.share_embed:
+        kw.update(share_embed=1)
     rewards.init_scorer('corpus')
 
     def make():
@@ -91,7 +94,10 @@ def main():
     for s in range(args.steps):
         optim.zeroing_optimizer(opt, od, od['speaker'])
         fwd_bwd(model, opt, batch_of(opt, rank, s))
-        assert set(agents['listener']._pending) == {'all'} and set(agents['speaker']._pending) == {'logit'}, \
+        # share_embed: the speaker's backward still adds the shared table's gradient into the listener's segment, so the listener's
+        # bucket leaves after the whole backward pass (optimizer.overlap_gradient_exchange); the logit bucket leaves early either way
+        want_lst = set() if args.share_embed else {'all'}
+        assert set(agents['listener']._pending) == want_lst and set(agents['speaker']._pending) == {'logit'}, \
             'the early buckets did not leave from inside backward()'
         for o in agents.values():
             o.all_reduce_grads()                             # what step() does first; idempotent within a step
@@ -121,6 +127,8 @@ def main():
             for n, (off, p) in names.items():
                 if n.endswith('alpha_net.bias'):
                     continue        # a softmax shift: gradient mathematically 0, rounding noise on both sides
+                if off is None:
+                    continue        # share_embed: the table's gradient lives in (and is compared through) its owner's buffer
                 want = o.flat.grad[off:off + p.numel()].double()
                 got = dp_grads[s][a][off:off + p.numel()].double()
                 err = float((got - want).norm() / (want.norm() + 1e-30))
