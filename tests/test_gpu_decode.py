@@ -158,16 +158,18 @@ def test_paired_decodes_equal_sequential_decodes(B, dims):
         np.testing.assert_allclose(lse_x.cpu().numpy(), lse_y.cpu().numpy(), rtol=0, atol=4e-6)
 
 
-@pytest.mark.parametrize('B,pair,ragged', [(128, True, False), (100, True, True), (32, False, False), (48, False, True)])
-def test_fused_attention_cell_launch_equals_the_two_launches(B, pair, ragged):
+@pytest.mark.parametrize('B,pair,ragged,K', [(128, True, False, 36), (100, True, True, 36), (32, False, False, 36), (48, False, True, 36),
+                                             (32, True, False, 7), (64, False, True, 20), (32, False, False, 40)])
+def test_fused_attention_cell_launch_equals_the_two_launches(B, pair, ragged, K):
     """(r4) attn_a2c_cell_kernel - attention, in-launch hand-off of att_res inside a 32-row strip, att2ctx product + cell - leaves
     exactly the bytes the two launches (attn_fwd_cols_kernel, a2c_cell_fused_kernel) leave: token ids, log-probs and the whole
     workspace of saved activations.  The two-launch form is what a process that declared its GPU shared runs (device_shared).
     B = 128 paired: 256 workgroups, a strip's rows and tiles on one XCD; B = 100 (a pair of that size runs as two decodes): 100 attention rows, 128 cell tiles, a
-    partial last strip; single decodes of 32 / 48 rows; ragged region counts (att_masks)."""
+    partial last strip; single decodes of 32 / 48 rows; ragged region counts (att_masks); region counts 7 / 20 / 40 (the kernel's
+    other region-group instantiations)."""
     from cooperativeimagecaptioning_amd import engine, _lib, status
-    K, D, H, V, T = 36, 64, 512, 9487, 16
-    g = torch.Generator().manual_seed(500 + B)
+    D, H, V, T = 64, 512, 9487, 16
+    g = torch.Generator().manual_seed(500 + B + K)
 
     def lin(o, i, s=1.0):
         r = s / np.sqrt(i)
@@ -183,7 +185,7 @@ def test_fused_attention_cell_launch_equals_the_two_launches(B, pair, ragged):
     att_pre = engine.speaker_att_embed_fwd(d, params, (torch.randn(B, K, D, generator=g).abs() * 0.5).cuda())
     masks = None
     if ragged:
-        n = torch.randint(20, K + 1, (B,), generator=g)
+        n = torch.randint(max(1, K // 2), K + 1, (B,), generator=g)
         masks = (torch.arange(K)[None, :] < n[:, None]).float().cuda()
 
     def noise():
