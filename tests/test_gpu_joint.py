@@ -38,7 +38,7 @@ def decode_tags(cfg, turn, n):
 
 CASES = ['joint_gumbel', 'joint_gumbel_dropout', 'joint_gumbel_tau', 'joint_multinomial', 'joint_reinforce_gt',
          'joint_reinforce_greedy', 'joint_reinforce_no', 'joint_reinforce_listener', 'joint_gumbel_mle',
-         'joint_plain_all', 'joint_gumbel_ps', 'joint_multinomial_ps', 'masked_joint_gumbel', 'fullwidth_joint_gumbel', 'fullwidth_plain_all', 'fullwidth_reinforce_listener', 'fullwidth_reinforce_speaker', 'fullsize_joint_gumbel', 'fullsize_mle', 'fullsize_reinforce_speaker',
+         'joint_plain_all', 'joint_gumbel_ps', 'joint_multinomial_ps', 'masked_joint_gumbel', 'bn_masked_joint_gumbel', 'fullwidth_joint_gumbel', 'fullwidth_plain_all', 'fullwidth_reinforce_listener', 'fullwidth_reinforce_speaker', 'fullsize_joint_gumbel', 'fullsize_mle', 'fullsize_reinforce_speaker',
          'fc_joint_reinforce_gt', 'fc_joint_reinforce_greedy']      # fc_*: the fc-feature speaker under REINFORCE / CIDEr
 
 
@@ -55,6 +55,9 @@ def test_joint_step_matches_reference(name):
     model = models.AlternatingJointModel(opt)
     sd = {k: T_(v) for k, v in z['weights'].items()}
     model.load_state_dict(sd)
+    bns = [m_ for m_ in model.modules() if isinstance(m_, torch.nn.BatchNorm1d)]
+    for bn in bns:      # use_bn: the fixture's w.* buffers were read off AFTER the reference's step, which started from a fresh BatchNorm1d
+        bn.reset_running_stats()
     model.cuda().train()
     tags = decode_tags(cfg, turn, int(z['n_decodes']))
     model.caption_generator.noise.override = {t: GU.noise_dict(z, f'noise{i}') for i, t in enumerate(tags)}
@@ -89,6 +92,11 @@ def test_joint_step_matches_reference(name):
     for k, g in grads.items():
         if 'gdig.' + k not in z and g is not None:
             assert float(g.abs().max()) == 0.0, k
+    if bns:                 # use_bn: the running statistics after the step - one update per decode, as the reference's att_embed calls
+        sd_after = model.state_dict()
+        for k in z:
+            if k.startswith('after.'):
+                np.testing.assert_allclose(sd_after[k[6:]].cpu().numpy(), z[k], rtol=1e-5, atol=1e-6, err_msg=k)
     if 'tokens0' in z:      # full-width case (BASELINE widths, recorded from the reference): token ids bit for bit
         for tag, key in (('sample', 'tokens0'), ('greedy', 'tokens1')):
             if key not in z:

@@ -165,7 +165,7 @@ def test_ciderd_counts_quirks():
 JOINT_CASES = ['joint_gumbel', 'joint_gumbel_dropout', 'joint_gumbel_tau', 'joint_multinomial',
                'joint_gumbel_ps', 'joint_multinomial_ps', 'joint_reinforce_gt',
                'joint_reinforce_greedy', 'joint_reinforce_no', 'joint_reinforce_listener',
-               'joint_gumbel_mle', 'joint_plain_all', 'masked_joint_gumbel', 'fullwidth_joint_gumbel', 'fullwidth_plain_all', 'fullwidth_reinforce_listener', 'fullwidth_reinforce_speaker', 'fullsize_joint_gumbel', 'fullsize_mle', 'fullsize_reinforce_speaker',
+               'joint_gumbel_mle', 'joint_plain_all', 'masked_joint_gumbel', 'bn_masked_joint_gumbel', 'fullwidth_joint_gumbel', 'fullwidth_plain_all', 'fullwidth_reinforce_listener', 'fullwidth_reinforce_speaker', 'fullsize_joint_gumbel', 'fullsize_mle', 'fullsize_reinforce_speaker',
                'fc_joint_reinforce_gt', 'fc_joint_reinforce_greedy']   # fc_*: the fc-feature speaker under REINFORCE / CIDEr
 
 

@@ -654,7 +654,7 @@ def main():
     if '--only-statedict' in sys.argv:
         gen_state_dict_layout(torch, models)
         return
-    only_masks = '--only-masks' in sys.argv     # the att_masks cases only (other fixtures untouched)
+    only_masks = '--only-masks' in sys.argv or '--only-bn' in sys.argv     # the att_masks cases only (other fixtures untouched); --only-bn: the two use_bn cases only
     only_full = '--only-fullwidth' in sys.argv  # the BASELINE-width joint step only
     if '--only-retrieval' in sys.argv:
         gen_retrieval(torch)
@@ -887,12 +887,13 @@ def main():
     ]
     U_SEED = 4242
 
-    def joint_case(name, kw, turn, eos, masked=False, regen=False, K=7):
+    def joint_case(name, kw, turn, eos, masked=False, regen=False, K=7, seed=5):
         # regen (the full-width case): nothing large is stored.  Weights are the seeded draw (seed + digests), features
         # a seeded draw, the Gumbel uniforms come from a generator of their own (Recorder.inject); golden_util.load_case
         # redraws all three and checks the digests stored here.
         opt = make_opt(**kw)
-        m = build(opt, 5, None, store=not regen)
+        # (seed: a model with other state-dict keys - use_bn = 1 - takes a base-weight file of its own)
+        m = build(opt, seed, None, store=not regen)
         m.train()
         batch = make_batch(torch, opt, K=K, seed=5)
         if masked:
@@ -948,6 +949,10 @@ def main():
             del m.prev_vse, m.prev_caption_generator, m.prev_gradDic
         del shapes[:]
         del tokens[:]
+        # use_bn = 1: the scan above has ticked the running statistics; the recorded step starts from a fresh BatchNorm1d
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.reset_running_stats()
         torch.manual_seed(13)
         rec.inject = torch.Generator().manual_seed(U_SEED) if regen else None
         rec.start()
@@ -980,7 +985,12 @@ def main():
             except Exception:
                 pass
         print(name, 'loss', float(loss), 'ndecodes', len(decs), 'ngrads', len(grads))
-        feats = dict(fc=batch['fc_feats'], att_raw=batch['att_feats'])
+        # use_bn = 1: the running statistics AFTER the step (one update per decode that ran att_embed), and the flag
+        after = {'after.' + k: v.detach().numpy().copy() for k, v in m.state_dict().items()
+                 if not k.startswith('prev_') and ('running_' in k or 'num_batches' in k)}
+        if getattr(opt, 'use_bn', 0):
+            after['cfg.use_bn'] = np.float64(1)
+        feats = dict(fc=batch['fc_feats'], att_raw=batch['att_feats'], **after)
         if regen:
             B_, K_, D_ = batch['att_feats'].shape
             feats = {'regen.att': np.array([5, B_, K_, D_], np.int64), 'regen.att_rowscale': rowscale,
@@ -1049,6 +1059,7 @@ def main():
     JOINT_MASKED = [('masked_joint_gumbel', dict(retrieval_reward='gumbel', drop_prob_lm=0.5), 'speaker', 2.5)]
     if '--only-bn' in sys.argv:      # use_bn = 1 on ragged region counts (the only input the option can run on, AttModel.py:44-51,82-85)
         mle_case('bn_masked_mle', {'drop_prob_lm': 0.5, 'use_bn': 1}, 0.0, masked=True, seed=33)
+        joint_case('bn_masked_joint_gumbel', dict(retrieval_reward='gumbel', drop_prob_lm=0.5, use_bn=1), 'speaker', 2.5, masked=True, seed=55)
         return
     if not only_masks:
         kernel_cases()
@@ -1066,6 +1077,7 @@ def main():
         sample_case(name, rr, kw, opts_, eos, masked=True)
     mle_case('masked_mle', {'drop_prob_lm': 0.5}, 0.0, masked=True)
     mle_case('bn_masked_mle', {'drop_prob_lm': 0.5, 'use_bn': 1}, 0.0, masked=True, seed=33)
+    joint_case('bn_masked_joint_gumbel', dict(retrieval_reward='gumbel', drop_prob_lm=0.5, use_bn=1), 'speaker', 2.5, masked=True, seed=55)
     for name, kw, turn, eos in JOINT_MASKED:
         joint_case(name, kw, turn, eos, masked=True)
     gen_beam(torch, models, rec, BEAM_CASES_MASKED)
