@@ -1837,6 +1837,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform
     const int rt = w & 3, kh = w >> 2;                     // row tile, K half
     const int li = lane & 15, lq = lane >> 4;
+    // development build: [workgroup][wave][64] phase stamps (100 MHz): start, A fragments ready, first tile staged; per tile: k loop
+    // done, barrier passed; end (tools/ldsb_bf_stamps.py)
+    unsigned long long* stamps = CIC_STAMP_BUF(g_stamp_buf);
+    if (stamps) stamps += ((size_t)blockIdx.x * 8 + w) * 64;
+    int sidx = 0;
+    auto stamp = [&]() { if (stamps && lane == 0 && sidx < 62) stamps[sidx] = __builtin_amdgcn_s_memrealtime(); ++sidx; };
+    stamp();
     const int per_xcd = gridDim.x / 8;
     const int wg = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * per_xcd + blockIdx.x / 8 : blockIdx.x;
     const int rg = wg % row_groups, first = wg / row_groups;
@@ -1905,9 +1912,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (stamps) { asm volatile("" :: "v"(ap[0][0]), "v"(ap[NP - 1][JS - 1])); stamp(); }
 #pragma unroll
     for (int e = 0; e < NPC; ++e) store_piece(ldsh, e);
     __syncthreads();
+    stamp();
     int buf = 0;
     float prev[4];                                         // the previous tile's sums of this wave's K half
     int prev_n = -1;
@@ -2051,7 +2060,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             prev_n = n;
             prev_bias = bias_v;
+            if (stamps) { asm volatile("" :: "v"(prev[0]), "v"(prev[3])); stamp(); }
             __syncthreads();
+            stamp();
             buf ^= 1;
         }
         if (ROLE == 1) load_noise();
@@ -2101,6 +2112,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
 #undef RP_STEP
     }
+    if (stamps && lane == 0) stamps[63] = __builtin_amdgcn_s_memrealtime();
 }
 
 template <int NP>
